@@ -1,0 +1,203 @@
+/* rainbow_hip.h — C ABI of librainbow_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the Rainbow *learn step* hot path of
+ * Kaixhin/Rainbow (reference = /root/reference, Python only, no FFI of its own).
+ * The reference's boundary is the Python class surface consumed by main.py/test.py
+ * (SURVEY.md §8b); rainbow_amd/{memory,agent}.py keep that surface and forward to the
+ * entry points below through ctypes.  Every entry point cites the reference code it
+ * replaces as  file:line  relative to /root/reference.
+ *
+ * Conventions
+ *   - plain C types only; no torch types cross this boundary;
+ *   - every pointer named *_dev is a DEVICE pointer (HBM); *_host is host memory;
+ *   - every call returns 0 on success, <0 on error (rb_last_error() has the text);
+ *     nothing throws across the ABI;
+ *   - every launch takes an explicit stream (a hipStream_t passed as void*);
+ *     calls are asynchronous unless stated otherwise;
+ *   - replay/tree/activation memory is OWNED by the library; parameter, gradient and
+ *     noise memory is BORROWED from the caller (torch tensors' data_ptr());
+ *   - handles are thread-compatible, not thread-safe (one handle per host thread).
+ */
+#ifndef RAINBOW_HIP_H_
+#define RAINBOW_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB_OK 0
+#define RB_ERR_INVALID (-1)
+#define RB_ERR_HIP (-2)
+#define RB_ERR_OOM (-3)
+#define RB_ERR_STATE (-4)
+
+#define RB_FRAME_H 84
+#define RB_FRAME_W 84
+#define RB_FRAME_BYTES (84 * 84) /* memory.py:7 'state' u8[84,84] */
+
+typedef void* rb_stream_t; /* hipStream_t */
+typedef struct rb_replay rb_replay_t;
+typedef struct rb_learner rb_learner_t;
+
+const char* rb_last_error(void);
+int rb_abi_version(void);
+
+/* ===================================================================== replay ==
+ * HBM-resident prioritised replay: SoA ring (frames u8[C][7056], timestep i32[C],
+ * action i32[C], reward f32[C], nonterminal u8[C]) + level-order float32 sum-tree
+ * with the reference's truncated leaf level (memory.py:17-18).                  */
+
+/* Device-resident header; host reads it with rb_replay_header (synchronising).   */
+typedef struct {
+  int64_t index;   /* SegmentTree.index   memory.py:14,59 */
+  int32_t full;    /* SegmentTree.full    memory.py:16,60 */
+  float max;       /* SegmentTree.max     memory.py:20,48,54,61 (p^w domain) */
+  float total;     /* sum_tree[0]         memory.py:88-89 */
+  int32_t last_attempts; /* sampler attempts used by the last rb_replay_sample */
+  int32_t last_status;   /* 0 ok, 1 = gave up after max attempts */
+  uint64_t rng_counter;  /* Philox counter of the device sampler */
+} rb_replay_header_t;
+
+/* Raw device pointers, for state dump/restore and white-box tests.               */
+typedef struct {
+  float* sum_tree_dev;    int64_t tree_len;   /* tree_start + capacity */
+  int64_t tree_start;
+  uint8_t* frames_dev;    /* [capacity][7056] */
+  int32_t* timestep_dev;  int32_t* action_dev;
+  float* reward_dev;      uint8_t* nonterminal_dev;
+  rb_replay_header_t* header_dev;
+} rb_replay_buffers_t;
+
+/* ReplayMemory.__init__ + SegmentTree.__init__  (memory.py:92-102, 13-20).
+ * capacity must be even and >= 2 (odd capacities crash the reference). */
+int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32_t multi_step,
+                     double discount, double priority_exponent, uint64_t seed);
+int rb_replay_destroy(rb_replay_t* r);
+int rb_replay_buffers(rb_replay_t* r, rb_replay_buffers_t* out_host);
+/* synchronises `stream`, then copies the header to host */
+int rb_replay_header(rb_replay_t* r, rb_replay_header_t* out_host, rb_stream_t stream);
+
+/* ReplayMemory.append (memory.py:105-108) + SegmentTree.append (memory.py:56-61):
+ * quantises state_dev[history-1] (f32 in [0,1]) to u8 by x*255 truncation ON DEVICE,
+ * stores (timestep, frame, action, reward, nonterminal) at `index`, sets the leaf to
+ * the running max priority and walks the sums to the root.                        */
+int rb_replay_append(rb_replay_t* r, const float* state_dev, int32_t timestep, int32_t action,
+                     float reward, int32_t nonterminal, rb_stream_t stream);
+/* n sequential appends of already-quantised frames (same result as n calls of
+ * rb_replay_append: all leaves get the current max, memory.py:107).               */
+int rb_replay_append_batch(rb_replay_t* r, const uint8_t* frames_dev, const int32_t* timesteps_dev,
+                           const int32_t* actions_dev, const float* rewards_dev,
+                           const uint8_t* nonterminals_dev, int64_t n, rb_stream_t stream);
+
+/* SegmentTree.find (memory.py:64-82): float64 values against float32 nodes.       */
+int rb_replay_find(rb_replay_t* r, const double* values_dev, int32_t n, float* probs_dev,
+                   int64_t* data_idx_dev, int64_t* tree_idx_dev, rb_stream_t stream);
+
+/* ReplayMemory.sample (memory.py:124-155), entirely on device:
+ * stratified draw (+ whole-batch rejection, memory.py:128-132), tree search, window
+ * gather with episode-boundary blanking (memory.py:111-121), n-step return, IS weights.
+ * unit_uniforms_dev: NULL = device Philox; else [max_attempts][batch] float64 in [0,1)
+ *   (parity hook: the reference's np.random.uniform(0,seg) == seg*u, memory.py:129).
+ * Outputs (all device, caller-allocated):
+ *   tree_idx i64[B]; states/next_states u8[B][history][7056] (NOT yet /255);
+ *   actions i64[B]; returns f32[B]; nonterminals f32[B]; weights f32[B].
+ * Status lands in the device header (last_attempts/last_status).                   */
+int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight,
+                     const double* unit_uniforms_dev, int32_t max_attempts,
+                     int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                     int64_t* actions_dev, float* returns_dev, float* nonterminals_dev,
+                     float* weights_dev, rb_stream_t stream);
+
+/* SegmentTree.update (memory.py:44-48): raw leaf values, duplicates last-write-wins. */
+int rb_replay_update_leaves(rb_replay_t* r, const int64_t* tree_idx_dev, const float* values_dev,
+                            int32_t n, rb_stream_t stream);
+/* ReplayMemory.update_priorities (memory.py:157-159): p = loss^w, then the above.  */
+int rb_replay_update_priorities(rb_replay_t* r, const int64_t* tree_idx_dev,
+                                const float* losses_dev, int32_t n, rb_stream_t stream);
+
+/* ReplayMemory.__next__ (memory.py:167-178): blanked history stack for data index i,
+ * as f32 /255, out_dev f32[history][7056].                                          */
+int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_stream_t stream);
+
+/* u8 -> f32 x/255 (memory.py:137-138 `.div_(255)`), correctly-rounded division.    */
+int rb_u8_to_unit_f32(const uint8_t* src_dev, float* dst_dev, int64_t n, rb_stream_t stream);
+
+/* ==================================================================== learner ==
+ * Rainbow network (model.py) + learn step (agent.py:61-100) on flat f32 buffers.  */
+
+typedef struct {
+  int32_t batch;        /* args.batch_size      agent.py:20 */
+  int32_t atoms;        /* args.atoms           agent.py:15 */
+  int32_t actions;      /* env.action_space()   agent.py:14 */
+  int32_t history;      /* args.history_length  model.py:56 */
+  int32_t hidden;       /* args.hidden_size     model.py:64 */
+  int32_t architecture; /* 0 canonical, 1 data-efficient  model.py:55-63 */
+  int32_t multi_step;   /* args.multi_step      agent.py:21 */
+  float v_min, v_max;   /* agent.py:16-17 */
+  double discount;      /* agent.py:22 */
+} rb_learner_config_t;
+
+/* One named tensor inside the flat parameter/gradient buffer (state-dict names of
+ * model.py: convs.{0,2,4}.{weight,bias}, fc_*.{weight,bias}_{mu,sigma}).          */
+typedef struct {
+  char name[48];
+  int64_t offset; /* in floats */
+  int32_t ndim;
+  int32_t shape[4];
+} rb_tensor_desc_t;
+
+/* Sizes of the flat buffers (in floats) for a config.                              */
+int rb_learner_sizes(const rb_learner_config_t* cfg, int64_t* n_params, int64_t* n_noise);
+/* Fills descs[0..*n) ; pass descs=NULL to query the count.                         */
+int rb_learner_param_layout(const rb_learner_config_t* cfg, rb_tensor_desc_t* descs, int32_t* n);
+/* Noise buffer layout: factorised vectors f(eps) (model.py:32-40), per layer
+ * {name = fc_h_v.eps_in, fc_h_v.eps_out, ...}.                                      */
+int rb_learner_noise_layout(const rb_learner_config_t* cfg, rb_tensor_desc_t* descs, int32_t* n);
+
+int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float* online_params_dev,
+                      float* target_params_dev, float* grads_dev, float* online_noise_dev,
+                      float* target_noise_dev, uint64_t seed);
+int rb_learner_destroy(rb_learner_t* l);
+
+/* DQN.reset_noise (model.py:82-85, 36-40).  which: 0 online (agent.py:49-50),
+ * 1 target (agent.py:74).  raw_normals_dev: NULL = device Philox + Box-Muller;
+ * else N(0,1) draws in the reference's order (per layer randn(in) then randn(out);
+ * layers fc_h_v, fc_h_a, fc_z_v, fc_z_a) — parity hook.                             */
+int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev,
+                           rb_stream_t stream);
+int64_t rb_learner_noise_draws(const rb_learner_config_t* cfg);
+
+/* Agent.act / evaluate_q (agent.py:53-55, 110-112): single state f32[history][7056]
+ * in [0,1]; writes argmax action (i32) and its expected value (f32).
+ * noisy=0 is online_net.eval() (mu only, model.py:46).                              */
+int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_dev,
+                   float* q_dev, rb_stream_t stream);
+
+/* Agent.learn minus sampling/optimiser (agent.py:66-96): three forwards, double-Q
+ * select, C51 projection, weighted cross-entropy, full backward into grads_dev.
+ * Inputs are rb_replay_sample's outputs.  loss_dev f32[B] = per-sample CE (agent.py:94),
+ * i.e. the new raw priorities (agent.py:100).                                        */
+int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* next_states_dev,
+                     const int64_t* actions_dev, const float* returns_dev,
+                     const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
+                     rb_stream_t stream);
+
+/* clip_grad_norm_ (agent.py:97): global L2 norm of grads_dev, scale in place by
+ * max_norm/(norm+1e-6) when that is < 1.  norm_dev (f32[1], may be NULL) gets ||g||. */
+int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream);
+
+/* Agent.update_target_net (agent.py:102-103): params AND noise, device-to-device.   */
+int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream);
+
+/* White-box access for parity tests: copies an internal activation to out_dev.
+ * what: 0 log_ps_a [B][atoms], 1 m (projected target) [B][atoms], 2 argmax a* i32[B],
+ *       3 pns_a [B][atoms].                                                          */
+int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAINBOW_HIP_H_ */

@@ -1,0 +1,114 @@
+"""ctypes binding of librainbow_hip.so (C ABI declared in include/rainbow_hip.h).
+
+The library is hand-written HIP for gfx950; there is NO fallback: if the shared object is
+missing or does not load, importing the hot path raises.  `declare()` only attaches
+argtypes/restypes and is reused by tests/hipemu (the host-interpreted test build of the
+same sources) so both builds are checked against one signature table.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librainbow_hip.so")
+
+c_void_p, c_int, c_int32, c_int64, c_uint64 = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64
+c_float, c_double, c_char_p = C.c_float, C.c_double, C.c_char_p
+
+
+class ReplayHeader(C.Structure):
+    _fields_ = [("index", c_int64), ("full", c_int32), ("max", c_float), ("total", c_float),
+                ("last_attempts", c_int32), ("last_status", c_int32), ("rng_counter", c_uint64)]
+
+
+class ReplayBuffers(C.Structure):
+    _fields_ = [("sum_tree_dev", c_void_p), ("tree_len", c_int64), ("tree_start", c_int64),
+                ("frames_dev", c_void_p), ("timestep_dev", c_void_p), ("action_dev", c_void_p),
+                ("reward_dev", c_void_p), ("nonterminal_dev", c_void_p), ("header_dev", c_void_p)]
+
+
+class LearnerConfig(C.Structure):
+    _fields_ = [("batch", c_int32), ("atoms", c_int32), ("actions", c_int32), ("history", c_int32),
+                ("hidden", c_int32), ("architecture", c_int32), ("multi_step", c_int32),
+                ("v_min", c_float), ("v_max", c_float), ("discount", c_double)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("offset", c_int64), ("ndim", c_int32), ("shape", c_int32 * 4)]
+
+
+# name -> (restype, argtypes); every symbol include/rainbow_hip.h declares
+SIGNATURES = {
+    "rb_last_error": (c_char_p, []),
+    "rb_abi_version": (c_int, []),
+    "rb_replay_create": (c_int, [C.POINTER(c_void_p), c_int64, c_int32, c_int32, c_double, c_double, c_uint64]),
+    "rb_replay_destroy": (c_int, [c_void_p]),
+    "rb_replay_buffers": (c_int, [c_void_p, C.POINTER(ReplayBuffers)]),
+    "rb_replay_header": (c_int, [c_void_p, C.POINTER(ReplayHeader), c_void_p]),
+    "rb_replay_append": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
+    "rb_replay_append_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rb_replay_find": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rb_replay_sample": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rb_replay_update_leaves": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "rb_replay_update_priorities": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "rb_replay_state_at": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rb_u8_to_unit_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rb_learner_sizes": (c_int, [C.POINTER(LearnerConfig), C.POINTER(c_int64), C.POINTER(c_int64)]),
+    "rb_learner_param_layout": (c_int, [C.POINTER(LearnerConfig), C.POINTER(TensorDesc), C.POINTER(c_int32)]),
+    "rb_learner_noise_layout": (c_int, [C.POINTER(LearnerConfig), C.POINTER(TensorDesc), C.POINTER(c_int32)]),
+    "rb_learner_create": (c_int, [C.POINTER(c_void_p), C.POINTER(LearnerConfig), c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_uint64]),
+    "rb_learner_destroy": (c_int, [c_void_p]),
+    "rb_learner_reset_noise": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "rb_learner_noise_draws": (c_int64, [C.POINTER(LearnerConfig)]),
+    "rb_learner_act": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rb_learner_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "rb_learner_clip_grad": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
+    "rb_learner_sync_target": (c_int, [c_void_p, c_void_p]),
+    "rb_learner_debug_read": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+}
+
+
+def declare(lib, strict=True):
+    """Attach restype/argtypes for every declared symbol; raises if one is missing."""
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing and strict:
+        raise ImportError("librainbow: missing C-ABI symbols: %s" % ", ".join(missing))
+    return lib
+
+
+class RainbowError(RuntimeError):
+    pass
+
+
+def check(lib, rc):
+    if rc != 0:
+        msg = lib.rb_last_error()
+        raise RainbowError("librainbow_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+_lib = None
+
+
+def load():
+    """Loads librainbow_hip.so (torch first, so HIP symbols bind to the runtime PyTorch-ROCm
+    already initialised — both use SONAME libamdhip64.so.7).  Fails loudly; no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "rainbow_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path." % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64 from torch/lib)
+    _lib = declare(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+    return _lib

@@ -1,0 +1,57 @@
+// rb_device.h — the one place the kernels touch the platform.
+//
+// Product build: hipcc --offload-arch=gfx950 (CDNA4, wave64, MFMA, 160 KiB LDS).
+// The RB_HOST_INTERP branch is NOT a portability layer: it binds the same kernel
+// sources to tests/hipemu (a fiber-based host interpreter) so kernel logic can be
+// unit-tested in the GPU-less build container.  Nothing in the shipped library or
+// in the rainbow_amd package is ever built with RB_HOST_INTERP.
+#pragma once
+
+#if defined(RB_HOST_INTERP)
+#include "hipemu.h"
+#define RB_LAUNCH(kern, grid, block, stream, ...) \
+  hipemu::launch([&]() { kern(__VA_ARGS__); }, (grid), (block))
+#else
+#include <hip/hip_runtime.h>
+typedef float rb_f32x16 __attribute__((ext_vector_type(16)));
+typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
+#define RB_LAUNCH(kern, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+#include <stdint.h>
+
+#define RB_WAVE 64
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32), exact f32 fmaf chain.
+// Lane l supplies A[l&31][l>>5] and B[l>>5][l&31]; D[r] sits at
+// row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+__device__ __forceinline__ rb_f32x16 rb_mfma32(float a, float b, rb_f32x16 c) {
+#if defined(RB_HOST_INTERP)
+  return hipemu_mfma_f32_32x32x2f32(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ int rb_mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int rb_wave() { return (int)(threadIdx.x >> 6); }
+
+// wave64 butterfly reductions (all 64 lanes must call)
+__device__ __forceinline__ float rb_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float rb_wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ double rb_wave_sum_f64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}

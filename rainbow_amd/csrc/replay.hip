@@ -1,0 +1,636 @@
+// replay.hip — HBM-resident prioritised replay for MI355X (gfx950).
+//
+// What it replaces: the host-RAM numpy SegmentTree/ReplayMemory of the reference
+// (memory.py:12-180).  Layout here is SoA in HBM (frames u8[C][7056] + 4 small
+// columns) with the reference's level-order float32 sum-tree (same truncated leaf
+// level, memory.py:17-18) so tree indices are interchangeable with the reference's.
+//
+// Invariant used everywhere: every internal node equals fl32(left + right) of its
+// CURRENT children (memory.py:25,39), i.e. the tree is a pure function of its leaves.
+// Batched updates therefore rebuild ancestors level by level and land on exactly the
+// floats the reference's sequential walks produce.
+//
+// All of this is HBM-latency / HBM-bandwidth work (no GEMM shape anywhere): the frame
+// gather moves (h+n)·7056 B in and 2h·7056 B out per sample with 16-byte lanes, the tree
+// search is L dependent 4-byte loads per sample.
+#include "rb_common.h"
+
+#include <new>
+
+// -------------------------------------------------------------------------------
+struct rb_replay {
+  int64_t capacity;
+  int32_t history, n;
+  int32_t levels;       // L = depth of the leaf level
+  int64_t tree_start;   // 2^L - 1
+  int64_t tree_len;     // tree_start + capacity
+  double omega;         // priority exponent (memory.py:99)
+  uint64_t seed;
+  float scaling[64];    // gamma^k as float32(double pow)  (memory.py:101)
+  // device
+  float* tree;
+  uint8_t* frames;
+  int32_t* timestep;
+  int32_t* action;
+  float* reward;
+  uint8_t* nonterminal;
+  rb_replay_header_t* hdr;
+  int32_t* win;         // [max_batch][h+n] ring index of each window slot, -1 = blank
+  float* scaling_dev;
+  int32_t max_batch;
+  // host mirror of the deterministic part of the header
+  int64_t host_index;
+  int32_t host_full;
+};
+
+struct ReplayView {
+  int64_t capacity;
+  int32_t history, n, levels;
+  int64_t tree_start, tree_len;
+  float* tree;
+  uint8_t* frames;
+  int32_t* timestep;
+  int32_t* action;
+  float* reward;
+  uint8_t* nonterminal;
+  rb_replay_header_t* hdr;
+};
+
+static ReplayView view_of(const rb_replay* r) {
+  ReplayView v;
+  v.capacity = r->capacity; v.history = r->history; v.n = r->n; v.levels = r->levels;
+  v.tree_start = r->tree_start; v.tree_len = r->tree_len;
+  v.tree = r->tree; v.frames = r->frames; v.timestep = r->timestep; v.action = r->action;
+  v.reward = r->reward; v.nonterminal = r->nonterminal; v.hdr = r->hdr;
+  return v;
+}
+
+__device__ __forceinline__ int64_t rb_floor_mod(int64_t a, int64_t m) {
+  int64_t r = a % m;
+  return r < 0 ? r + m : r;
+}
+
+// ---------------------------------------------------------------- init / header --
+__global__ void k_replay_init(rb_replay_header_t* hdr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    hdr->index = 0;
+    hdr->full = 0;
+    hdr->max = 1.0f;  // memory.py:20  (1 = 1^w)
+    hdr->total = 0.0f;
+    hdr->last_attempts = 0;
+    hdr->last_status = 0;
+    hdr->rng_counter = 0;
+  }
+}
+
+// ---------------------------------------------------------------------- append --
+// One transition (memory.py:105-108 + 56-61).  One 256-thread workgroup: quantise and
+// store the frame with 4-byte packed writes, thread 0 walks the L sums to the root.
+__global__ __launch_bounds__(256) void k_append_one(ReplayView v, const float* last_frame, int32_t timestep,
+                                                     int32_t action, float reward, int32_t nonterminal) {
+  const int64_t idx = v.hdr->index;
+  const float prio = v.hdr->max;
+  __syncthreads();  // every thread has read the header before thread 0 rewrites it
+  uint32_t* dst = (uint32_t*)(v.frames + idx * RB_FRAME_BYTES);
+  for (int w = (int)threadIdx.x; w < RB_FRAME_BYTES / 4; w += (int)blockDim.x) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // state[-1].mul(255).to(uint8): f32 multiply, truncating conversion (memory.py:106)
+      const float x = __fmul_rn(last_frame[4 * w + j], 255.0f);
+      const uint32_t q = (uint32_t)(int32_t)x & 0xFFu;
+      packed |= q << (8 * j);
+    }
+    dst[w] = packed;
+  }
+  if (threadIdx.x == 0) {
+    v.timestep[idx] = timestep;
+    v.action[idx] = action;
+    v.reward[idx] = reward;
+    v.nonterminal[idx] = nonterminal ? 1 : 0;
+    int64_t node = idx + v.tree_start;
+    v.tree[node] = prio;  // memory.py:52
+    while (node != 0) {   // memory.py:36-41
+      const int64_t parent = (node - 1) / 2;
+      v.tree[parent] = __fadd_rn(v.tree[2 * parent + 1], v.tree[2 * parent + 2]);
+      node = parent;
+    }
+    const int64_t next = (idx + 1) % v.capacity;
+    v.hdr->index = next;                 // memory.py:59
+    if (next == 0) v.hdr->full = 1;      // memory.py:60
+    v.hdr->total = v.tree[0];
+    // memory.py:54,61: max(value, max) with value == max — unchanged
+  }
+}
+
+// Bulk append: frames + columns + leaves (any grid), then ancestor rebuild kernels.
+__global__ __launch_bounds__(256) void k_append_copy(ReplayView v, int64_t start, const uint8_t* frames,
+                                                      const int32_t* timesteps, const int32_t* actions,
+                                                      const float* rewards, const uint8_t* nonterminals, int64_t n) {
+  constexpr int VEC = RB_FRAME_BYTES / 16;  // 441 uint4 per frame
+  const float prio = v.hdr->max;
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t idx = (start + i) % v.capacity;
+    const uint4* s = (const uint4*)(frames + i * RB_FRAME_BYTES);
+    uint4* d = (uint4*)(v.frames + idx * RB_FRAME_BYTES);
+    for (int t = (int)threadIdx.x; t < VEC; t += (int)blockDim.x) d[t] = s[t];
+    if (threadIdx.x == 0) {
+      v.timestep[idx] = timesteps[i];
+      v.action[idx] = actions[i];
+      v.reward[idx] = rewards[i];
+      v.nonterminal[idx] = nonterminals[i] ? 1 : 0;
+      v.tree[idx + v.tree_start] = prio;
+    }
+  }
+}
+
+// tree[p] = tree[2p+1] + tree[2p+2] for p in [lo0,hi0] U [lo1,hi1] (inclusive; empty if hi<lo)
+__global__ __launch_bounds__(256) void k_rebuild_ranges(float* tree, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1) {
+  const int64_t n0 = hi0 >= lo0 ? hi0 - lo0 + 1 : 0;
+  const int64_t n1 = hi1 >= lo1 ? hi1 - lo1 + 1 : 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n0 + n1; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t < n0 ? lo0 + t : lo1 + (t - n0);
+    tree[p] = __fadd_rn(tree[2 * p + 1], tree[2 * p + 2]);
+  }
+}
+
+// Finishes the rebuild from small ranges up to the root inside one workgroup, then
+// publishes the new header.  ranges are NODE ranges at the level to process first.
+__global__ __launch_bounds__(1024) void k_rebuild_top(ReplayView v, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1,
+                                                       int32_t have_ranges, int64_t new_index, int32_t set_full) {
+  if (have_ranges) {
+    for (;;) {
+      const int64_t n0 = hi0 >= lo0 ? hi0 - lo0 + 1 : 0;
+      const int64_t n1 = hi1 >= lo1 ? hi1 - lo1 + 1 : 0;
+      for (int64_t t = threadIdx.x; t < n0 + n1; t += blockDim.x) {
+        const int64_t p = t < n0 ? lo0 + t : lo1 + (t - n0);
+        v.tree[p] = __fadd_rn(v.tree[2 * p + 1], v.tree[2 * p + 2]);
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (lo0 == 0 || (n0 == 0 && lo1 == 0)) break;  // root done
+      if (n0 > 0) { lo0 = (lo0 - 1) / 2; hi0 = (hi0 - 1) / 2; }
+      if (n1 > 0) { lo1 = (lo1 - 1) / 2; hi1 = (hi1 - 1) / 2; }
+      // merged / overlapping ranges only recompute the same node twice with the same value
+    }
+  }
+  if (threadIdx.x == 0) {
+    v.hdr->index = new_index;
+    if (set_full) v.hdr->full = 1;
+    v.hdr->total = v.tree[0];
+  }
+}
+
+// ------------------------------------------------------------------------ find --
+// SegmentTree._retrieve (memory.py:64-76) for ONE value: float64 value vs float32 nodes,
+// strict '>' to go right, float64 subtraction, children clamped on the last internal
+// level (memory.py:70-71).  Exactly L steps from the root.
+__device__ __forceinline__ int64_t rb_tree_descend(const float* tree, int32_t levels, int64_t tree_start,
+                                                   int64_t tree_len, double value) {
+  int64_t node = 0;
+  for (int32_t lv = 0; lv < levels; ++lv) {
+    int64_t left = 2 * node + 1;
+    int64_t right = left + 1;
+    if (left >= tree_start) {  // children are leaves: bound outliers (memory.py:70-71)
+      if (left > tree_len - 1) left = tree_len - 1;
+      if (right > tree_len - 1) right = tree_len - 1;
+    }
+    const float lv_f = tree[left];
+    const double lv_d = (double)lv_f;
+    const bool go_right = value > lv_d;            // memory.py:73
+    node = go_right ? right : left;                // memory.py:74
+    if (go_right) value = __dsub_rn(value, lv_d);  // memory.py:75
+  }
+  return node;
+}
+
+__global__ __launch_bounds__(256) void k_find(ReplayView v, const double* values, int32_t n, float* probs,
+                                               int64_t* data_idx, int64_t* tree_idx) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const int64_t leaf = rb_tree_descend(v.tree, v.levels, v.tree_start, v.tree_len, values[i]);
+  probs[i] = v.tree[leaf];
+  data_idx[i] = leaf - v.tree_start;
+  tree_idx[i] = leaf;
+}
+
+// ---------------------------------------------------------------------- sample --
+// ReplayMemory.sample on device (memory.py:124-155).  ONE workgroup, thread i = sample i
+// (batch <= 1024).  The rejection loop (memory.py:128-132) runs inside the kernel so the
+// steady-state learn step has no host round trip.
+__global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, float neg_beta_f32,
+                                                  const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
+                                                  const float* scaling, int64_t* tree_idx_out, int32_t* win,
+                                                  int64_t* actions_out, float* returns_out, float* nonterminals_out,
+                                                  float* weights_out) {
+  __shared__ int s_flag[16];
+  __shared__ float s_red[16];
+  const int i = (int)threadIdx.x;
+  const bool active = i < batch;
+  const int64_t C = v.capacity;
+  const int h = v.history, n = v.n;
+
+  const float p_total = v.tree[0];                              // memory.py:149
+  const int64_t w_index = v.hdr->index;
+  const int32_t full = v.hdr->full;
+  const uint64_t rng_base = v.hdr->rng_counter;
+  // segment_length = p_total / batch_size: float32 / python int -> float32 (NEP 50)
+  const float seg_f = __fdiv_rn(p_total, (float)batch);         // memory.py:125
+  const double seg = (double)seg_f;
+  const double start = __dmul_rn((double)i, seg);               // memory.py:126 (int64 * f32 -> f64)
+
+  int64_t leaf = v.tree_start;
+  float prob = 0.0f;
+  int attempt = 0;
+  int ok = 0;
+  for (; attempt < max_attempts; ++attempt) {
+    double u;
+    if (unit_uniforms) {
+      u = active ? unit_uniforms[(int64_t)attempt * batch + i] : 0.0;
+    } else {
+      const rb_philox_out r = rb_philox(seed, rng_base + (uint64_t)attempt, (uint64_t)i);
+      u = rb_u53(r.v[0], r.v[1]);
+    }
+    // np.random.uniform(0.0, seg, B) = 0.0 + seg*u ; + segment_starts   (memory.py:129)
+    const double sample = __dadd_rn(__dadd_rn(0.0, __dmul_rn(seg, u)), start);
+    int valid = 1;
+    if (active) {
+      leaf = rb_tree_descend(v.tree, v.levels, v.tree_start, v.tree_len, sample);   // memory.py:130
+      prob = v.tree[leaf];
+      const int64_t idx = leaf - v.tree_start;
+      // memory.py:131
+      valid = (rb_floor_mod(w_index - idx, C) > (int64_t)n) && (rb_floor_mod(idx - w_index, C) >= (int64_t)h) &&
+              (prob != 0.0f);
+    }
+    ok = rb_block_all(valid, s_flag);
+    if (ok) break;
+  }
+  const int attempts_used = ok ? attempt + 1 : max_attempts;
+
+  // ---- window (memory.py:111-121), scalars (memory.py:140-145), IS weights (151-154)
+  float w = 0.0f;
+  if (active) {
+    const int64_t idx = leaf - v.tree_start;
+    const int win_len = h + n;
+    int32_t* my_win = win + (int64_t)i * win_len;
+    // firsts: timestep == 0
+    unsigned long long first_bits = 0ull;  // h+n <= 64
+    for (int t = 0; t < win_len; ++t) {
+      const int64_t ring = rb_floor_mod(idx + (int64_t)(t - (h - 1)), C);
+      my_win[t] = (int32_t)ring;
+      if (v.timestep[ring] == 0) first_bits |= 1ull << t;
+    }
+    unsigned long long blank = 0ull;
+    for (int t = h - 2; t >= 0; --t) {  // memory.py:116-117
+      const bool b = ((blank >> (t + 1)) & 1ull) || ((first_bits >> (t + 1)) & 1ull);
+      if (b) blank |= 1ull << t;
+    }
+    for (int t = h; t < win_len; ++t) {  // memory.py:118-119
+      const bool b = ((blank >> (t - 1)) & 1ull) || ((first_bits >> t) & 1ull);
+      if (b) blank |= 1ull << t;
+    }
+    for (int t = 0; t < win_len; ++t)
+      if ((blank >> t) & 1ull) my_win[t] = -1;
+    // slot h-1 is never blanked
+    const int64_t ring_now = rb_floor_mod(idx, C);
+    actions_out[i] = (int64_t)v.action[ring_now];                       // memory.py:140
+    float R = 0.0f;                                                     // memory.py:142-143
+    for (int k = 0; k < n; ++k) {
+      const int t = h - 1 + k;
+      const float rew = ((blank >> t) & 1ull) ? 0.0f : v.reward[my_win[t] < 0 ? 0 : my_win[t]];
+      R = __fadd_rn(R, __fmul_rn(rew, scaling[k]));
+    }
+    returns_out[i] = R;
+    const int t_last = h + n - 1;                                       // memory.py:145
+    nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (v.nonterminal[my_win[t_last]] ? 1.0f : 0.0f);
+    tree_idx_out[i] = leaf;
+    // probs / p_total ; capacity * probs ; ** -beta   (memory.py:151-153), all float32
+    const float pn = __fdiv_rn(prob, p_total);
+    const float cap = (float)(full ? C : w_index);
+    const float base = __fmul_rn(cap, pn);
+    w = (float)pow((double)base, (double)neg_beta_f32);
+  }
+  const float w_max = rb_block_max(active ? w : -INFINITY, s_red);
+  if (active) weights_out[i] = __fdiv_rn(w, w_max);                     // memory.py:154
+  if (threadIdx.x == 0) {
+    v.hdr->last_attempts = attempts_used;
+    v.hdr->last_status = ok ? 0 : 1;
+    if (!unit_uniforms) v.hdr->rng_counter = rng_base + (uint64_t)attempts_used;
+  }
+}
+
+// Frame-stack gather (memory.py:136-138 minus the /255): block = (sample, stack slot),
+// 441 sixteen-byte lanes per 7056-byte frame, zero fill for blanked slots.
+__global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t batch, const int32_t* win,
+                                                        uint8_t* states, uint8_t* next_states) {
+  constexpr int VEC = RB_FRAME_BYTES / 16;
+  const int h = v.history, n = v.n;
+  const int per_sample = 2 * h;
+  for (int b = (int)blockIdx.x; b < batch * per_sample; b += (int)gridDim.x) {
+    const int i = b / per_sample;
+    const int s = b % per_sample;
+    const bool is_next = s >= h;
+    const int c = is_next ? s - h : s;
+    const int slot = is_next ? n + c : c;
+    const int32_t ring = win[(int64_t)i * (h + n) + slot];
+    uint4* d = (uint4*)((is_next ? next_states : states) + ((int64_t)i * h + c) * RB_FRAME_BYTES);
+    if (ring < 0) {
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      for (int t = (int)threadIdx.x; t < VEC; t += (int)blockDim.x) d[t] = z;
+    } else {
+      const uint4* src = (const uint4*)(v.frames + (int64_t)ring * RB_FRAME_BYTES);
+      for (int t = (int)threadIdx.x; t < VEC; t += (int)blockDim.x) d[t] = src[t];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------- update --
+// SegmentTree.update (memory.py:44-48) for n <= 1024 leaves in ONE workgroup.
+// Duplicate indices: numpy fancy assignment is last-write-wins (memory.py:45).
+// apply_pow: ReplayMemory.update_priorities' p = loss^w first (memory.py:158).
+__global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
+                                                  int32_t apply_pow, double omega) {
+  __shared__ int64_t s_idx[1024];
+  __shared__ float s_red[16];
+  const int i = (int)threadIdx.x;
+  const bool active = i < n;
+  int64_t node = active ? tree_idx[i] : -1;
+  float val = 0.0f;
+  if (active) {
+    val = values[i];
+    if (apply_pow) val = (float)pow((double)val, omega);
+  }
+  s_idx[i] = node;
+  __syncthreads();
+  if (active) {
+    bool last = true;
+    for (int j = i + 1; j < n; ++j)
+      if (s_idx[j] == node) { last = false; break; }
+    if (last) v.tree[node] = val;
+  }
+  const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47
+  __threadfence_block();
+  __syncthreads();
+  // memory.py:28-33: parents of all indices, level by level, until the root is written
+  for (int32_t lv = 0; lv < v.levels; ++lv) {
+    if (active) {
+      node = (node - 1) / 2;
+      v.tree[node] = __fadd_rn(v.tree[2 * node + 1], v.tree[2 * node + 2]);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    v.hdr->max = fmaxf(vmax, v.hdr->max);  // memory.py:48
+    v.hdr->total = v.tree[0];
+  }
+}
+
+// -------------------------------------------------------------- validation view --
+// ReplayMemory.__next__ (memory.py:167-178): history stack ending at data index i.
+// NOTE the reference indexes data[i-h+1 .. i] with numpy negative wrap-around, not % C.
+__global__ __launch_bounds__(256) void k_state_at(ReplayView v, int64_t data_index, float* out) {
+  __shared__ int s_blank[64];
+  const int h = v.history;
+  if (threadIdx.x == 0) {
+    int blank_next = 0;
+    s_blank[h - 1] = 0;
+    for (int t = h - 2; t >= 0; --t) {
+      const int64_t ring_next = rb_floor_mod(data_index - (h - 1) + (t + 1), v.capacity);
+      const int b = blank_next || (v.timestep[ring_next] == 0);
+      s_blank[t] = b;
+      blank_next = b;
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < h; ++t) {
+    const int64_t ring = rb_floor_mod(data_index - (h - 1) + t, v.capacity);
+    const uint8_t* src = v.frames + ring * RB_FRAME_BYTES;
+    float* dst = out + (int64_t)t * RB_FRAME_BYTES;
+    const bool blank = s_blank[t] != 0;
+    for (int p = (int)threadIdx.x; p < RB_FRAME_BYTES; p += (int)blockDim.x)
+      dst[p] = blank ? 0.0f : __fdiv_rn((float)src[p], 255.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_u8_to_unit(const uint8_t* src, float* dst, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    dst[t] = __fdiv_rn((float)src[t], 255.0f);  // memory.py:137 .div_(255)
+}
+
+// ================================================================ host entry points
+extern "C" {
+
+int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32_t multi_step, double discount,
+                     double priority_exponent, uint64_t seed) {
+  RB_REQUIRE(out != nullptr, "rb_replay_create: out is NULL");
+  RB_REQUIRE(capacity >= 2 && (capacity % 2) == 0,
+             "rb_replay_create: capacity must be even and >= 2 (the reference's sum-tree walk reads past the "
+             "array for odd sizes, memory.py:38-39), got %lld", (long long)capacity);
+  RB_REQUIRE(capacity <= ((int64_t)1 << 30), "rb_replay_create: capacity too large");
+  RB_REQUIRE(history >= 1 && multi_step >= 1 && history + multi_step <= 64, "rb_replay_create: need history>=1, multi_step>=1, history+multi_step<=64");
+  rb_replay* r = new (std::nothrow) rb_replay();
+  if (!r) { rb_set_error("rb_replay_create: host OOM"); return RB_ERR_OOM; }
+  r->capacity = capacity; r->history = history; r->n = multi_step; r->omega = priority_exponent; r->seed = seed;
+  int32_t L = 0;
+  while (((int64_t)1 << L) < capacity) ++L;  // (capacity-1).bit_length()   memory.py:17
+  r->levels = L;
+  r->tree_start = ((int64_t)1 << L) - 1;
+  r->tree_len = r->tree_start + capacity;
+  for (int k = 0; k < multi_step; ++k) r->scaling[k] = (float)pow(discount, (double)k);  // memory.py:101
+  r->max_batch = 1024;
+  r->host_index = 0; r->host_full = 0;
+  r->tree = nullptr; r->frames = nullptr; r->timestep = nullptr; r->action = nullptr; r->reward = nullptr;
+  r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr;
+#define RB_ALLOC(ptr, bytes)                                                                      \
+  do {                                                                                            \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                                   \
+    if (e_ != hipSuccess) {                                                                       \
+      rb_set_error("rb_replay_create: hipMalloc(%lld B) failed: %s", (long long)(bytes), hipGetErrorString(e_)); \
+      rb_replay_destroy(r);                                                                       \
+      return RB_ERR_OOM;                                                                          \
+    }                                                                                             \
+  } while (0)
+  RB_ALLOC(r->tree, r->tree_len * sizeof(float));
+  RB_ALLOC(r->frames, capacity * (int64_t)RB_FRAME_BYTES);
+  RB_ALLOC(r->timestep, capacity * sizeof(int32_t));
+  RB_ALLOC(r->action, capacity * sizeof(int32_t));
+  RB_ALLOC(r->reward, capacity * sizeof(float));
+  RB_ALLOC(r->nonterminal, capacity);
+  RB_ALLOC(r->hdr, sizeof(rb_replay_header_t));
+  RB_ALLOC(r->win, (int64_t)r->max_batch * 64 * sizeof(int32_t));
+  RB_ALLOC(r->scaling_dev, 64 * sizeof(float));
+#undef RB_ALLOC
+  // blank_trans everywhere (memory.py:8,19), zero tree (memory.py:18)
+  RB_HIP_TRY(hipMemset(r->tree, 0, r->tree_len * sizeof(float)));
+  RB_HIP_TRY(hipMemset(r->frames, 0, capacity * (int64_t)RB_FRAME_BYTES));
+  RB_HIP_TRY(hipMemset(r->timestep, 0, capacity * sizeof(int32_t)));
+  RB_HIP_TRY(hipMemset(r->action, 0, capacity * sizeof(int32_t)));
+  RB_HIP_TRY(hipMemset(r->reward, 0, capacity * sizeof(float)));
+  RB_HIP_TRY(hipMemset(r->nonterminal, 0, capacity));
+  RB_HIP_TRY(hipMemcpy(r->scaling_dev, r->scaling, 64 * sizeof(float), hipMemcpyHostToDevice));
+  RB_LAUNCH(k_replay_init, dim3(1), dim3(64), nullptr, r->hdr);
+  RB_LAUNCH_CHECK();
+  RB_HIP_TRY(hipDeviceSynchronize());
+  *out = r;
+  return RB_OK;
+}
+
+int rb_replay_destroy(rb_replay_t* r) {
+  if (!r) return RB_OK;
+  if (r->tree) (void)hipFree(r->tree);
+  if (r->frames) (void)hipFree(r->frames);
+  if (r->timestep) (void)hipFree(r->timestep);
+  if (r->action) (void)hipFree(r->action);
+  if (r->reward) (void)hipFree(r->reward);
+  if (r->nonterminal) (void)hipFree(r->nonterminal);
+  if (r->hdr) (void)hipFree(r->hdr);
+  if (r->win) (void)hipFree(r->win);
+  if (r->scaling_dev) (void)hipFree(r->scaling_dev);
+  delete r;
+  return RB_OK;
+}
+
+int rb_replay_buffers(rb_replay_t* r, rb_replay_buffers_t* o) {
+  RB_REQUIRE(r && o, "rb_replay_buffers: NULL argument");
+  o->sum_tree_dev = r->tree; o->tree_len = r->tree_len; o->tree_start = r->tree_start;
+  o->frames_dev = r->frames; o->timestep_dev = r->timestep; o->action_dev = r->action;
+  o->reward_dev = r->reward; o->nonterminal_dev = r->nonterminal; o->header_dev = r->hdr;
+  return RB_OK;
+}
+
+int rb_replay_header(rb_replay_t* r, rb_replay_header_t* o, rb_stream_t stream) {
+  RB_REQUIRE(r && o, "rb_replay_header: NULL argument");
+  RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  RB_HIP_TRY(hipMemcpy(o, r->hdr, sizeof(*o), hipMemcpyDeviceToHost));
+  r->host_index = o->index;  // resynchronise the mirror (e.g. after a state restore)
+  r->host_full = o->full;
+  return RB_OK;
+}
+
+int rb_replay_append(rb_replay_t* r, const float* state_dev, int32_t timestep, int32_t action, float reward,
+                     int32_t nonterminal, rb_stream_t stream) {
+  RB_REQUIRE(r && state_dev, "rb_replay_append: NULL argument");
+  const float* last = state_dev + (int64_t)(r->history - 1) * RB_FRAME_BYTES;  // state[-1], memory.py:106
+  RB_LAUNCH(k_append_one, dim3(1), dim3(256), stream, view_of(r), last, timestep, action, reward, nonterminal);
+  RB_LAUNCH_CHECK();
+  r->host_index = (r->host_index + 1) % r->capacity;
+  if (r->host_index == 0) r->host_full = 1;
+  return RB_OK;
+}
+
+int rb_replay_append_batch(rb_replay_t* r, const uint8_t* frames_dev, const int32_t* timesteps_dev,
+                           const int32_t* actions_dev, const float* rewards_dev, const uint8_t* nonterminals_dev,
+                           int64_t n, rb_stream_t stream) {
+  RB_REQUIRE(r && frames_dev && timesteps_dev && actions_dev && rewards_dev && nonterminals_dev,
+             "rb_replay_append_batch: NULL argument");
+  RB_REQUIRE(n >= 0 && n <= r->capacity, "rb_replay_append_batch: n must be in [0, capacity]");
+  if (n == 0) return RB_OK;
+  const ReplayView v = view_of(r);
+  const int64_t start = r->host_index;
+  const int grid = (int)(n < 4096 ? n : 4096);
+  RB_LAUNCH(k_append_copy, dim3(grid), dim3(256), stream, v, start, frames_dev, timesteps_dev, actions_dev,
+            rewards_dev, nonterminals_dev, n);
+  RB_LAUNCH_CHECK();
+  // leaf ranges (tree indices), possibly wrapping around the ring
+  int64_t lo0 = r->tree_start + start, hi0, lo1 = 0, hi1 = -1;
+  if (start + n <= r->capacity) {
+    hi0 = lo0 + n - 1;
+  } else {
+    hi0 = r->tree_start + r->capacity - 1;
+    lo1 = r->tree_start;
+    hi1 = r->tree_start + (start + n - r->capacity) - 1;
+  }
+  // parents of the leaf ranges
+  lo0 = (lo0 - 1) / 2; hi0 = (hi0 - 1) / 2;
+  if (hi1 >= lo1) { lo1 = (lo1 - 1) / 2; hi1 = (hi1 - 1) / 2; }
+  for (;;) {
+    const int64_t cnt = (hi0 - lo0 + 1) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0);
+    if (cnt <= 2048 || lo0 == 0) break;
+    const int g = (int)rb_div_up(cnt, 256);
+    RB_LAUNCH(k_rebuild_ranges, dim3(g > 2048 ? 2048 : g), dim3(256), stream, r->tree, lo0, hi0, lo1, hi1);
+    RB_LAUNCH_CHECK();
+    lo0 = (lo0 - 1) / 2; hi0 = (hi0 - 1) / 2;
+    if (hi1 >= lo1) { lo1 = (lo1 - 1) / 2; hi1 = (hi1 - 1) / 2; }
+  }
+  const int64_t new_index = (start + n) % r->capacity;
+  const int32_t set_full = (start + n >= r->capacity) ? 1 : 0;
+  RB_LAUNCH(k_rebuild_top, dim3(1), dim3(1024), stream, v, lo0, hi0, lo1, hi1, 1, new_index, set_full);
+  RB_LAUNCH_CHECK();
+  r->host_index = new_index;
+  if (set_full) r->host_full = 1;
+  return RB_OK;
+}
+
+int rb_replay_find(rb_replay_t* r, const double* values_dev, int32_t n, float* probs_dev, int64_t* data_idx_dev,
+                   int64_t* tree_idx_dev, rb_stream_t stream) {
+  RB_REQUIRE(r && values_dev && probs_dev && data_idx_dev && tree_idx_dev, "rb_replay_find: NULL argument");
+  if (n <= 0) return RB_OK;
+  RB_LAUNCH(k_find, dim3((unsigned)rb_div_up(n, 256)), dim3(256), stream, view_of(r), values_dev, n, probs_dev,
+            data_idx_dev, tree_idx_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
+                     int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                     int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
+                     rb_stream_t stream) {
+  RB_REQUIRE(r && tree_idx_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev,
+             "rb_replay_sample: NULL argument");
+  RB_REQUIRE(batch >= 1 && batch <= r->max_batch, "rb_replay_sample: batch must be in [1,%d]", r->max_batch);
+  RB_REQUIRE(max_attempts >= 1, "rb_replay_sample: max_attempts must be >= 1");
+  const ReplayView v = view_of(r);
+  const int threads = (int)(rb_div_up(batch, 64) * 64);
+  // weights ** -beta: python float exponent is cast to float32 by numpy (NEP 50 weak scalar)
+  const float neg_beta = (float)(-priority_weight);
+  RB_LAUNCH(k_sample, dim3(1), dim3(threads), stream, v, batch, neg_beta, unit_uniforms_dev, max_attempts, r->seed,
+            r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev);
+  RB_LAUNCH_CHECK();
+  if (states_dev && next_states_dev) {
+    RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win,
+              states_dev, next_states_dev);
+    RB_LAUNCH_CHECK();
+  }
+  return RB_OK;
+}
+
+static int rb_update_impl(rb_replay_t* r, const int64_t* tree_idx_dev, const float* values_dev, int32_t n,
+                          int32_t apply_pow, rb_stream_t stream) {
+  RB_REQUIRE(r && tree_idx_dev && values_dev, "rb_replay_update: NULL argument");
+  RB_REQUIRE(n >= 1 && n <= 1024, "rb_replay_update: n must be in [1,1024]");
+  const int threads = (int)(rb_div_up(n, 64) * 64);
+  RB_LAUNCH(k_update, dim3(1), dim3(threads), stream, view_of(r), tree_idx_dev, values_dev, n, apply_pow, r->omega);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_replay_update_leaves(rb_replay_t* r, const int64_t* tree_idx_dev, const float* values_dev, int32_t n,
+                            rb_stream_t stream) {
+  return rb_update_impl(r, tree_idx_dev, values_dev, n, 0, stream);
+}
+
+int rb_replay_update_priorities(rb_replay_t* r, const int64_t* tree_idx_dev, const float* losses_dev, int32_t n,
+                                rb_stream_t stream) {
+  return rb_update_impl(r, tree_idx_dev, losses_dev, n, 1, stream);
+}
+
+int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_stream_t stream) {
+  RB_REQUIRE(r && out_dev, "rb_replay_state_at: NULL argument");
+  RB_REQUIRE(data_index >= 0 && data_index < r->capacity, "rb_replay_state_at: index out of range");
+  RB_LAUNCH(k_state_at, dim3(1), dim3(256), stream, view_of(r), data_index, out_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_u8_to_unit_f32(const uint8_t* src_dev, float* dst_dev, int64_t n, rb_stream_t stream) {
+  RB_REQUIRE(src_dev && dst_dev && n >= 0, "rb_u8_to_unit_f32: bad argument");
+  if (n == 0) return RB_OK;
+  int64_t g = rb_div_up(n, 256);
+  if (g > 4096) g = 4096;
+  RB_LAUNCH(k_u8_to_unit, dim3((unsigned)g), dim3(256), stream, src_dev, dst_dev, n);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+}  // extern "C"

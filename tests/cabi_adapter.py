@@ -1,0 +1,178 @@
+"""C-ABI backends for tests/scenarios.py.  The same adapter drives
+  - the host-interpreted test build (tests/hipemu/librainbow_emu.so, numpy memory, CPU), and
+  - the shipped HIP library (rainbow_amd/librainbow_hip.so, torch cuda memory, -m gpu).
+"""
+import ctypes as C
+
+import numpy as np
+
+from rainbow_amd import _lib as L
+
+
+class NumpyMem:
+    """'Device' memory for the host interpreter: plain numpy arrays."""
+    stream = None
+
+    def empty(self, shape, dtype):
+        return np.zeros(shape, dtype=dtype)
+
+    def upload(self, arr):
+        return np.ascontiguousarray(arr).copy()
+
+    def download(self, buf):
+        return np.array(buf, copy=True)
+
+    def ptr(self, buf):
+        return buf.ctypes.data if buf is not None else None
+
+    def view(self, ptr, shape, dtype):
+        n = int(np.prod(shape))
+        ct = C.cast(ptr, C.POINTER(C.c_uint8))
+        return np.ctypeslib.as_array(ct, shape=(n * np.dtype(dtype).itemsize,)).view(dtype).reshape(shape).copy()
+
+    def sync(self):
+        pass
+
+
+class TorchMem:
+    """Device memory owned by torch (HBM) for the real library."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda:0")
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    _map = {np.dtype(np.float32): "float32", np.dtype(np.float64): "float64", np.dtype(np.int64): "int64",
+            np.dtype(np.int32): "int32", np.dtype(np.uint8): "uint8"}
+
+    def empty(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=getattr(self.torch, self._map[np.dtype(dtype)]), device=self.dev)
+
+    def upload(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
+
+    def download(self, buf):
+        return buf.cpu().numpy()
+
+    def ptr(self, buf):
+        return buf.data_ptr() if buf is not None else None
+
+    def view(self, ptr, shape, dtype):
+        # copy raw library-owned device memory into a torch tensor via hipMemcpy (D2D)
+        out = self.empty(shape, dtype)
+        nbytes = out.numel() * out.element_size()
+        self.sync()
+        rt = C.CDLL("libamdhip64.so.7") if not hasattr(self, "_rt") else self._rt
+        self._rt = rt
+        rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = rt.hipMemcpy(out.data_ptr(), ptr, nbytes, 3)
+        assert rc == 0, rc
+        return out.cpu().numpy()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+class CAbiReplayAdapter:
+    def __init__(self, lib, mem, capacity, history, n, discount, omega, seed=7):
+        self.lib, self.mem = lib, mem
+        self.capacity, self.history, self.n = capacity, history, n
+        self.h = C.c_void_p()
+        L.check(lib, lib.rb_replay_create(C.byref(self.h), capacity, history, n, discount, omega, seed))
+        self.t = 0
+        self.bufs = L.ReplayBuffers()
+        L.check(lib, lib.rb_replay_buffers(self.h, C.byref(self.bufs)))
+
+    def close(self):
+        if self.h:
+            self.lib.rb_replay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- protocol ----------------------------------------------------------------
+    def append(self, state, action, reward, terminal):
+        m = self.mem
+        st = m.upload(np.asarray(state, dtype=np.float32))
+        L.check(self.lib, self.lib.rb_replay_append(self.h, m.ptr(st), self.t, int(action), float(reward),
+                                                    0 if terminal else 1, m.stream))
+        m.sync()
+        self.t = 0 if terminal else self.t + 1
+
+    def append_batch(self, frames_u8, timesteps, actions, rewards, nonterminals):
+        m = self.mem
+        bufs = [m.upload(np.asarray(frames_u8, dtype=np.uint8)), m.upload(np.asarray(timesteps, dtype=np.int32)),
+                m.upload(np.asarray(actions, dtype=np.int32)), m.upload(np.asarray(rewards, dtype=np.float32)),
+                m.upload(np.asarray(nonterminals, dtype=np.uint8))]
+        L.check(self.lib, self.lib.rb_replay_append_batch(self.h, *[m.ptr(b) for b in bufs], len(timesteps), m.stream))
+        m.sync()
+
+    def sample(self, batch, unit_uniforms, beta):
+        m = self.mem
+        h = self.history
+        uu = m.upload(np.asarray(unit_uniforms, dtype=np.float64)) if unit_uniforms is not None else None
+        attempts = int(np.asarray(unit_uniforms).shape[0]) if unit_uniforms is not None else 16
+        tree_idx = m.empty((batch,), np.int64)
+        states = m.empty((batch, h, 84, 84), np.uint8)
+        next_states = m.empty((batch, h, 84, 84), np.uint8)
+        actions = m.empty((batch,), np.int64)
+        returns = m.empty((batch,), np.float32)
+        nonterm = m.empty((batch,), np.float32)
+        weights = m.empty((batch,), np.float32)
+        L.check(self.lib, self.lib.rb_replay_sample(self.h, batch, float(beta), m.ptr(uu), attempts, m.ptr(tree_idx),
+                                                    m.ptr(states), m.ptr(next_states), m.ptr(actions), m.ptr(returns),
+                                                    m.ptr(nonterm), m.ptr(weights), m.stream))
+        m.sync()
+        hdr = self.raw_header()
+        assert hdr.last_status == 0, "device sampler gave up after %d attempts" % hdr.last_attempts
+        return dict(tree_idxs=m.download(tree_idx), states=m.download(states), next_states=m.download(next_states),
+                    actions=m.download(actions), returns=m.download(returns),
+                    nonterminals=m.download(nonterm)[:, None], weights=m.download(weights),
+                    attempts=hdr.last_attempts)
+
+    def update_priorities(self, tree_idxs, losses):
+        m = self.mem
+        ti = m.upload(np.asarray(tree_idxs, dtype=np.int64))
+        lo = m.upload(np.asarray(losses, dtype=np.float32))
+        L.check(self.lib, self.lib.rb_replay_update_priorities(self.h, m.ptr(ti), m.ptr(lo), len(tree_idxs), m.stream))
+        m.sync()
+
+    def update_leaves(self, tree_idxs, values):
+        m = self.mem
+        ti = m.upload(np.asarray(tree_idxs, dtype=np.int64))
+        va = m.upload(np.asarray(values, dtype=np.float32))
+        L.check(self.lib, self.lib.rb_replay_update_leaves(self.h, m.ptr(ti), m.ptr(va), len(tree_idxs), m.stream))
+        m.sync()
+
+    def find(self, values):
+        m = self.mem
+        n = len(values)
+        v = m.upload(np.asarray(values, dtype=np.float64))
+        probs, di, ti = m.empty((n,), np.float32), m.empty((n,), np.int64), m.empty((n,), np.int64)
+        L.check(self.lib, self.lib.rb_replay_find(self.h, m.ptr(v), n, m.ptr(probs), m.ptr(di), m.ptr(ti), m.stream))
+        m.sync()
+        return m.download(probs), m.download(di), m.download(ti)
+
+    def tree(self):
+        return self.mem.view(self.bufs.sum_tree_dev, (self.bufs.tree_len,), np.float32)
+
+    def raw_header(self):
+        hdr = L.ReplayHeader()
+        L.check(self.lib, self.lib.rb_replay_header(self.h, C.byref(hdr), self.mem.stream))
+        return hdr
+
+    def header(self):
+        hdr = self.raw_header()
+        return int(hdr.index), bool(hdr.full), np.float32(hdr.max)
+
+    def state_at(self, i):
+        m = self.mem
+        out = m.empty((self.history, 84, 84), np.float32)
+        L.check(self.lib, self.lib.rb_replay_state_at(self.h, int(i), m.ptr(out), m.stream))
+        m.sync()
+        return m.download(out)

@@ -1,0 +1,30 @@
+"""Shared comparison helpers for the parity tests."""
+import os
+
+import numpy as np
+
+import scenarios
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# float32 quantities that pass through a power function (p = loss^w, w = (N p)^-beta) are only
+# defined to ~1 ulp even for the reference itself (numpy's SIMD powf differs from libm by machine);
+# sums of such values in the tree inherit that.  4 float32 ulps relative:
+F32_ULP_RTOL = 4 * 2.0 ** -23
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def assert_trace_matches(trace, golden, rtol=F32_ULP_RTOL, label=""):
+    assert set(trace.keys()) == set(golden.keys()), (sorted(set(trace) ^ set(golden)))
+    for key in sorted(golden.keys()):
+        got, want = np.asarray(trace[key]), np.asarray(golden[key])
+        assert got.shape == want.shape, "%s %s: shape %s vs %s" % (label, key, got.shape, want.shape)
+        if scenarios.is_exact_key(key):
+            assert np.array_equal(got, want), "%s %s: exact mismatch\n got %s\nwant %s" % (label, key, got.ravel()[:16], want.ravel()[:16])
+        else:
+            np.testing.assert_allclose(got.astype(np.float64), want.astype(np.float64), rtol=rtol, atol=0,
+                                       err_msg="%s %s" % (label, key))

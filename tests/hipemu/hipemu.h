@@ -1,0 +1,161 @@
+// hipemu — a tiny single-threaded *host interpreter* for HIP kernels.
+//
+// TEST INFRASTRUCTURE ONLY.  It exists so that the kernel sources under
+// rainbow_amd/csrc/ can be compiled for x86 (clang++ -DRB_HOST_INTERP) and their
+// indexing / reduction / barrier logic checked on the GPU-less build container
+// before a GPU slot is spent.  It is never built into librainbow_hip.so and is never
+// loaded by the rainbow_amd package; only tests/hipemu/ loads the resulting
+// librainbow_emu.so.
+//
+// Model: blocks run one after another; the threads of a block are ucontext fibers
+// scheduled round-robin.  __syncthreads() and the wave collectives (shuffle, ballot,
+// MFMA) yield until every participant arrived, so a missing or divergent barrier
+// shows up as a detected deadlock instead of silently passing.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hipemu {
+extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+void block_barrier();
+void wave_barrier();
+int lane_id();
+int wave_id();
+int wave_width();            // active lanes in this wave (64 except a ragged tail)
+uint64_t* wave_slots(int which);  // 64 x 8-byte exchange slots, which in {0,1}
+}  // namespace hipemu
+
+#define threadIdx hipemu::g_threadIdx
+#define blockIdx hipemu::g_blockIdx
+#define blockDim hipemu::g_blockDim
+#define gridDim hipemu::g_gridDim
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+inline void __syncthreads() { hipemu::block_barrier(); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---- minimal HIP runtime surface (device memory == host memory) ----------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+
+struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+struct float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+struct float2 { float x, y; };
+inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+
+// ---- wave-level collectives --------------------------------------------------
+namespace hipemu {
+template <class T> inline T xchg(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "xchg width");
+  uint64_t* s = wave_slots(0);
+  uint64_t raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  s[lane_id()] = raw;
+  wave_barrier();
+  int w = wave_width();
+  uint64_t got = s[(src_lane >= 0 && src_lane < w) ? src_lane : lane_id()];
+  wave_barrier();
+  T out;
+  std::memcpy(&out, &got, sizeof(T));
+  return out;
+}
+}  // namespace hipemu
+template <class T> inline T __shfl(T v, int src, int = 64) { return hipemu::xchg(v, src); }
+template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::xchg(v, hipemu::lane_id() ^ mask); }
+template <class T> inline T __shfl_down(T v, unsigned d, int = 64) { return hipemu::xchg(v, hipemu::lane_id() + (int)d); }
+template <class T> inline T __shfl_up(T v, unsigned d, int = 64) { return hipemu::xchg(v, hipemu::lane_id() - (int)d); }
+inline unsigned long long __ballot(int pred) {
+  uint64_t* s = hipemu::wave_slots(0);
+  s[hipemu::lane_id()] = pred ? 1 : 0;
+  hipemu::wave_barrier();
+  unsigned long long m = 0;
+  for (int i = 0; i < hipemu::wave_width(); ++i) m |= (unsigned long long)(s[i] & 1) << i;
+  hipemu::wave_barrier();
+  return m;
+}
+inline int __all(int pred) { return __ballot(!pred) == 0ull; }
+inline int __any(int pred) { return __ballot(pred) != 0ull; }
+
+// ---- atomics (single-threaded interpreter: plain read-modify-write) -----------------
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+
+// ---- MFMA: v_mfma_f32_32x32x2_f32 semantics (k-ordered fmaf chain, §3 of the guide) ---
+typedef float rb_f32x16 __attribute__((ext_vector_type(16)));
+typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
+inline rb_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, rb_f32x16 c) {
+  // A[i][k] lives in lane k*32+i, B[k][j] in lane k*32+j.
+  // D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  uint64_t* sa = hipemu::wave_slots(0);
+  uint64_t* sb = hipemu::wave_slots(1);
+  const int lane = hipemu::lane_id();
+  uint64_t ra = 0, rb = 0;
+  std::memcpy(&ra, &a, 4);
+  std::memcpy(&rb, &b, 4);
+  sa[lane] = ra;
+  sb[lane] = rb;
+  hipemu::wave_barrier();
+  if (hipemu::wave_width() != 64) { std::fprintf(stderr, "hipemu: MFMA in a partial wave\n"); std::abort(); }
+  const int col = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      std::memcpy(&av, &sa[k * 32 + row], 4);
+      std::memcpy(&bv, &sb[k * 32 + col], 4);
+      acc = std::fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return c;
+}
+
+// ---- device math used by the kernels --------------------------------------------
+inline float __fdividef(float a, float b) { return a / b; }
+inline double __dmul_rn(double a, double b) { return a * b; }
+inline double __dadd_rn(double a, double b) { return a + b; }
+inline double __dsub_rn(double a, double b) { return a - b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fdiv_rn(float a, float b) { return a / b; }
