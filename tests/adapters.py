@@ -38,3 +38,36 @@ class OracleReplayAdapter:
 
     def state_at(self, i):
         return self.o.state_at(i)
+
+
+# --------------------------------------------------------------------------- learn step
+from oracle import learner_oracle as O  # noqa: E402
+import scenarios  # noqa: E402
+
+
+class OracleLearnAdapter:
+    def __init__(self, name):
+        self.cfg = O.Config(**scenarios.LEARN_CONFIGS[name])
+        self.h = scenarios.LEARN_HYPER
+
+    def load(self, online, target):
+        self.online = {k: v.copy() for k, v in online.items()}
+        self.target = {k: v.copy() for k, v in target.items()}
+        self.adam = O.AdamOracle(self.online, self.h["lr"], self.h["adam_eps"])
+        self.noise_online = None
+
+    def reset_noise_online(self, raw):
+        self.noise_online = O.make_noise(self.cfg, raw)
+
+    def learn_step(self, batch, target_raw):
+        out = O.learn(self.cfg, self.online, self.target, self.noise_online, O.make_noise(self.cfg, target_raw), batch)
+        total, clipped = O.clip_grads(out["grads"], self.h["norm_clip"])
+        self.online = self.adam.step(clipped)
+        self.last = out
+        return dict(loss=out["loss"], grad_norm=total, grads=clipped)
+
+    def params(self):
+        return self.online
+
+    def act(self, state, noisy):
+        return O.act(self.cfg, self.online, self.noise_online if noisy else None, state)

@@ -28,3 +28,23 @@ def assert_trace_matches(trace, golden, rtol=F32_ULP_RTOL, label=""):
         else:
             np.testing.assert_allclose(got.astype(np.float64), want.astype(np.float64), rtol=rtol, atol=0,
                                        err_msg="%s %s" % (label, key))
+
+
+def assert_learn_trace_matches(trace, golden, label="", grad_rtol=2e-4, grad_atol_rel=5e-6, param_atol=2e-7):
+    """Float tolerances of the learn step (stated, SURVEY §8c): loss / norms 1e-5 relative;
+    gradient elements rtol 2e-4 + 5e-6*max|g| (fp32 accumulation-order noise on cancelling sums);
+    post-Adam parameters 2e-7 absolute (lr 6.25e-5 times an O(1e-3) relative update error);
+    greedy actions exact."""
+    assert set(trace.keys()) == set(golden.keys()), sorted(set(trace) ^ set(golden))[:10]
+    for key in sorted(golden.keys()):
+        got, want = np.asarray(trace[key]), np.asarray(golden[key])
+        assert got.shape == want.shape, "%s %s: shape %s vs %s" % (label, key, got.shape, want.shape)
+        if key.startswith("act_"):
+            assert np.array_equal(got, want), "%s %s" % (label, key)
+        elif "_grad/" in key:
+            atol = grad_atol_rel * float(np.max(np.abs(want))) + 1e-12
+            np.testing.assert_allclose(got, want, rtol=grad_rtol, atol=atol, err_msg="%s %s" % (label, key))
+        elif "_param/" in key:
+            np.testing.assert_allclose(got, want, rtol=0, atol=param_atol, err_msg="%s %s" % (label, key))
+        else:  # loss, grad norms, q values
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7, err_msg="%s %s" % (label, key))

@@ -137,3 +137,88 @@ def is_exact_key(key):
     return any(k.startswith(p) for p in ("tree_idxs", "actions", "hdr", "states_crc", "next_states_crc", "states_sum",
                                          "next_states_sum", "find_data_idx", "find_tree_idx", "state_at", "nonterminals",
                                          "find_values"))
+
+
+# =============================================================================== learn step
+LEARN_CONFIGS = {
+    # canonical conv stack (k8s4,k4s2,k3s1) with a narrow hidden layer to keep fixtures small
+    "canon": dict(architecture="canonical", hidden=64, actions=6, atoms=51, batch=8, multi_step=3, discount=0.99,
+                  history=4, v_min=-10.0, v_max=10.0),
+    # data-efficient stack (k5s5,k5s5), n=20
+    "dataeff": dict(architecture="data-efficient", hidden=32, actions=4, atoms=51, batch=6, multi_step=20,
+                    discount=0.99, history=4, v_min=-10.0, v_max=10.0),
+    # other atom count / support / action count / history
+    "atoms21": dict(architecture="data-efficient", hidden=48, actions=3, atoms=21, batch=5, multi_step=1,
+                    discount=0.9, history=2, v_min=-5.0, v_max=5.0),
+}
+LEARN_HYPER = dict(lr=6.25e-5, adam_eps=1.5e-4, norm_clip=10.0)   # main.py:43-46 defaults
+LEARN_STEPS = 3
+
+
+def make_batch(cfg, seed):
+    """Synthetic learn() inputs incl. the projection's corner cases: clamped returns (|R| beyond
+    the support), terminal rows (all mass on two atoms) and integer-b rows (agent.py:85-86)."""
+    rs = np.random.RandomState(seed)
+    B, h = cfg["batch"], cfg["history"]
+    states = rs.randint(0, 256, size=(B, h, 84, 84)).astype(np.uint8)
+    next_states = rs.randint(0, 256, size=(B, h, 84, 84)).astype(np.uint8)
+    states[0, 0] = 0                      # a blanked frame
+    actions = rs.randint(0, cfg["actions"], size=B).astype(np.int64)
+    returns = rs.uniform(-3, 3, size=B).astype(np.float32)
+    nonterminals = (rs.random_sample(B) < 0.7).astype(np.float32)
+    returns[0] = 0.0; nonterminals[0] = 0.0                     # b exactly integer (mid support)
+    returns[1] = cfg["v_max"] + 2.0                             # clamp high: b = Z-1 for every atom
+    returns[2] = cfg["v_min"] - 2.0; nonterminals[2] = 1.0      # clamp low / partially
+    if B > 3:
+        returns[3] = 1.0; nonterminals[3] = 0.0
+    weights = rs.uniform(0.2, 1.0, size=B).astype(np.float32)
+    weights[rs.randint(0, B)] = 1.0
+    return dict(states=states, next_states=next_states, actions=actions, returns=returns,
+                nonterminals=nonterminals, weights=weights)
+
+
+def summarize(a):
+    """Full tensor when small, else a strided sample (keeps fixtures small)."""
+    a = np.asarray(a, dtype=np.float32).ravel()
+    if a.size <= 4096:
+        return a.copy()
+    stride = a.size // 2048 + 1
+    return a[::stride].copy()
+
+
+def learn_scenario(backend, name, oracle_mod):
+    """backend protocol:
+         load(online_params, target_params)            # {state-dict name: f32 array}
+         reset_noise_online(raw_normals f32[D])
+         learn_step(batch, target_raw_normals) -> dict(loss f32[B], grad_norm float, grads {name: f32 array (clipped)})
+         params() -> {name: array}                      # online, after the optimiser step
+         act(state_f32[h,84,84], noisy) -> (action, q)
+    oracle_mod supplies Config/init_params/noise_draw_count only (pure bookkeeping)."""
+    c = LEARN_CONFIGS[name]
+    cfg = oracle_mod.Config(**c)
+    seed0 = {"canon": 1000, "dataeff": 2000, "atoms21": 3000}[name]
+    online = oracle_mod.init_params(cfg, seed0)
+    target = oracle_mod.init_params(cfg, seed0 + 1)
+    backend.load(online, target)
+    draws = oracle_mod.noise_draw_count(cfg)
+    trace = {}
+    for k in range(LEARN_STEPS):
+        rs = np.random.RandomState(seed0 + 10 + k)
+        backend.reset_noise_online(rs.randn(draws).astype(np.float32))
+        batch = make_batch(c, seed0 + 20 + k)
+        out = backend.learn_step(batch, rs.randn(draws).astype(np.float32))
+        trace["s%d_loss" % k] = np.asarray(out["loss"], dtype=np.float32)
+        trace["s%d_grad_norm" % k] = np.float32(out["grad_norm"])
+        for pname, g in out["grads"].items():
+            trace["s%d_grad/%s" % (k, pname)] = summarize(g)
+            trace["s%d_gradnorm/%s" % (k, pname)] = np.float32(np.sqrt(np.sum(np.asarray(g, dtype=np.float64) ** 2)))
+        for pname, p in backend.params().items():
+            trace["s%d_param/%s" % (k, pname)] = summarize(p)
+    st = synth_state(np.random.RandomState(seed0 + 99), c["history"], 0)
+    a_noisy, q_noisy = backend.act(st, True)
+    a_eval, q_eval = backend.act(st, False)
+    trace["act_noisy"] = np.array([a_noisy], dtype=np.int64)
+    trace["act_eval"] = np.array([a_eval], dtype=np.int64)
+    trace["q_noisy"] = np.float32(q_noisy)
+    trace["q_eval"] = np.float32(q_eval)
+    return trace
