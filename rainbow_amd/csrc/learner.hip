@@ -1,0 +1,876 @@
+// learner.hip — the Rainbow learn step on MI355X (gfx950): three forwards, double-Q select,
+// C51 projection, importance-weighted cross-entropy and the full backward, as hand-written
+// HIP over flat float32 parameter / gradient / noise buffers borrowed from the caller.
+//
+// Reference being replaced: model.py (NoisyLinear, DQN) and agent.py:61-97.  The reference
+// issues ~1750 framework ops per learn(); here the step is a fixed chain of launches:
+//   conv fwd x L  ->  fc_h (split-K) -> finish -> fc_z -> head (dueling + softmax + double-Q
+//   + projection + loss + dlogits, one workgroup per sample, atom bins in LDS)
+//   -> fc_z dW/dX -> fc_h dW/dX -> finish -> conv dW/dX x L -> partial reduce -> norm/clip.
+// All contractions run on v_mfma_f32_32x32x2_f32 through gemm_core.h (exact f32: parity with
+// the float32 reference is the contract); everything else is fused into their operand
+// gathers / epilogues (learner_problems.h).
+#include "learner_problems.h"
+#include "rb_common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+typedef ConvGeom<8, 4, 84, 20> GeomC1;   // model.py:56
+typedef ConvGeom<4, 2, 20, 9> GeomC2;    // model.py:57
+typedef ConvGeom<3, 1, 9, 7> GeomC3;     // model.py:58
+typedef ConvGeom<5, 5, 84, 16> GeomD1;   // model.py:61
+typedef ConvGeom<5, 5, 16, 3> GeomD2;    // model.py:62
+
+struct ConvLayer {
+  int cin, cout, ks, s, ih, oh;
+  int K() const { return cin * ks * ks; }
+  int P() const { return oh * oh; }
+  int IP() const { return ih * ih; }
+};
+
+struct Layout {
+  int B, Z, A, H, F, NZ, hist, nconv;
+  ConvLayer conv[3];
+  // offsets (floats) inside the flat parameter buffer
+  int64_t conv_w[3], conv_b[3];
+  int64_t h_mu, h_sigma, h_bmu, h_bsigma, z_mu, z_sigma, z_bmu, z_bsigma;
+  int64_t n_params;
+  // offsets inside the flat noise buffer
+  int64_t h_ein, h_eout, z_ein, z_eout, n_noise;
+};
+
+static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
+
+static int make_layout(const rb_learner_config_t* c, Layout* L) {
+  RB_REQUIRE(c != nullptr, "learner config is NULL");
+  RB_REQUIRE(c->batch >= 1 && c->batch <= 1024, "batch must be in [1,1024]");
+  RB_REQUIRE(c->atoms >= 2 && c->atoms <= 256, "atoms must be in [2,256]");
+  RB_REQUIRE(c->actions >= 1 && c->actions <= 64, "actions must be in [1,64]");
+  RB_REQUIRE(c->history >= 1 && c->history <= 16, "history must be in [1,16]");
+  RB_REQUIRE(c->hidden >= 1 && c->hidden <= 8192, "hidden must be in [1,8192]");
+  RB_REQUIRE(c->architecture == 0 || c->architecture == 1, "architecture must be 0 (canonical) or 1 (data-efficient)");
+  RB_REQUIRE(c->multi_step >= 1, "multi_step must be >= 1");
+  RB_REQUIRE(c->v_max > c->v_min, "v_max must exceed v_min");
+  memset(L, 0, sizeof(*L));
+  L->B = c->batch; L->Z = c->atoms; L->A = c->actions; L->H = c->hidden; L->hist = c->history;
+  L->NZ = L->Z + L->A * L->Z;
+  if (c->architecture == 0) {
+    L->nconv = 3;
+    L->conv[0] = ConvLayer{c->history, 32, 8, 4, 84, 20};
+    L->conv[1] = ConvLayer{32, 64, 4, 2, 20, 9};
+    L->conv[2] = ConvLayer{64, 64, 3, 1, 9, 7};
+    L->F = 3136;  // model.py:59
+  } else {
+    L->nconv = 2;
+    L->conv[0] = ConvLayer{c->history, 32, 5, 5, 84, 16};
+    L->conv[1] = ConvLayer{32, 64, 5, 5, 16, 3};
+    L->F = 576;   // model.py:63
+  }
+  int64_t off = 0;
+  for (int l = 0; l < L->nconv; ++l) {
+    L->conv_w[l] = off; off = align64(off + (int64_t)L->conv[l].cout * L->conv[l].K());
+    L->conv_b[l] = off; off = align64(off + L->conv[l].cout);
+  }
+  const int64_t H2 = 2 * L->H;
+  L->h_mu = off; off = align64(off + H2 * L->F);
+  L->h_sigma = off; off = align64(off + H2 * L->F);
+  L->h_bmu = off; off = align64(off + H2);
+  L->h_bsigma = off; off = align64(off + H2);
+  L->z_mu = off; off = align64(off + (int64_t)L->NZ * L->H);
+  L->z_sigma = off; off = align64(off + (int64_t)L->NZ * L->H);
+  L->z_bmu = off; off = align64(off + L->NZ);
+  L->z_bsigma = off; off = align64(off + L->NZ);
+  L->n_params = off;
+  int64_t n = 0;
+  L->h_ein = n; n = align64(n + 2 * (int64_t)L->F);
+  L->h_eout = n; n = align64(n + H2);
+  L->z_ein = n; n = align64(n + H2);
+  L->z_eout = n; n = align64(n + L->NZ);
+  L->n_noise = n;
+  return RB_OK;
+}
+
+static NetPtrs net_ptrs(const Layout& L, const float* params, const float* noise) {
+  NetPtrs p;
+  for (int l = 0; l < 3; ++l) {
+    p.conv_w[l] = l < L.nconv ? params + L.conv_w[l] : nullptr;
+    p.conv_b[l] = l < L.nconv ? params + L.conv_b[l] : nullptr;
+  }
+  p.h_mu = params + L.h_mu; p.h_sigma = params + L.h_sigma; p.h_bmu = params + L.h_bmu; p.h_bsigma = params + L.h_bsigma;
+  p.z_mu = params + L.z_mu; p.z_sigma = params + L.z_sigma; p.z_bmu = params + L.z_bmu; p.z_bsigma = params + L.z_bsigma;
+  p.h_ein = noise + L.h_ein; p.h_eout = noise + L.h_eout; p.z_ein = noise + L.z_ein; p.z_eout = noise + L.z_eout;
+  return p;
+}
+
+// ---------------------------------------------------------------------- handle --
+struct rb_learner {
+  rb_learner_config_t cfg;
+  Layout L;
+  float *p_online, *p_target, *grads, *n_online, *n_target;   // borrowed
+  uint64_t seed;
+  uint64_t noise_epoch;
+  // owned workspace
+  float* act[3];        // [NI][cout][P]; act[nconv-1] doubles as feat [NI][F]
+  float* dact[3];       // [B][cout][P]
+  float* hpart;         // [hs][NI][2H]
+  float* h;             // [NI][2H]
+  float* logits;        // [NI][NZ]
+  float* dlogits;       // [B][NZ]
+  float* dh;            // [B][2H]
+  float* dfeat_part;    // [xs][B][F]
+  float* dw_part[3];    // [ws_l][cout][K+1]
+  float* log_ps_a;      // [B][Z]
+  float* pns_a;         // [B][Z]
+  float* m;             // [B][Z]
+  int32_t* a_star;      // [B]
+  float* support;       // [Z]
+  float* zero_noise;    // [n_noise] zeros (eval mode, model.py:46)
+  float* norm_part;     // [1024]
+  int hs, xs, ws[3];    // split counts
+  float gamma_n;        // float32(discount ** n)        agent.py:79
+  float delta_z;        // float32((Vmax - Vmin)/(Z-1))   agent.py:19,82
+};
+
+// ------------------------------------------------------------------------ noise --
+// f(x) = sign(x) * sqrt(|x|)  (model.py:32-34).  raw == NULL: N(0,1) from Philox + Box-Muller.
+// Draw order = the reference's: per layer randn(in) then randn(out); fc_h_v, fc_h_a, fc_z_v,
+// fc_z_a (model.py:36-38, 82-85).
+struct NoiseMap {
+  int64_t seg_begin[9];   // prefix of draw counts: hv_in, hv_out, ha_in, ha_out, zv_in, zv_out, za_in, za_out
+  int64_t dst[8];         // destination offsets in the noise buffer
+};
+__global__ __launch_bounds__(256) void k_noise(float* noise, const float* raw, NoiseMap map, uint64_t seed, uint64_t epoch) {
+  const int64_t total = map.seg_begin[8];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float x;
+    if (raw) {
+      x = raw[i];
+    } else {
+      const rb_philox_out r = rb_philox(seed, epoch, (uint64_t)(i >> 1));
+      const float u1 = ((float)(r.v[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(r.v[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      const float ang = 6.283185307179586f * u2;
+      x = (i & 1) ? rad * sinf(ang) : rad * cosf(ang);
+    }
+    const float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+    const float f = s * sqrtf(fabsf(x));
+    int seg = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) seg += (i >= map.seg_begin[q]) ? 1 : 0;
+    noise[map.dst[seg] + (i - map.seg_begin[seg])] = f;
+  }
+}
+
+// ----------------------------------------------------------- small fused passes --
+// h[img][n] = relu(sum_s part[s][img][n] + (bias_mu + bias_sigma*eps_out)[n])        model.py:44,72-73
+__global__ __launch_bounds__(256) void k_fc_h_finish(const float* part, int splits, int NI, int H2, int n_online,
+                                                      NetPtrs on, NetPtrs tg, float* h) {
+  const int64_t total = (int64_t)NI * H2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int img = (int)(i / H2), n = (int)(i % H2);
+    const NetPtrs& p = img < n_online ? on : tg;
+    float acc = 0.0f;
+    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];
+    const float bias = p.h_bmu[n] + p.h_bsigma[n] * p.h_eout[n];
+    h[i] = fmaxf(acc + bias, 0.0f);
+  }
+}
+
+// dfeat[b][k] = (feat[b][k] > 0) * sum_s part[s][b][k]
+__global__ __launch_bounds__(256) void k_dfeat_finish(const float* part, int splits, int64_t total, const float* feat,
+                                                       float* dfeat) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];
+    dfeat[i] = feat[i] > 0.0f ? acc : 0.0f;
+  }
+}
+
+// conv weight/bias grads: sum the split-K slices in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void k_reduce_conv_dw(const float* part, int splits, int cout, int K, float* gw,
+                                                         float* gb) {
+  const int64_t total = (int64_t)cout * (K + 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];
+    const int co = (int)(i / (K + 1)), col = (int)(i % (K + 1));
+    if (col < K) gw[(int64_t)co * K + col] = acc;
+    else gb[co] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------- head --
+// One workgroup (256 threads) per sample b.  Dueling combine (model.py:74-75), log-softmax of
+// the taken action (agent.py:66-67), double-Q argmax on the online net (agent.py:71-73), target
+// probabilities of that action (agent.py:75-76), C51 projection with the atom bins staged in LDS
+// and accumulated in the reference's order (agent.py:79-92), cross-entropy (agent.py:94) and
+// d loss / d logits for mean(w * loss) (agent.py:96).
+#define RB_MAX_ATOMS 256
+#define RB_MAX_ACTIONS 64
+
+__device__ __forceinline__ float rb_dueling_q(const float* lg, const float* mean_a, int Z, int a, int z) {
+  // q = v + a - mean_a(a)          model.py:75
+  return (lg[z] + lg[Z + a * Z + z]) - mean_a[z];
+}
+
+__global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
+                                               const float* returns, const float* nonterminals, const float* weights,
+                                               const float* support, float v_min, float v_max, float gamma_n,
+                                               float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
+                                               int32_t* a_star_out, float* loss_out, float* dlogits) {
+  __shared__ float s_mean[RB_MAX_ATOMS];
+  __shared__ float s_p[RB_MAX_ATOMS];        // probabilities (reused)
+  __shared__ float s_logp[RB_MAX_ATOMS];
+  __shared__ float s_m[RB_MAX_ATOMS];
+  __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS];
+  __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
+  __shared__ float s_ev[RB_MAX_ACTIONS];
+  __shared__ float s_red[16];
+  __shared__ int s_astar;
+  const int b = (int)blockIdx.x;
+  const int t = (int)threadIdx.x;
+  const int NZ = Z + A * Z;
+  const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
+  const float inv_unused = 0.0f; (void)inv_unused;
+
+  // ---------------- double-Q selection on online(next_states)   agent.py:71-73
+  const float* lg_n = logits + (int64_t)(B + b) * NZ;
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    float acc = 0.0f;
+    for (int a = 0; a < A; ++a) acc += lg_n[Z + a * Z + z];
+    s_mean[z] = acc / (float)A;                                   // a.mean(1)
+  }
+  __syncthreads();
+  for (int a = wave; a < A; a += nw) {                            // one wave per action
+    float mx = -INFINITY;
+    for (int z = lane; z < Z; z += 64) mx = fmaxf(mx, rb_dueling_q(lg_n, s_mean, Z, a, z));
+    mx = rb_wave_max(mx);
+    float se = 0.0f, sv = 0.0f;
+    for (int z = lane; z < Z; z += 64) {
+      const float e = expf(rb_dueling_q(lg_n, s_mean, Z, a, z) - mx);
+      se += e;
+      sv += support[z] * e;
+    }
+    se = rb_wave_sum(se);
+    sv = rb_wave_sum(sv);
+    if (lane == 0) s_ev[a] = sv / se;                             // sum_z z * p(z)
+  }
+  __syncthreads();
+  if (t == 0) {
+    int best = 0;
+    float bv = s_ev[0];
+    for (int a = 1; a < A; ++a)
+      if (s_ev[a] > bv) { bv = s_ev[a]; best = a; }               // argmax, first maximum
+    s_astar = best;
+    a_star_out[b] = best;
+  }
+  __syncthreads();
+  const int a_star = s_astar;
+
+  // ---------------- target(next_states)[a*] probabilities        agent.py:75-76
+  const float* lg_t = logits + (int64_t)(2 * B + b) * NZ;
+  __syncthreads();
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    float acc = 0.0f;
+    for (int a = 0; a < A; ++a) acc += lg_t[Z + a * Z + z];
+    s_mean[z] = acc / (float)A;
+  }
+  __syncthreads();
+  {
+    float mx = -INFINITY;
+    for (int z = t; z < Z; z += (int)blockDim.x) mx = fmaxf(mx, rb_dueling_q(lg_t, s_mean, Z, a_star, z));
+    mx = rb_block_max(mx, s_red);
+    float se = 0.0f;
+    for (int z = t; z < Z; z += (int)blockDim.x) {
+      const float e = expf(rb_dueling_q(lg_t, s_mean, Z, a_star, z) - mx);
+      s_p[z] = e;
+      se += e;
+    }
+    se = rb_block_sum(se, s_red);
+    for (int z = t; z < Z; z += (int)blockDim.x) {
+      const float p = s_p[z] / se;
+      s_p[z] = p;
+      pns_a_out[(int64_t)b * Z + z] = p;
+    }
+  }
+  __syncthreads();
+
+  // ---------------- C51 projection                               agent.py:79-92
+  const float R = returns[b], nt = nonterminals[b];
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    float Tz = R + (nt * gamma_n) * support[z];                   // agent.py:79
+    Tz = fminf(fmaxf(Tz, v_min), v_max);                          // agent.py:80
+    const float bq = (Tz - v_min) / delta_z;                      // agent.py:82
+    int l = (int)floorf(bq), u = (int)ceilf(bq);                  // agent.py:83
+    if (u > 0 && l == u) l -= 1;                                  // agent.py:85
+    if (l < Z - 1 && l == u) u += 1;                              // agent.py:86
+    s_l[z] = l; s_u[z] = u;
+    s_lo[z] = s_p[z] * ((float)u - bq);                           // agent.py:91
+    s_hi[z] = s_p[z] * (bq - (float)l);                           // agent.py:92
+  }
+  __syncthreads();
+  for (int k = t; k < Z; k += (int)blockDim.x) {
+    float acc = 0.0f;
+    for (int j = 0; j < Z; ++j)                                   // first index_add_ (l bins), in j order
+      if (s_l[j] == k) acc += s_lo[j];
+    for (int j = 0; j < Z; ++j)                                   // then the u bins
+      if (s_u[j] == k) acc += s_hi[j];
+    s_m[k] = acc;
+    m_out[(int64_t)b * Z + k] = acc;
+  }
+  __syncthreads();
+
+  // ---------------- online(states): log p(s_t, a_t)              agent.py:66-67
+  const float* lg_s = logits + (int64_t)b * NZ;
+  const int act = (int)actions[b];
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    float acc = 0.0f;
+    for (int a = 0; a < A; ++a) acc += lg_s[Z + a * Z + z];
+    s_mean[z] = acc / (float)A;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int z = t; z < Z; z += (int)blockDim.x) mx = fmaxf(mx, rb_dueling_q(lg_s, s_mean, Z, act, z));
+  mx = rb_block_max(mx, s_red);
+  float se = 0.0f;
+  for (int z = t; z < Z; z += (int)blockDim.x) se += expf(rb_dueling_q(lg_s, s_mean, Z, act, z) - mx);
+  se = rb_block_sum(se, s_red);
+  const float lse = logf(se);
+  float part_loss = 0.0f, part_m = 0.0f;
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    const float lp = (rb_dueling_q(lg_s, s_mean, Z, act, z) - mx) - lse;   // log_softmax
+    s_logp[z] = lp;
+    log_ps_a_out[(int64_t)b * Z + z] = lp;
+    part_loss += s_m[z] * lp;
+    part_m += s_m[z];
+  }
+  const float dot = rb_block_sum(part_loss, s_red);
+  const float msum = rb_block_sum(part_m, s_red);
+  if (t == 0) loss_out[b] = -dot;                                  // agent.py:94
+  __syncthreads();
+
+  // ---------------- backward of mean(w * loss) to the logits     agent.py:96
+  // d/dq[z] = (w/B) * (p[z] * sum(m) - m[z]) on the taken action; dueling adjoint:
+  // dv[z] = g[z] ; da[a'][z] = (delta(a',act) - 1/A) * g[z]
+  const float coef = weights[b] / (float)B;
+  float* dl = dlogits + (int64_t)b * NZ;
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    const float g = coef * (expf(s_logp[z]) * msum - s_m[z]);
+    dl[z] = g;
+    const float ga = g / (float)A;
+    for (int a = 0; a < A; ++a) dl[Z + a * Z + z] = (a == act ? g : 0.0f) - ga;
+  }
+}
+
+// Agent.act / evaluate_q head (agent.py:53-55, 110-112) for ONE image at logits row `row`.
+__global__ __launch_bounds__(256) void k_head_act(int Z, int A, const float* logits, int row, const float* support,
+                                                   int32_t* action_out, float* q_out) {
+  __shared__ float s_mean[RB_MAX_ATOMS];
+  __shared__ float s_ev[RB_MAX_ACTIONS];
+  const int t = (int)threadIdx.x;
+  const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
+  const int NZ = Z + A * Z;
+  const float* lg = logits + (int64_t)row * NZ;
+  for (int z = t; z < Z; z += (int)blockDim.x) {
+    float acc = 0.0f;
+    for (int a = 0; a < A; ++a) acc += lg[Z + a * Z + z];
+    s_mean[z] = acc / (float)A;
+  }
+  __syncthreads();
+  for (int a = wave; a < A; a += nw) {
+    float mx = -INFINITY;
+    for (int z = lane; z < Z; z += 64) mx = fmaxf(mx, rb_dueling_q(lg, s_mean, Z, a, z));
+    mx = rb_wave_max(mx);
+    float se = 0.0f, sv = 0.0f;
+    for (int z = lane; z < Z; z += 64) {
+      const float e = expf(rb_dueling_q(lg, s_mean, Z, a, z) - mx);
+      se += e;
+      sv += support[z] * e;
+    }
+    se = rb_wave_sum(se);
+    sv = rb_wave_sum(sv);
+    if (lane == 0) s_ev[a] = sv / se;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int best = 0;
+    float bv = s_ev[0];
+    for (int a = 1; a < A; ++a)
+      if (s_ev[a] > bv) { bv = s_ev[a]; best = a; }
+    if (action_out) *action_out = best;
+    if (q_out) *q_out = bv;
+  }
+}
+
+// -------------------------------------------------------------- global-norm clip --
+// clip_grad_norm_ (agent.py:97).  Stage 1: per-block sum of squares (fixed tree order).
+__global__ __launch_bounds__(256) void k_sumsq(const float* g, int64_t n, float* part) {
+  __shared__ float s_red[16];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    acc = fmaf(g[i], g[i], acc);
+  acc = rb_block_sum(acc, s_red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+// Stage 2: every block re-reduces the partials (same order everywhere), then scales its slice.
+__global__ __launch_bounds__(256) void k_clip_scale(float* g, int64_t n, const float* part, int nparts, float max_norm,
+                                                     float* norm_out) {
+  __shared__ float s_red[16];
+  float acc = 0.0f;
+  for (int i = (int)threadIdx.x; i < nparts; i += (int)blockDim.x) acc += part[i];
+  acc = rb_block_sum(acc, s_red);
+  const float total = sqrtf(acc);
+  float coef = max_norm / (total + 1e-6f);
+  if (coef > 1.0f) coef = 1.0f;                                    // clamp(max=1.0)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
+  if (coef < 1.0f)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+      g[i] *= coef;
+}
+
+// ========================================================================= host ==
+static int pick_splits(int64_t tiles, int ksteps, int64_t target_blocks) {
+  int64_t s = target_blocks / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (s > ksteps) s = ksteps;
+  if (s > 64) s = 64;
+  const int64_t per = (ksteps + s - 1) / s;   // no empty trailing split (every partial slice gets written)
+  s = (ksteps + per - 1) / per;
+  return (int)s;
+}
+
+template <class G>
+static int launch_conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
+                           const NetPtrs& tg, hipStream_t stream) {
+  const ConvLayer& c = l->L.conv[layer];
+  const int n_max = (n_on > n_tg ? n_on : n_tg) * G::P;
+  if (layer == 0) {
+    ConvFwdProb<G, true> p;
+    p.cin = c.cin; p.cout = c.cout;
+    p.n_img[0] = n_on; p.n_img[1] = n_tg; p.img_base[0] = 0; p.img_base[1] = n_on;
+    p.w[0] = on.conv_w[0]; p.w[1] = tg.conv_w[0]; p.bias[0] = on.conv_b[0]; p.bias[1] = tg.conv_b[0];
+    p.src = src; p.in_f = nullptr; p.out = l->act[0];
+    RB_LAUNCH((k_gemm<1, 2, ConvFwdProb<G, true>>), dim3(1, (unsigned)rb_div_up(n_max, 64), 2), dim3(128), stream, p);
+  } else {
+    ConvFwdProb<G, false> p;
+    p.cin = c.cin; p.cout = c.cout;
+    p.n_img[0] = n_on; p.n_img[1] = n_tg; p.img_base[0] = 0; p.img_base[1] = n_on;
+    p.w[0] = on.conv_w[layer]; p.w[1] = tg.conv_w[layer]; p.bias[0] = on.conv_b[layer]; p.bias[1] = tg.conv_b[layer];
+    p.src = src; p.in_f = l->act[layer - 1]; p.out = l->act[layer];
+    RB_LAUNCH((k_gemm<2, 1, ConvFwdProb<G, false>>), dim3(1, (unsigned)rb_div_up(n_max, 32), 2), dim3(128), stream, p);
+  }
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
+                    const NetPtrs& tg, hipStream_t stream) {
+  const ConvLayer& c = l->L.conv[layer];
+  if (c.ks == 8) return launch_conv_fwd<GeomC1>(l, layer, n_on, n_tg, src, on, tg, stream);
+  if (c.ks == 4) return launch_conv_fwd<GeomC2>(l, layer, n_on, n_tg, src, on, tg, stream);
+  if (c.ks == 3) return launch_conv_fwd<GeomC3>(l, layer, n_on, n_tg, src, on, tg, stream);
+  if (c.ih == 84) return launch_conv_fwd<GeomD1>(l, layer, n_on, n_tg, src, on, tg, stream);
+  return launch_conv_fwd<GeomD2>(l, layer, n_on, n_tg, src, on, tg, stream);
+}
+
+// Forward of n_on online images + n_tg target images up to the logits.
+static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on, const NetPtrs& tg,
+                   hipStream_t stream) {
+  const Layout& L = l->L;
+  const int NI = n_on + n_tg;
+  for (int layer = 0; layer < L.nconv; ++layer) {
+    int rc = conv_fwd(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (rc != RB_OK) return rc;
+  }
+  const float* feat = l->act[L.nconv - 1];
+  {
+    FcHFwdProb p;
+    p.F = L.F; p.H = L.H; p.NI = NI; p.splits = l->hs;
+    p.n_img[0] = n_on; p.n_img[1] = n_tg; p.img_base[0] = 0; p.img_base[1] = n_on;
+    p.feat = feat; p.net[0] = on; p.net[1] = tg; p.part = l->hpart;
+    const int m_max = n_on > n_tg ? n_on : n_tg;
+    RB_LAUNCH((k_gemm<2, 2, FcHFwdProb>),
+              dim3((unsigned)rb_div_up(m_max, 64), (unsigned)rb_div_up(2 * L.H, 64), (unsigned)(2 * l->hs)), dim3(256),
+              stream, p);
+    RB_LAUNCH_CHECK();
+    const int64_t total = (int64_t)NI * 2 * L.H;
+    RB_LAUNCH(k_fc_h_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->hpart, l->hs, NI,
+              2 * L.H, n_on, on, tg, l->h);
+    RB_LAUNCH_CHECK();
+  }
+  {
+    FcZFwdProb p;
+    p.H = L.H; p.Z = L.Z; p.NZ = L.NZ;
+    p.n_img[0] = n_on; p.n_img[1] = n_tg; p.img_base[0] = 0; p.img_base[1] = n_on;
+    p.h = l->h; p.net[0] = on; p.net[1] = tg; p.logits = l->logits;
+    const int m_max = n_on > n_tg ? n_on : n_tg;
+    RB_LAUNCH((k_gemm<1, 1, FcZFwdProb>),
+              dim3((unsigned)rb_div_up(m_max, 32), (unsigned)rb_div_up(L.NZ - L.Z, 32), 4), dim3(64), stream, p);
+    RB_LAUNCH_CHECK();
+  }
+  return RB_OK;
+}
+
+template <class G>
+static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream) {
+  const Layout& L = l->L;
+  const ConvLayer& c = L.conv[layer];
+  const int K = c.K();
+  float* gw = l->grads + L.conv_w[layer];
+  float* gb = l->grads + L.conv_b[layer];
+  const int splits = l->ws[layer];
+  if (layer == 0) {
+    ConvDwProb<G, true> p;
+    p.B = L.B; p.cin = c.cin; p.cout = c.cout; p.splits = splits;
+    p.dy = l->dact[0]; p.x_u8 = states; p.x_f = nullptr; p.part = l->dw_part[0];
+    RB_LAUNCH((k_gemm<1, 2, ConvDwProb<G, true>>),
+              dim3((unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(K + 1, 64), (unsigned)splits), dim3(128), stream, p);
+  } else {
+    ConvDwProb<G, false> p;
+    p.B = L.B; p.cin = c.cin; p.cout = c.cout; p.splits = splits;
+    p.dy = l->dact[layer]; p.x_u8 = nullptr; p.x_f = l->act[layer - 1]; p.part = l->dw_part[layer];
+    RB_LAUNCH((k_gemm<2, 2, ConvDwProb<G, false>>),
+              dim3((unsigned)rb_div_up(c.cout, 64), (unsigned)rb_div_up(K + 1, 64), (unsigned)splits), dim3(256), stream, p);
+  }
+  RB_LAUNCH_CHECK();
+  const int64_t total = (int64_t)c.cout * (K + 1);
+  RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream,
+            (const float*)l->dw_part[layer], splits, c.cout, K, gw, gb);
+  RB_LAUNCH_CHECK();
+  if (layer > 0) {
+    ConvDxProb<G> p;
+    p.B = L.B; p.cin = c.cin; p.cout = c.cout;
+    p.w = l->p_online + L.conv_w[layer]; p.dy = l->dact[layer]; p.x_act = l->act[layer - 1]; p.dx = l->dact[layer - 1];
+    const int nyy = (G::IH + G::S - 1) / G::S;
+    const int n_max = L.B * nyy * nyy;
+    if (c.cin <= 32) {
+      RB_LAUNCH((k_gemm<1, 2, ConvDxProb<G>>), dim3(1, (unsigned)rb_div_up(n_max, 64), (unsigned)(G::S * G::S)),
+                dim3(128), stream, p);
+    } else {
+      RB_LAUNCH((k_gemm<2, 1, ConvDxProb<G>>),
+                dim3((unsigned)rb_div_up(c.cin, 64), (unsigned)rb_div_up(n_max, 32), (unsigned)(G::S * G::S)), dim3(128),
+                stream, p);
+    }
+    RB_LAUNCH_CHECK();
+  }
+  return RB_OK;
+}
+
+static int conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream) {
+  const ConvLayer& c = l->L.conv[layer];
+  if (c.ks == 8) return launch_conv_bwd<GeomC1>(l, layer, states, stream);
+  if (c.ks == 4) return launch_conv_bwd<GeomC2>(l, layer, states, stream);
+  if (c.ks == 3) return launch_conv_bwd<GeomC3>(l, layer, states, stream);
+  if (c.ih == 84) return launch_conv_bwd<GeomD1>(l, layer, states, stream);
+  return launch_conv_bwd<GeomD2>(l, layer, states, stream);
+}
+
+// torch.linspace(start, end, steps) float32 semantics (agent.py:18): step = (end-start)/(steps-1);
+// first half counts up from start, second half counts down from end.
+static void linspace_f32(float start, float end, int steps, float* out) {
+  const float step = (end - start) / (float)(steps - 1);
+  const int half = steps / 2;
+  for (int i = 0; i < steps; ++i)
+    out[i] = i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+extern "C" {
+
+int rb_learner_sizes(const rb_learner_config_t* cfg, int64_t* n_params, int64_t* n_noise) {
+  Layout L;
+  int rc = make_layout(cfg, &L);
+  if (rc != RB_OK) return rc;
+  if (n_params) *n_params = L.n_params;
+  if (n_noise) *n_noise = L.n_noise;
+  return RB_OK;
+}
+
+static void set_desc(rb_tensor_desc_t* d, const char* name, int64_t off, int ndim, int s0, int s1, int s2, int s3) {
+  memset(d, 0, sizeof(*d));
+  snprintf(d->name, sizeof(d->name), "%s", name);
+  d->offset = off; d->ndim = ndim;
+  d->shape[0] = s0; d->shape[1] = s1; d->shape[2] = s2; d->shape[3] = s3;
+}
+
+int rb_learner_param_layout(const rb_learner_config_t* cfg, rb_tensor_desc_t* descs, int32_t* n) {
+  Layout L;
+  int rc = make_layout(cfg, &L);
+  if (rc != RB_OK) return rc;
+  RB_REQUIRE(n != nullptr, "rb_learner_param_layout: n is NULL");
+  const int count = 2 * L.nconv + 16;
+  if (!descs) { *n = count; return RB_OK; }
+  RB_REQUIRE(*n >= count, "rb_learner_param_layout: need room for %d descriptors", count);
+  int i = 0;
+  char name[48];
+  for (int l = 0; l < L.nconv; ++l) {
+    const ConvLayer& c = L.conv[l];
+    snprintf(name, sizeof(name), "convs.%d.weight", 2 * l);
+    set_desc(&descs[i++], name, L.conv_w[l], 4, c.cout, c.cin, c.ks, c.ks);
+    snprintf(name, sizeof(name), "convs.%d.bias", 2 * l);
+    set_desc(&descs[i++], name, L.conv_b[l], 1, c.cout, 0, 0, 0);
+  }
+  const int64_t HF = (int64_t)L.H * L.F, ZH = (int64_t)L.Z * L.H;
+  const int AZ = L.A * L.Z;
+  set_desc(&descs[i++], "fc_h_v.weight_mu", L.h_mu, 2, L.H, L.F, 0, 0);
+  set_desc(&descs[i++], "fc_h_v.weight_sigma", L.h_sigma, 2, L.H, L.F, 0, 0);
+  set_desc(&descs[i++], "fc_h_v.bias_mu", L.h_bmu, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_h_v.bias_sigma", L.h_bsigma, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_h_a.weight_mu", L.h_mu + HF, 2, L.H, L.F, 0, 0);
+  set_desc(&descs[i++], "fc_h_a.weight_sigma", L.h_sigma + HF, 2, L.H, L.F, 0, 0);
+  set_desc(&descs[i++], "fc_h_a.bias_mu", L.h_bmu + L.H, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_h_a.bias_sigma", L.h_bsigma + L.H, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_v.weight_mu", L.z_mu, 2, L.Z, L.H, 0, 0);
+  set_desc(&descs[i++], "fc_z_v.weight_sigma", L.z_sigma, 2, L.Z, L.H, 0, 0);
+  set_desc(&descs[i++], "fc_z_v.bias_mu", L.z_bmu, 1, L.Z, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_v.bias_sigma", L.z_bsigma, 1, L.Z, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_a.weight_mu", L.z_mu + ZH, 2, AZ, L.H, 0, 0);
+  set_desc(&descs[i++], "fc_z_a.weight_sigma", L.z_sigma + ZH, 2, AZ, L.H, 0, 0);
+  set_desc(&descs[i++], "fc_z_a.bias_mu", L.z_bmu + L.Z, 1, AZ, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_a.bias_sigma", L.z_bsigma + L.Z, 1, AZ, 0, 0, 0);
+  *n = i;
+  return RB_OK;
+}
+
+int rb_learner_noise_layout(const rb_learner_config_t* cfg, rb_tensor_desc_t* descs, int32_t* n) {
+  Layout L;
+  int rc = make_layout(cfg, &L);
+  if (rc != RB_OK) return rc;
+  RB_REQUIRE(n != nullptr, "rb_learner_noise_layout: n is NULL");
+  if (!descs) { *n = 8; return RB_OK; }
+  RB_REQUIRE(*n >= 8, "rb_learner_noise_layout: need room for 8 descriptors");
+  int i = 0;
+  set_desc(&descs[i++], "fc_h_v.eps_in", L.h_ein, 1, L.F, 0, 0, 0);
+  set_desc(&descs[i++], "fc_h_v.eps_out", L.h_eout, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_h_a.eps_in", L.h_ein + L.F, 1, L.F, 0, 0, 0);
+  set_desc(&descs[i++], "fc_h_a.eps_out", L.h_eout + L.H, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_v.eps_in", L.z_ein, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_v.eps_out", L.z_eout, 1, L.Z, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_a.eps_in", L.z_ein + L.H, 1, L.H, 0, 0, 0);
+  set_desc(&descs[i++], "fc_z_a.eps_out", L.z_eout + L.Z, 1, L.A * L.Z, 0, 0, 0);
+  *n = i;
+  return RB_OK;
+}
+
+int64_t rb_learner_noise_draws(const rb_learner_config_t* cfg) {
+  Layout L;
+  if (make_layout(cfg, &L) != RB_OK) return -1;
+  return 2 * (int64_t)L.F + 2 * (int64_t)L.H + 2 * (int64_t)L.H + L.NZ;
+}
+
+int rb_learner_destroy(rb_learner_t* l) {
+  if (!l) return RB_OK;
+  float** owned[] = {&l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
+                     &l->logits, &l->dlogits, &l->dh, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
+                     &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
+  for (float** p : owned)
+    if (*p) (void)hipFree(*p);
+  if (l->a_star) (void)hipFree(l->a_star);
+  delete l;
+  return RB_OK;
+}
+
+int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float* online_params_dev,
+                      float* target_params_dev, float* grads_dev, float* online_noise_dev, float* target_noise_dev,
+                      uint64_t seed) {
+  RB_REQUIRE(out && cfg && online_params_dev && target_params_dev && grads_dev && online_noise_dev && target_noise_dev,
+             "rb_learner_create: NULL argument");
+  Layout L;
+  int rc = make_layout(cfg, &L);
+  if (rc != RB_OK) return rc;
+  rb_learner* l = new (std::nothrow) rb_learner();
+  if (!l) { rb_set_error("rb_learner_create: host OOM"); return RB_ERR_OOM; }
+  memset(l, 0, sizeof(*l));
+  l->cfg = *cfg; l->L = L;
+  l->p_online = online_params_dev; l->p_target = target_params_dev; l->grads = grads_dev;
+  l->n_online = online_noise_dev; l->n_target = target_noise_dev;
+  l->seed = seed; l->noise_epoch = 0;
+  l->gamma_n = (float)pow(cfg->discount, (double)cfg->multi_step);
+  l->delta_z = (float)(((double)cfg->v_max - (double)cfg->v_min) / (double)(cfg->atoms - 1));
+  const int B = L.B, NI = 3 * B;
+  // split-K factors: aim for >= ~2 workgroups per CU on the 256-CU part
+  l->hs = pick_splits(rb_div_up(2 * B, 64) * rb_div_up(2 * L.H, 64) * 2, (L.F + 15) / 16, 512);
+  l->xs = pick_splits(rb_div_up(B, 32) * rb_div_up(L.F, 64), (2 * L.H + 15) / 16, 512);
+  for (int i = 0; i < L.nconv; ++i) {
+    const ConvLayer& c = L.conv[i];
+    const int64_t tiles = i == 0 ? rb_div_up(c.cout, 32) * rb_div_up(c.K() + 1, 64)
+                                 : rb_div_up(c.cout, 64) * rb_div_up(c.K() + 1, 64);
+    l->ws[i] = pick_splits(tiles, (B * c.P() + 15) / 16, 512);
+  }
+#define RB_ALLOC(ptr, count)                                                                         \
+  do {                                                                                               \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(count) * 4);                                  \
+    if (e_ != hipSuccess) {                                                                          \
+      rb_set_error("rb_learner_create: hipMalloc(%lld B) failed: %s", (long long)(count) * 4, hipGetErrorString(e_)); \
+      rb_learner_destroy(l);                                                                         \
+      return RB_ERR_OOM;                                                                             \
+    }                                                                                                \
+  } while (0)
+  for (int i = 0; i < L.nconv; ++i) {
+    const ConvLayer& c = L.conv[i];
+    RB_ALLOC(l->act[i], (int64_t)NI * c.cout * c.P());
+    RB_ALLOC(l->dact[i], (int64_t)B * c.cout * c.P());
+    RB_ALLOC(l->dw_part[i], (int64_t)l->ws[i] * c.cout * (c.K() + 1));
+  }
+  RB_ALLOC(l->hpart, (int64_t)l->hs * NI * 2 * L.H);
+  RB_ALLOC(l->h, (int64_t)NI * 2 * L.H);
+  RB_ALLOC(l->logits, (int64_t)NI * L.NZ);
+  RB_ALLOC(l->dlogits, (int64_t)B * L.NZ);
+  RB_ALLOC(l->dh, (int64_t)B * 2 * L.H);
+  RB_ALLOC(l->dfeat_part, (int64_t)l->xs * B * L.F);
+  RB_ALLOC(l->log_ps_a, (int64_t)B * L.Z);
+  RB_ALLOC(l->pns_a, (int64_t)B * L.Z);
+  RB_ALLOC(l->m, (int64_t)B * L.Z);
+  RB_ALLOC(l->a_star, (int64_t)B);
+  RB_ALLOC(l->support, (int64_t)L.Z);
+  RB_ALLOC(l->zero_noise, L.n_noise);
+  RB_ALLOC(l->norm_part, 1024);
+#undef RB_ALLOC
+  float sup[RB_MAX_ATOMS];
+  linspace_f32(cfg->v_min, cfg->v_max, L.Z, sup);
+  RB_HIP_TRY(hipMemcpy(l->support, sup, L.Z * sizeof(float), hipMemcpyHostToDevice));
+  RB_HIP_TRY(hipMemset(l->zero_noise, 0, L.n_noise * sizeof(float)));
+  RB_HIP_TRY(hipMemset(l->hpart, 0, (size_t)l->hs * NI * 2 * L.H * 4));
+  *out = l;
+  return RB_OK;
+}
+
+int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_reset_noise: NULL handle");
+  RB_REQUIRE(which == 0 || which == 1, "rb_learner_reset_noise: which must be 0 (online) or 1 (target)");
+  const Layout& L = l->L;
+  NoiseMap map;
+  const int64_t counts[8] = {L.F, L.H, L.F, L.H, L.H, L.Z, L.H, (int64_t)L.A * L.Z};
+  const int64_t dst[8] = {L.h_ein, L.h_eout, L.h_ein + L.F, L.h_eout + L.H, L.z_ein, L.z_eout, L.z_ein + L.H, L.z_eout + L.Z};
+  map.seg_begin[0] = 0;
+  for (int i = 0; i < 8; ++i) { map.seg_begin[i + 1] = map.seg_begin[i] + counts[i]; map.dst[i] = dst[i]; }
+  float* noise = which == 0 ? l->n_online : l->n_target;
+  const uint64_t epoch = ++l->noise_epoch;
+  RB_LAUNCH(k_noise, dim3((unsigned)rb_div_up(map.seg_begin[8], 256)), dim3(256), stream, noise, raw_normals_dev, map,
+            l->seed, epoch);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_dev, float* q_dev,
+                   rb_stream_t stream) {
+  RB_REQUIRE(l && state_dev, "rb_learner_act: NULL argument");
+  const Layout& L = l->L;
+  ImgSrc src;
+  src.u8_states = nullptr; src.u8_next = nullptr; src.f32 = state_dev; src.B = 1;
+  const NetPtrs on = net_ptrs(L, l->p_online, noisy ? l->n_online : l->zero_noise);
+  int rc = forward(l, 1, 0, src, on, on, (hipStream_t)stream);
+  if (rc != RB_OK) return rc;
+  RB_LAUNCH(k_head_act, dim3(1), dim3(256), stream, L.Z, L.A, (const float*)l->logits, 0, (const float*)l->support,
+            action_dev, q_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* next_states_dev,
+                     const int64_t* actions_dev, const float* returns_dev, const float* nonterminals_dev,
+                     const float* weights_dev, float* loss_dev, rb_stream_t stream_) {
+  RB_REQUIRE(l && states_dev && next_states_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev && loss_dev,
+             "rb_learner_learn: NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  const Layout& L = l->L;
+  const int B = L.B;
+  ImgSrc src;
+  src.u8_states = states_dev; src.u8_next = next_states_dev; src.f32 = nullptr; src.B = B;
+  const NetPtrs on = net_ptrs(L, l->p_online, l->n_online);
+  const NetPtrs tg = net_ptrs(L, l->p_target, l->n_target);
+  int rc = forward(l, 2 * B, B, src, on, tg, stream);
+  if (rc != RB_OK) return rc;
+  RB_LAUNCH(k_head, dim3((unsigned)B), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
+            nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
+  RB_LAUNCH_CHECK();
+
+  // ---- backward (online net, images [0,B))
+  FcGradOut gz;
+  gz.g_mu = l->grads + L.z_mu; gz.g_sigma = l->grads + L.z_sigma; gz.g_bmu = l->grads + L.z_bmu;
+  gz.g_bsigma = l->grads + L.z_bsigma; gz.eout = on.z_eout; gz.ein = on.z_ein;
+  {
+    FcZDwProb p;
+    p.B = B; p.H = L.H; p.Z = L.Z; p.NZ = L.NZ; p.dlogits = l->dlogits; p.h = l->h; p.o = gz;
+    RB_LAUNCH((k_gemm<1, 2, FcZDwProb>),
+              dim3((unsigned)rb_div_up(L.NZ - L.Z, 32), (unsigned)rb_div_up(L.H + 1, 64), 2), dim3(128), stream, p);
+    RB_LAUNCH_CHECK();
+  }
+  {
+    FcZDxProb p;
+    p.B = B; p.H = L.H; p.Z = L.Z; p.NZ = L.NZ; p.dlogits = l->dlogits; p.h = l->h; p.net = on; p.dh = l->dh;
+    RB_LAUNCH((k_gemm<1, 1, FcZDxProb>), dim3((unsigned)rb_div_up(B, 32), (unsigned)rb_div_up(L.H, 32), 2), dim3(64),
+              stream, p);
+    RB_LAUNCH_CHECK();
+  }
+  const float* feat = l->act[L.nconv - 1];
+  {
+    FcHDwProb p;
+    p.B = B; p.H = L.H; p.F = L.F; p.dh = l->dh; p.feat = feat;
+    p.o.g_mu = l->grads + L.h_mu; p.o.g_sigma = l->grads + L.h_sigma; p.o.g_bmu = l->grads + L.h_bmu;
+    p.o.g_bsigma = l->grads + L.h_bsigma; p.o.eout = on.h_eout; p.o.ein = on.h_ein;
+    RB_LAUNCH((k_gemm<2, 2, FcHDwProb>), dim3((unsigned)rb_div_up(2 * L.H, 64), (unsigned)rb_div_up(L.F + 1, 64), 1),
+              dim3(256), stream, p);
+    RB_LAUNCH_CHECK();
+  }
+  {
+    FcHDxProb p;
+    p.B = B; p.H = L.H; p.F = L.F; p.splits = l->xs; p.dh = l->dh; p.net = on; p.part = l->dfeat_part;
+    RB_LAUNCH((k_gemm<1, 2, FcHDxProb>), dim3((unsigned)rb_div_up(B, 32), (unsigned)rb_div_up(L.F, 64), (unsigned)l->xs),
+              dim3(128), stream, p);
+    RB_LAUNCH_CHECK();
+    const int64_t total = (int64_t)B * L.F;
+    RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
+              l->xs, total, feat, l->dact[L.nconv - 1]);
+    RB_LAUNCH_CHECK();
+  }
+  for (int layer = L.nconv - 1; layer >= 0; --layer) {
+    rc = conv_bwd(l, layer, states_dev, stream);
+    if (rc != RB_OK) return rc;
+  }
+  return RB_OK;
+}
+
+int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_clip_grad: NULL handle");
+  const int64_t n = l->L.n_params;
+  int nparts = (int)rb_div_up(n, 256 * 16);
+  if (nparts > 1024) nparts = 1024;
+  RB_LAUNCH(k_sumsq, dim3((unsigned)nparts), dim3(256), stream, (const float*)l->grads, n, l->norm_part);
+  RB_LAUNCH_CHECK();
+  RB_LAUNCH(k_clip_scale, dim3((unsigned)nparts), dim3(256), stream, l->grads, n, (const float*)l->norm_part, nparts,
+            max_norm, norm_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_sync_target: NULL handle");
+  // load_state_dict copies parameters AND the epsilon buffers (agent.py:102-103)
+  RB_HIP_TRY(hipMemcpyAsync(l->p_target, l->p_online, (size_t)l->L.n_params * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  RB_HIP_TRY(hipMemcpyAsync(l->n_target, l->n_online, (size_t)l->L.n_noise * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return RB_OK;
+}
+
+int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream) {
+  RB_REQUIRE(l && out_dev, "rb_learner_debug_read: NULL argument");
+  const Layout& L = l->L;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case 0: src = l->log_ps_a; bytes = (size_t)L.B * L.Z * 4; break;
+    case 1: src = l->m; bytes = (size_t)L.B * L.Z * 4; break;
+    case 2: src = l->a_star; bytes = (size_t)L.B * 4; break;
+    case 3: src = l->pns_a; bytes = (size_t)L.B * L.Z * 4; break;
+    case 4: src = l->logits; bytes = (size_t)3 * L.B * L.NZ * 4; break;
+    default: rb_set_error("rb_learner_debug_read: unknown selector %d", what); return RB_ERR_INVALID;
+  }
+  RB_HIP_TRY(hipMemcpyAsync(out_dev, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return RB_OK;
+}
+
+}  // extern "C"

@@ -176,3 +176,130 @@ class CAbiReplayAdapter:
         L.check(self.lib, self.lib.rb_replay_state_at(self.h, int(i), m.ptr(out), m.stream))
         m.sync()
         return m.download(out)
+
+
+# =============================================================================== learn step
+import scenarios  # noqa: E402
+
+
+def learner_config(c):
+    return L.LearnerConfig(batch=c["batch"], atoms=c["atoms"], actions=c["actions"], history=c["history"],
+                           hidden=c["hidden"], architecture=0 if c["architecture"] == "canonical" else 1,
+                           multi_step=c["multi_step"], v_min=c["v_min"], v_max=c["v_max"], discount=c["discount"])
+
+
+def query_layout(lib, cfg, fn):
+    n = C.c_int32(0)
+    L.check(lib, fn(C.byref(cfg), None, C.byref(n)))
+    descs = (L.TensorDesc * n.value)()
+    L.check(lib, fn(C.byref(cfg), descs, C.byref(n)))
+    out = {}
+    for d in descs[:n.value]:
+        shape = tuple(d.shape[i] for i in range(d.ndim))
+        out[d.name.decode()] = (int(d.offset), shape)
+    return out
+
+
+class CAbiLearnAdapter:
+    """Drives rb_learner_* exactly like rainbow_amd.agent.Agent does (learn -> clip -> torch Adam)."""
+
+    def __init__(self, lib, mem, name):
+        import torch
+        self.torch = torch
+        self.lib, self.mem = lib, mem
+        self.c = scenarios.LEARN_CONFIGS[name]
+        self.hy = scenarios.LEARN_HYPER
+        self.cfg = learner_config(self.c)
+        n_params, n_noise = C.c_int64(0), C.c_int64(0)
+        L.check(lib, lib.rb_learner_sizes(C.byref(self.cfg), C.byref(n_params), C.byref(n_noise)))
+        self.n_params, self.n_noise = n_params.value, n_noise.value
+        self.layout = query_layout(lib, self.cfg, lib.rb_learner_param_layout)
+        self.p_on = mem.empty((self.n_params,), np.float32)
+        self.p_tg = mem.empty((self.n_params,), np.float32)
+        self.grads = mem.empty((self.n_params,), np.float32)
+        self.z_on = mem.empty((self.n_noise,), np.float32)
+        self.z_tg = mem.empty((self.n_noise,), np.float32)
+        self.h = C.c_void_p()
+        L.check(lib, lib.rb_learner_create(C.byref(self.h), C.byref(self.cfg), mem.ptr(self.p_on), mem.ptr(self.p_tg),
+                                           mem.ptr(self.grads), mem.ptr(self.z_on), mem.ptr(self.z_tg), 1234))
+        self.opt = None
+
+    def close(self):
+        if self.h:
+            self.lib.rb_learner_destroy(self.h)
+            self.h = None
+
+    def _flat(self, params):
+        flat = np.zeros(self.n_params, dtype=np.float32)
+        for name, (off, shape) in self.layout.items():
+            a = np.asarray(params[name], dtype=np.float32)
+            assert a.shape == shape, (name, a.shape, shape)
+            flat[off:off + a.size] = a.ravel()
+        return flat
+
+    def _unflat(self, flat):
+        return {name: flat[off:off + int(np.prod(shape))].reshape(shape).copy() for name, (off, shape) in self.layout.items()}
+
+    def _as_torch(self, buf):
+        return self.torch.from_numpy(buf) if isinstance(buf, np.ndarray) else buf
+
+    def load(self, online, target):
+        m = self.mem
+        if isinstance(self.p_on, np.ndarray):
+            self.p_on[:] = self._flat(online)
+            self.p_tg[:] = self._flat(target)
+        else:
+            self.p_on.copy_(self.torch.from_numpy(self._flat(online)))
+            self.p_tg.copy_(self.torch.from_numpy(self._flat(target)))
+        p = self._as_torch(self.p_on).requires_grad_()
+        p.grad = self._as_torch(self.grads)
+        self.param_t = p
+        self.opt = self.torch.optim.Adam([p], lr=self.hy["lr"], eps=self.hy["adam_eps"])   # agent.py:46
+        m.sync()
+
+    def reset_noise_online(self, raw):
+        m = self.mem
+        r = m.upload(np.asarray(raw, dtype=np.float32))
+        L.check(self.lib, self.lib.rb_learner_reset_noise(self.h, 0, m.ptr(r), m.stream))
+        m.sync()
+
+    def learn_step(self, batch, target_raw):
+        m = self.mem
+        B = self.c["batch"]
+        r = m.upload(np.asarray(target_raw, dtype=np.float32))
+        L.check(self.lib, self.lib.rb_learner_reset_noise(self.h, 1, m.ptr(r), m.stream))       # agent.py:74
+        bufs = dict(states=m.upload(batch["states"]), next_states=m.upload(batch["next_states"]),
+                    actions=m.upload(batch["actions"].astype(np.int64)), returns=m.upload(batch["returns"]),
+                    nonterminals=m.upload(batch["nonterminals"].astype(np.float32).reshape(B)),
+                    weights=m.upload(batch["weights"]))
+        loss = m.empty((B,), np.float32)
+        norm = m.empty((1,), np.float32)
+        L.check(self.lib, self.lib.rb_learner_learn(self.h, m.ptr(bufs["states"]), m.ptr(bufs["next_states"]),
+                                                    m.ptr(bufs["actions"]), m.ptr(bufs["returns"]),
+                                                    m.ptr(bufs["nonterminals"]), m.ptr(bufs["weights"]), m.ptr(loss),
+                                                    m.stream))
+        L.check(self.lib, self.lib.rb_learner_clip_grad(self.h, self.hy["norm_clip"], m.ptr(norm), m.stream))
+        m.sync()
+        grads = self._unflat(m.download(self.grads))
+        self.opt.step()                                                                            # agent.py:98
+        m.sync()
+        return dict(loss=m.download(loss), grad_norm=float(m.download(norm)[0]), grads=grads)
+
+    def debug(self, what, shape, dtype):
+        m = self.mem
+        out = m.empty(shape, dtype)
+        L.check(self.lib, self.lib.rb_learner_debug_read(self.h, what, m.ptr(out), m.stream))
+        m.sync()
+        return m.download(out)
+
+    def params(self):
+        return self._unflat(self.mem.download(self.p_on.detach() if hasattr(self.p_on, "detach") else self.p_on))
+
+    def act(self, state, noisy):
+        m = self.mem
+        st = m.upload(np.asarray(state, dtype=np.float32))
+        a = m.empty((1,), np.int32)
+        q = m.empty((1,), np.float32)
+        L.check(self.lib, self.lib.rb_learner_act(self.h, m.ptr(st), 1 if noisy else 0, m.ptr(a), m.ptr(q), m.stream))
+        m.sync()
+        return int(m.download(a)[0]), float(m.download(q)[0])
