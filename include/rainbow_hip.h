@@ -44,6 +44,19 @@ typedef struct rb_learner rb_learner_t;
 
 const char* rb_last_error(void);
 int rb_abi_version(void);
+/* Synchronous copies between host memory and library/torch-owned device memory (state
+ * dump/restore of the replay buffer — main.py:94-100,118 pickles the whole memory — and
+ * white-box tests).  `stream` is synchronised first.                                     */
+int rb_copy_to_host(void* dst_host, const void* src_dev, size_t nbytes, rb_stream_t stream);
+int rb_copy_to_device(void* dst_dev, const void* src_host, size_t nbytes, rb_stream_t stream);
+
+/* Live kernel timing for bench.py's roofline line: every launch whose kernel expression
+ * contains `kernel_substr` (e.g. "FcHFwdProb") is bracketed by two hipEvents recorded on the
+ * stream it is launched on.  NULL/"" disables.  Not for use under stream capture.
+ * rb_profile_read synchronises the recorded events, returns their summed elapsed time and
+ * the number of launches, and resets the counters.                                        */
+int rb_profile_select(const char* kernel_substr);
+int rb_profile_read(double* total_ms, int64_t* launches);
 
 /* ===================================================================== replay ==
  * HBM-resident prioritised replay: SoA ring (frames u8[C][7056], timestep i32[C],

@@ -84,6 +84,25 @@ class SumTreeOracle:
         self.full = self.full or self.index == 0         # memory.py:60
         self.max = np.float32(max(np.float32(value), self.max))  # memory.py:54,61
 
+    def bulk_append(self, timesteps, frames_u8, actions, rewards, nonterminals):
+        """len(timesteps) sequential appends at the running max priority, vectorised: the tree is a pure
+        function of its leaves (memory.py:25,39), so rebuilding the touched ancestors level by level gives the
+        floats the one-at-a-time walks (memory.py:36-41) give.  Benchmark-fill helper."""
+        n = len(timesteps)
+        assert n <= self.capacity
+        pos = (self.index + np.arange(n)) % self.capacity
+        self.timestep[pos] = timesteps
+        self.frames[pos] = frames_u8
+        self.action[pos] = actions
+        self.reward[pos] = rewards
+        self.nonterminal[pos] = nonterminals
+        nodes = pos + self.tree_start
+        self.tree[nodes] = self.max
+        for _ in range(self.levels):
+            nodes = self._rebuild_parents_of(nodes)
+        self.full = self.full or self.index + n >= self.capacity
+        self.index = (self.index + n) % self.capacity
+
     # -- reads -------------------------------------------------------------------
     def find(self, values):
         """SegmentTree.find (memory.py:64-82) -> (probs f32, data_idx i64, tree_idx i64)."""

@@ -40,6 +40,10 @@ class TensorDesc(C.Structure):
 SIGNATURES = {
     "rb_last_error": (c_char_p, []),
     "rb_abi_version": (c_int, []),
+    "rb_copy_to_host": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "rb_copy_to_device": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "rb_profile_select": (c_int, [c_char_p]),
+    "rb_profile_read": (c_int, [C.POINTER(c_double), C.POINTER(c_int64)]),
     "rb_replay_create": (c_int, [C.POINTER(c_void_p), c_int64, c_int32, c_int32, c_double, c_double, c_uint64]),
     "rb_replay_destroy": (c_int, [c_void_p]),
     "rb_replay_buffers": (c_int, [c_void_p, C.POINTER(ReplayBuffers)]),

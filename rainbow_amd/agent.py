@@ -1,0 +1,278 @@
+"""Drop-in `Agent` for the reference's main.py / test.py (replaces /root/reference/agent.py + model.py).
+
+Same constructor and methods as the reference class (agent.py:12-118).  The networks are not
+nn.Modules: online / target parameters, gradients and factorised noise are flat float32 HBM
+buffers (torch tensors used purely as memory owners) and every forward / backward kernel is
+hand-written HIP behind librainbow_hip.so.  PyTorch-ROCm runs exactly one thing: the Adam step
+on the flat parameter buffer (agent.py:46,98).
+
+learn(mem):  rainbow_amd.memory.ReplayMemory  -> fully device-resident step, no host sync:
+                 sample -> 3 forwards + projection + loss + backward -> [RCCL all-reduce]
+                 -> global-norm clip -> Adam -> priority update
+             any other object with the reference's sample()/update_priorities() -> compat path.
+
+Multi-GPU (BASELINE config 5): one process per GPU, identical parameters, each replica owns its
+replay; gradients are averaged with ONE RCCL all-reduce of the flat buffer between backward and
+clip.  Enabled automatically when torch.distributed is initialised.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dist as rdist
+from .memory import ReplayMemory
+
+_LAYERS = ("fc_h_v", "fc_h_a", "fc_z_v", "fc_z_a")
+
+
+def _query_layout(lib, cfg, fn):
+    n = C.c_int32(0)
+    L.check(lib, fn(C.byref(cfg), None, C.byref(n)))
+    descs = (L.TensorDesc * n.value)()
+    L.check(lib, fn(C.byref(cfg), descs, C.byref(n)))
+    return [(d.name.decode(), int(d.offset), tuple(d.shape[i] for i in range(d.ndim))) for d in descs[:n.value]]
+
+
+class Agent:
+    def __init__(self, args, env):
+        self.device = torch.device(args.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("rainbow_amd.Agent runs on MI355X: args.device must be a cuda (ROCm) device, got %s"
+                               % self.device)
+        self._lib = L.load()
+        self.action_space = env.action_space()                       # agent.py:14
+        self.atoms = args.atoms
+        self.Vmin, self.Vmax = args.V_min, args.V_max
+        self.support = torch.linspace(args.V_min, args.V_max, self.atoms).to(device=self.device)   # agent.py:18
+        self.delta_z = (args.V_max - args.V_min) / (self.atoms - 1)
+        self.batch_size = args.batch_size
+        self.n = args.multi_step
+        self.discount = args.discount
+        self.norm_clip = args.norm_clip
+        self.training = True
+
+        arch = getattr(args, "architecture", "canonical")
+        self._cfg = L.LearnerConfig(batch=int(args.batch_size), atoms=int(args.atoms), actions=int(self.action_space),
+                                    history=int(args.history_length), hidden=int(args.hidden_size),
+                                    architecture=0 if arch == "canonical" else 1, multi_step=int(args.multi_step),
+                                    v_min=float(args.V_min), v_max=float(args.V_max), discount=float(args.discount))
+        n_params, n_noise = C.c_int64(0), C.c_int64(0)
+        L.check(self._lib, self._lib.rb_learner_sizes(C.byref(self._cfg), C.byref(n_params), C.byref(n_noise)))
+        self._layout = _query_layout(self._lib, self._cfg, self._lib.rb_learner_param_layout)
+        self._noise_layout = _query_layout(self._lib, self._cfg, self._lib.rb_learner_noise_layout)
+        d = self.device
+        self.params = torch.zeros(n_params.value, dtype=torch.float32, device=d)          # online, flat
+        self.target_params = torch.zeros(n_params.value, dtype=torch.float32, device=d)
+        self.grads = torch.zeros(n_params.value, dtype=torch.float32, device=d)
+        self.noise = torch.zeros(n_noise.value, dtype=torch.float32, device=d)
+        self.target_noise = torch.zeros(n_noise.value, dtype=torch.float32, device=d)
+        self._h = C.c_void_p()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        with torch.cuda.device(d):
+            L.check(self._lib, self._lib.rb_learner_create(
+                C.byref(self._h), C.byref(self._cfg), self.params.data_ptr(), self.target_params.data_ptr(),
+                self.grads.data_ptr(), self.noise.data_ptr(), self.target_noise.data_ptr(), seed))
+
+        self._init_parameters(float(getattr(args, "noisy_std", 0.1)))
+        if getattr(args, "model", None):                             # agent.py:26-36
+            if os.path.isfile(args.model):
+                self.load_state_dict(torch.load(args.model, map_location="cpu"))
+                print("Loading pretrained model: " + args.model)
+            else:
+                raise FileNotFoundError(args.model)
+        self.reset_noise()                                           # NoisyLinear.__init__ (model.py:23)
+        self.update_target_net()                                     # agent.py:41
+
+        self.params.requires_grad_(True)
+        self.params.grad = self.grads
+        try:
+            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps, fused=True)
+        except (TypeError, RuntimeError):
+            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps)
+        self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
+        self._norm = torch.zeros(1, dtype=torch.float32, device=d)
+        self._act_out = torch.zeros(1, dtype=torch.int32, device=d)
+        self._q_out = torch.zeros(1, dtype=torch.float32, device=d)
+        self._world = rdist.world_size()
+        if self._world > 1:   # identical replicas: rank 0's initial parameters everywhere
+            rdist.broadcast_parameters(self.params.detach(), 0)
+            self.update_target_net()
+
+    # ------------------------------------------------------------------ plumbing
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.rb_learner_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _view(self, flat, name):
+        for n, off, shape in self._layout:
+            if n == name:
+                return flat.detach()[off:off + int(np.prod(shape))].view(shape)
+        raise KeyError(name)
+
+    def _noise_view(self, flat, name):
+        for n, off, shape in self._noise_layout:
+            if n == name:
+                return flat[off:off + shape[0]]
+        raise KeyError(name)
+
+    def _init_parameters(self, noisy_std):
+        """Same distributions as the reference: Conv2d default U(+-1/sqrt(fan_in)) and
+        NoisyLinear.reset_parameters (model.py:25-30), drawn from torch's CPU generator."""
+        flat = torch.zeros(self.params.numel(), dtype=torch.float32)
+        for name, off, shape in self._layout:
+            numel = int(np.prod(shape))
+            if name.startswith("convs"):
+                if name.endswith("weight"):
+                    fan_in = int(np.prod(shape[1:]))
+                    self._last_fan_in = fan_in
+                else:
+                    fan_in = self._last_fan_in
+                bound = 1.0 / math.sqrt(fan_in)
+                flat[off:off + numel] = torch.empty(numel).uniform_(-bound, bound)
+            else:
+                kind = name.split(".")[1]
+                w_shape = dict((n, s) for n, _o, s in self._layout)[name.split(".")[0] + ".weight_mu"]
+                out_f, in_f = w_shape
+                if kind in ("weight_mu", "bias_mu"):
+                    bound = 1.0 / math.sqrt(in_f)
+                    flat[off:off + numel] = torch.empty(numel).uniform_(-bound, bound)
+                elif kind == "weight_sigma":
+                    flat[off:off + numel] = noisy_std / math.sqrt(in_f)
+                else:
+                    flat[off:off + numel] = noisy_std / math.sqrt(out_f)
+        with torch.no_grad():
+            self.params.copy_(flat)
+
+    # ------------------------------------------------------------------ reference API
+    def reset_noise(self, raw_normals=None):
+        """agent.py:49-50 (online net only).  raw_normals: optional float32 device tensor of N(0,1) draws in the
+        reference's order (parity hook)."""
+        ptr = None
+        if raw_normals is not None:
+            self._raw_on = raw_normals.to(device=self.device, dtype=torch.float32).contiguous()
+            ptr = self._raw_on.data_ptr()
+        L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 0, ptr, self._stream()))
+
+    def _reset_target_noise(self, raw_normals=None):
+        ptr = None
+        if raw_normals is not None:
+            self._raw_tg = raw_normals.to(device=self.device, dtype=torch.float32).contiguous()
+            ptr = self._raw_tg.data_ptr()
+        L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 1, ptr, self._stream()))   # agent.py:74
+
+    def _forward_single(self, state):
+        st = state.to(device=self.device, dtype=torch.float32).contiguous()
+        L.check(self._lib, self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0,
+                                                    self._act_out.data_ptr(), self._q_out.data_ptr(), self._stream()))
+
+    def act(self, state):
+        """agent.py:53-55: greedy action on the expected value of the (noisy) online distribution."""
+        self._forward_single(state)
+        return int(self._act_out.item())
+
+    def act_e_greedy(self, state, epsilon=0.001):
+        """agent.py:58-59."""
+        return np.random.randint(0, self.action_space) if np.random.random() < epsilon else self.act(state)
+
+    def evaluate_q(self, state):
+        """agent.py:110-112."""
+        self._forward_single(state)
+        return float(self._q_out.item())
+
+    def learn(self, mem, _target_raw_normals=None, _unit_uniforms=None):
+        """agent.py:61-100."""
+        B = self.batch_size
+        device_mem = isinstance(mem, ReplayMemory)
+        if device_mem:
+            o = mem.sample_device(B, _unit_uniforms)                                       # agent.py:63
+            idxs, states, next_states = o["tree_idxs"], o["states"], o["next_states"]
+            actions, returns, nonterminals, weights = o["actions"], o["returns"], o["nonterminals"], o["weights"]
+        else:   # foreign replay with the reference's API: float32 /255 states come back; re-quantise (exact for k/255)
+            idxs, s, actions, returns, ns, nonterminals, weights = mem.sample(B)
+            d = self.device
+            states = s.to(d).mul(255).round_().to(torch.uint8).contiguous()
+            next_states = ns.to(d).mul(255).round_().to(torch.uint8).contiguous()
+            actions = actions.to(device=d, dtype=torch.int64).contiguous()
+            returns = returns.to(device=d, dtype=torch.float32).contiguous()
+            nonterminals = nonterminals.to(device=d, dtype=torch.float32).reshape(B).contiguous()
+            weights = weights.to(device=d, dtype=torch.float32).contiguous()
+        self._reset_target_noise(_target_raw_normals)                                      # agent.py:74
+        L.check(self._lib, self._lib.rb_learner_learn(
+            self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
+            nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), self._stream()))   # agent.py:66-96
+        if self._world > 1:   # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
+            rdist.average_gradients(self.grads)
+        L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
+                                                          self._stream()))                # agent.py:97
+        self.optimiser.step()                                                              # agent.py:98
+        if device_mem:
+            mem.update_priorities(idxs, self._loss)                                        # agent.py:100, no D2H
+        else:
+            mem.update_priorities(idxs, self._loss.detach().cpu().numpy())
+
+    def update_target_net(self):
+        """agent.py:102-103."""
+        L.check(self._lib, self._lib.rb_learner_sync_target(self._h, self._stream()))
+
+    def train(self):
+        self.training = True        # agent.py:114-115
+
+    def eval(self):
+        self.training = False       # agent.py:117-118 -> mu-only forward (model.py:46)
+
+    # ------------------------------------------------------------------ checkpoints (agent.py:26-36,106-107)
+    def state_dict(self):
+        """Reference-compatible keys: convs.{0,2,4}.{weight,bias}, fc_*.{weight,bias}_{mu,sigma,epsilon}."""
+        sd = {}
+        for name, _off, _shape in self._layout:
+            sd[name] = self._view(self.params, name).clone()
+        for layer in _LAYERS:
+            e_in = self._noise_view(self.noise, layer + ".eps_in")
+            e_out = self._noise_view(self.noise, layer + ".eps_out")
+            sd[layer + ".weight_epsilon"] = torch.outer(e_out, e_in)    # model.py:39
+            sd[layer + ".bias_epsilon"] = e_out.clone()                 # model.py:40
+        order = []
+        for name, _o, _s in self._layout:
+            order.append(name)
+            if name.endswith("weight_sigma"):
+                order.append(name.replace("weight_sigma", "weight_epsilon"))
+            if name.endswith("bias_sigma"):
+                order.append(name.replace("bias_sigma", "bias_epsilon"))
+        return {k: sd[k] for k in order}
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        if "conv1.weight" in sd:                                                           # agent.py:29-32
+            for old, new in (("conv1.weight", "convs.0.weight"), ("conv1.bias", "convs.0.bias"),
+                             ("conv2.weight", "convs.2.weight"), ("conv2.bias", "convs.2.bias"),
+                             ("conv3.weight", "convs.4.weight"), ("conv3.bias", "convs.4.bias")):
+                sd[new] = sd.pop(old)
+        with torch.no_grad():
+            for name, _off, shape in self._layout:
+                t = sd[name]
+                if tuple(t.shape) != tuple(shape):
+                    raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(t.shape), shape))
+                self._view(self.params, name).copy_(t.to(self.device, torch.float32))
+            for layer in _LAYERS:   # epsilon buffers are rank-1: recover the factorised vectors
+                if layer + ".bias_epsilon" not in sd:
+                    continue
+                e_out = sd[layer + ".bias_epsilon"].to(self.device, torch.float32)
+                e_w = sd[layer + ".weight_epsilon"].to(self.device, torch.float32)
+                j = int(torch.argmax(e_out.abs()).item())
+                e_in = e_w[j] / e_out[j] if float(e_out[j]) != 0.0 else torch.zeros_like(e_w[j])
+                self._noise_view(self.noise, layer + ".eps_in").copy_(e_in)
+                self._noise_view(self.noise, layer + ".eps_out").copy_(e_out)
+
+    def save(self, path, name="model.pth"):
+        torch.save(self.state_dict(), os.path.join(path, name))

@@ -12,7 +12,74 @@ void rb_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- live kernel timing (rb_profile_select / rb_profile_read) ---------------------------
+#if !defined(RB_HOST_INTERP)
+#include <vector>
+int g_rb_prof_on = 0;
+static char g_prof_pat[128] = "";
+static std::vector<hipEvent_t> g_prof_events;   // pairs: [2i] before, [2i+1] after
+static size_t g_prof_used = 0;
+
+bool rb_prof_begin(const char* kernel_expr, hipStream_t stream) {
+  if (!strstr(kernel_expr, g_prof_pat)) return false;
+  if (g_prof_used + 2 > g_prof_events.size()) {
+    if (g_prof_events.size() >= 65536) return false;
+    for (int i = 0; i < 256; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return false;
+      g_prof_events.push_back(e);
+    }
+  }
+  return hipEventRecord(g_prof_events[g_prof_used++], stream) == hipSuccess;
+}
+void rb_prof_end(hipStream_t stream) { (void)hipEventRecord(g_prof_events[g_prof_used++], stream); }
+#endif
+
 extern "C" {
+int rb_profile_select(const char* kernel_substr) {
+#if !defined(RB_HOST_INTERP)
+  g_prof_used = 0;
+  if (!kernel_substr || !kernel_substr[0]) { g_rb_prof_on = 0; g_prof_pat[0] = 0; return RB_OK; }
+  snprintf(g_prof_pat, sizeof(g_prof_pat), "%s", kernel_substr);
+  g_rb_prof_on = 1;
+#else
+  (void)kernel_substr;
+#endif
+  return RB_OK;
+}
+
+int rb_profile_read(double* total_ms, int64_t* launches) {
+  double total = 0.0;
+  int64_t n = 0;
+#if !defined(RB_HOST_INTERP)
+  for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+    RB_HIP_TRY(hipEventSynchronize(g_prof_events[i + 1]));
+    float ms = 0.0f;
+    RB_HIP_TRY(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
+    total += ms;
+    ++n;
+  }
+  g_prof_used = 0;
+#endif
+  if (total_ms) *total_ms = total;
+  if (launches) *launches = n;
+  return RB_OK;
+}
+
 const char* rb_last_error(void) { return g_rb_error; }
 int rb_abi_version(void) { return 1; }
+
+int rb_copy_to_host(void* dst_host, const void* src_dev, size_t nbytes, rb_stream_t stream) {
+  RB_REQUIRE(dst_host && src_dev, "rb_copy_to_host: NULL argument");
+  RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  RB_HIP_TRY(hipMemcpy(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost));
+  return RB_OK;
+}
+
+int rb_copy_to_device(void* dst_dev, const void* src_host, size_t nbytes, rb_stream_t stream) {
+  RB_REQUIRE(dst_dev && src_host, "rb_copy_to_device: NULL argument");
+  RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  RB_HIP_TRY(hipMemcpy(dst_dev, src_host, nbytes, hipMemcpyHostToDevice));
+  return RB_OK;
+}
 }

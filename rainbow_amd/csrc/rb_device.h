@@ -15,8 +15,16 @@
 #include <hip/hip_runtime.h>
 typedef float rb_f32x16 __attribute__((ext_vector_type(16)));
 typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
-#define RB_LAUNCH(kern, grid, block, stream, ...) \
-  hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+// launch + optional event bracket (rb_profile_select, common.hip)
+bool rb_prof_begin(const char* kernel_expr, hipStream_t stream);
+void rb_prof_end(hipStream_t stream);
+extern int g_rb_prof_on;
+#define RB_LAUNCH(kern, grid, block, stream, ...)                                               \
+  do {                                                                                          \
+    const bool rb_pf_ = g_rb_prof_on && rb_prof_begin(#kern, (hipStream_t)(stream));            \
+    hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__);           \
+    if (rb_pf_) rb_prof_end((hipStream_t)(stream));                                             \
+  } while (0)
 #endif
 
 #include <stdint.h>

@@ -1,0 +1,248 @@
+"""Drop-in `ReplayMemory` for the reference's main.py / test.py (replaces /root/reference/memory.py).
+
+Same constructor, attributes and methods as the reference class (memory.py:91-180), but the ring
+buffer, the float32 sum-tree, the stratified sampler, the frame-stack gather and the priority
+update all live in HBM behind librainbow_hip.so (C ABI: include/rainbow_hip.h).  Python only
+forwards pointers; there is no CPU path.
+
+Two ways to consume a batch:
+  * `sample(batch_size)` — the reference's 7-tuple (memory.py:148-155), states as float32 /255.
+    Needs one D2H copy of the tree indices because the reference returns them as a numpy array.
+  * `sample_device(batch_size)` — device-resident outputs (uint8 frame stacks, no sync); this is
+    what rainbow_amd.agent.Agent.learn uses.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class _TransitionsView:
+    """Read-only stand-in for the reference's `mem.transitions` SegmentTree attribute."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def _hdr(self):
+        return self._o._header()
+
+    @property
+    def index(self):
+        return int(self._hdr().index)
+
+    @property
+    def full(self):
+        return bool(self._hdr().full)
+
+    @property
+    def max(self):
+        return float(self._hdr().max)
+
+    def total(self):
+        return float(self._hdr().total)
+
+
+class ReplayMemory:
+    MAX_ATTEMPTS = 32   # device-side whole-batch rejection attempts per sample() (memory.py:128-132)
+
+    def __init__(self, args, capacity, seed=None):
+        self.device = torch.device(args.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("rainbow_amd.ReplayMemory lives in HBM: args.device must be a cuda (ROCm) device, got %s"
+                               % self.device)
+        self._lib = L.load()
+        self.capacity = int(capacity)
+        self.history = int(args.history_length)
+        self.discount = float(args.discount)
+        self.n = int(args.multi_step)
+        self.priority_weight = float(args.priority_weight)      # beta, annealed by the caller (main.py:161)
+        self.priority_exponent = float(args.priority_exponent)
+        self.t = 0                                              # episode timestep counter (memory.py:100)
+        self._seed = int(seed if seed is not None else np.random.randint(0, 2 ** 31 - 1))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self._lib, self._lib.rb_replay_create(C.byref(self._h), self.capacity, self.history, self.n,
+                                                          self.discount, self.priority_exponent, self._seed))
+        self.transitions = _TransitionsView(self)
+        self._out = {}
+        self.current_idx = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.rb_replay_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _header(self):
+        hdr = L.ReplayHeader()
+        L.check(self._lib, self._lib.rb_replay_header(self._h, C.byref(hdr), self._stream()))
+        return hdr
+
+    def _buffers(self, batch):
+        key = int(batch)
+        if key not in self._out:
+            d, h = self.device, self.history
+            self._out[key] = dict(
+                tree_idxs=torch.empty(batch, dtype=torch.int64, device=d),
+                states=torch.empty(batch, h, 84, 84, dtype=torch.uint8, device=d),
+                next_states=torch.empty(batch, h, 84, 84, dtype=torch.uint8, device=d),
+                actions=torch.empty(batch, dtype=torch.int64, device=d),
+                returns=torch.empty(batch, dtype=torch.float32, device=d),
+                nonterminals=torch.empty(batch, dtype=torch.float32, device=d),
+                weights=torch.empty(batch, dtype=torch.float32, device=d))
+        return self._out[key]
+
+    # ------------------------------------------------------------------ reference API
+    def append(self, state, action, reward, terminal):
+        """memory.py:105-108.  `state` float32 [h,84,84] in [0,1] on the device (env.py:52,77)."""
+        st = state.to(device=self.device, dtype=torch.float32).contiguous()
+        L.check(self._lib, self._lib.rb_replay_append(self._h, st.data_ptr(), int(self.t), int(action), float(reward),
+                                                      0 if terminal else 1, self._stream()))
+        self.t = 0 if terminal else self.t + 1
+
+    def append_batch(self, frames_u8, actions, rewards, terminals):
+        """n sequential appends of already-quantised last frames (uint8 [n,84,84], device)."""
+        n = int(frames_u8.shape[0])
+        terminals = np.asarray(terminals, dtype=bool)
+        ts = np.empty(n, dtype=np.int32)
+        t = self.t
+        for i in range(n):
+            ts[i] = t
+            t = 0 if terminals[i] else t + 1
+        self.t = t
+        d = self.device
+        fr = frames_u8.to(device=d, dtype=torch.uint8).contiguous()
+        ts_d = torch.from_numpy(ts).to(d)
+        ac_d = torch.as_tensor(np.asarray(actions, dtype=np.int32)).to(d)
+        rw_d = torch.as_tensor(np.asarray(rewards, dtype=np.float32)).to(d)
+        nt_d = torch.from_numpy((~terminals).astype(np.uint8)).to(d)
+        L.check(self._lib, self._lib.rb_replay_append_batch(self._h, fr.data_ptr(), ts_d.data_ptr(), ac_d.data_ptr(),
+                                                            rw_d.data_ptr(), nt_d.data_ptr(), n, self._stream()))
+        torch.cuda.current_stream(d).synchronize()   # the temporaries above must outlive the kernels
+
+    def sample_device(self, batch_size, unit_uniforms=None):
+        """Device-resident batch: dict(tree_idxs i64[B], states u8[B,h,84,84], next_states u8, actions i64[B],
+        returns f32[B], nonterminals f32[B], weights f32[B]).  Asynchronous.  unit_uniforms (float64 device
+        tensor [attempts,B]) injects the sampler's random numbers for parity tests."""
+        o = self._buffers(batch_size)
+        uu_ptr, attempts = None, self.MAX_ATTEMPTS
+        if unit_uniforms is not None:
+            self._uu = unit_uniforms.to(device=self.device, dtype=torch.float64).contiguous()
+            uu_ptr, attempts = self._uu.data_ptr(), int(self._uu.shape[0])
+        L.check(self._lib, self._lib.rb_replay_sample(
+            self._h, int(batch_size), float(self.priority_weight), uu_ptr, attempts, o["tree_idxs"].data_ptr(),
+            o["states"].data_ptr(), o["next_states"].data_ptr(), o["actions"].data_ptr(), o["returns"].data_ptr(),
+            o["nonterminals"].data_ptr(), o["weights"].data_ptr(), self._stream()))
+        return o
+
+    def sample(self, batch_size):
+        """memory.py:148-155 7-tuple: (tree_idxs ndarray, states f32, actions i64, returns f32, next_states f32,
+        nonterminals f32[B,1], weights f32)."""
+        o = self.sample_device(batch_size)
+        states = torch.empty(o["states"].shape, dtype=torch.float32, device=self.device)
+        next_states = torch.empty_like(states)
+        n = states.numel()
+        L.check(self._lib, self._lib.rb_u8_to_unit_f32(o["states"].data_ptr(), states.data_ptr(), n, self._stream()))
+        L.check(self._lib, self._lib.rb_u8_to_unit_f32(o["next_states"].data_ptr(), next_states.data_ptr(), n, self._stream()))
+        tree_idxs = o["tree_idxs"].cpu().numpy()      # the reference hands indices back as numpy (memory.py:155)
+        hdr = self._header()
+        if hdr.last_status != 0:
+            raise RuntimeError("ReplayMemory.sample: no valid batch in %d attempts (buffer too small for batch?)"
+                               % hdr.last_attempts)
+        return (tree_idxs, states, o["actions"].clone(), o["returns"].clone(), next_states,
+                o["nonterminals"].clone().unsqueeze(1), o["weights"].clone())
+
+    def update_priorities(self, idxs, priorities):
+        """memory.py:157-159.  Accepts numpy arrays (reference call site agent.py:100) or device tensors."""
+        d = self.device
+        if not torch.is_tensor(idxs):
+            idxs = torch.as_tensor(np.asarray(idxs, dtype=np.int64))
+        if not torch.is_tensor(priorities):
+            priorities = torch.as_tensor(np.asarray(priorities, dtype=np.float32))
+        self._upd = (idxs.to(device=d, dtype=torch.int64).contiguous(),
+                     priorities.to(device=d, dtype=torch.float32).contiguous())
+        L.check(self._lib, self._lib.rb_replay_update_priorities(self._h, self._upd[0].data_ptr(),
+                                                                 self._upd[1].data_ptr(), int(self._upd[0].numel()),
+                                                                 self._stream()))
+
+    # validation iterator (memory.py:162-180)
+    def __iter__(self):
+        self.current_idx = 0
+        return self
+
+    def __next__(self):
+        if self.current_idx == self.capacity:
+            raise StopIteration
+        out = torch.empty(self.history, 84, 84, dtype=torch.float32, device=self.device)
+        L.check(self._lib, self._lib.rb_replay_state_at(self._h, int(self.current_idx), out.data_ptr(), self._stream()))
+        self.current_idx += 1
+        return out
+
+    next = __next__
+
+    # ------------------------------------------------------------------ pickling (main.py:94-100,118)
+    def _grab(self, field, start=0, count=None):
+        """Copies rows [start, start+count) of one device column to a numpy array (tests / partial dumps)."""
+        b = L.ReplayBuffers()
+        L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(b)))
+        spec = {"tree": (b.sum_tree_dev, 4, np.float32, b.tree_len), "frames": (b.frames_dev, 7056, np.uint8, self.capacity),
+                "timestep": (b.timestep_dev, 4, np.int32, self.capacity), "action": (b.action_dev, 4, np.int32, self.capacity),
+                "reward": (b.reward_dev, 4, np.float32, self.capacity), "nonterminal": (b.nonterminal_dev, 1, np.uint8, self.capacity)}
+        ptr, row, dtype, rows = spec[field]
+        count = rows - start if count is None else count
+        host = np.empty(count * row, dtype=np.uint8)
+        L.check(self._lib, self._lib.rb_copy_to_host(host.ctypes.data, ptr + start * row, host.nbytes, self._stream()))
+        out = host.view(dtype)
+        return out.reshape(count, 84, 84) if field == "frames" else out
+
+    def _dump(self):
+        b = L.ReplayBuffers()
+        L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(b)))
+        hdr = self._header()
+        cap = self.capacity
+
+        def grab(ptr, nbytes):
+            host = np.empty(nbytes, dtype=np.uint8)
+            L.check(self._lib, self._lib.rb_copy_to_host(host.ctypes.data, ptr, nbytes, self._stream()))
+            return host
+
+        return dict(tree=grab(b.sum_tree_dev, b.tree_len * 4).view(np.float32),
+                    frames=grab(b.frames_dev, cap * 7056), timestep=grab(b.timestep_dev, cap * 4).view(np.int32),
+                    action=grab(b.action_dev, cap * 4).view(np.int32), reward=grab(b.reward_dev, cap * 4).view(np.float32),
+                    nonterminal=grab(b.nonterminal_dev, cap),
+                    header=bytes(hdr))
+
+    def __getstate__(self):
+        st = {k: v for k, v in self.__dict__.items() if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd")}
+        st["device"] = str(self.device)
+        st["_dump"] = self._dump()
+        return st
+
+    def __setstate__(self, st):
+        dump = st.pop("_dump")
+        self.__dict__.update(st)
+        self.device = torch.device(self.device)
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self._lib, self._lib.rb_replay_create(C.byref(self._h), self.capacity, self.history, self.n,
+                                                          self.discount, self.priority_exponent, self._seed))
+        b = L.ReplayBuffers()
+        L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(b)))
+        for key, ptr in (("tree", b.sum_tree_dev), ("frames", b.frames_dev), ("timestep", b.timestep_dev),
+                         ("action", b.action_dev), ("reward", b.reward_dev), ("nonterminal", b.nonterminal_dev)):
+            a = np.ascontiguousarray(dump[key])
+            L.check(self._lib, self._lib.rb_copy_to_device(ptr, a.ctypes.data, a.nbytes, self._stream()))
+        hdr = np.frombuffer(dump["header"], dtype=np.uint8).copy()
+        L.check(self._lib, self._lib.rb_copy_to_device(b.header_dev, hdr.ctypes.data, hdr.nbytes, self._stream()))
+        self.transitions = _TransitionsView(self)
+        self._out = {}
+        self._header()   # resynchronise the library's host mirror of index/full

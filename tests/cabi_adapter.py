@@ -59,16 +59,11 @@ class TorchMem:
         return buf.data_ptr() if buf is not None else None
 
     def view(self, ptr, shape, dtype):
-        # copy raw library-owned device memory into a torch tensor via hipMemcpy (D2D)
-        out = self.empty(shape, dtype)
-        nbytes = out.numel() * out.element_size()
-        self.sync()
-        rt = C.CDLL("libamdhip64.so.7") if not hasattr(self, "_rt") else self._rt
-        self._rt = rt
-        rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        rc = rt.hipMemcpy(out.data_ptr(), ptr, nbytes, 3)
-        assert rc == 0, rc
-        return out.cpu().numpy()
+        # copy raw library-owned device memory to the host through the library's own copy helper
+        host = np.empty(shape, dtype=dtype)
+        lib = L.load()
+        L.check(lib, lib.rb_copy_to_host(host.ctypes.data, ptr, host.nbytes, self.stream))
+        return host
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -263,6 +258,8 @@ class CAbiLearnAdapter:
         L.check(self.lib, self.lib.rb_learner_reset_noise(self.h, 0, m.ptr(r), m.stream))
         m.sync()
 
+    grad_hook = None   # e.g. rainbow_amd.dist.average_gradients between backward and clip
+
     def learn_step(self, batch, target_raw):
         m = self.mem
         B = self.c["batch"]
@@ -278,6 +275,9 @@ class CAbiLearnAdapter:
                                                     m.ptr(bufs["actions"]), m.ptr(bufs["returns"]),
                                                     m.ptr(bufs["nonterminals"]), m.ptr(bufs["weights"]), m.ptr(loss),
                                                     m.stream))
+        if self.grad_hook is not None:
+            m.sync()
+            self.grad_hook(self._as_torch(self.grads))
         L.check(self.lib, self.lib.rb_learner_clip_grad(self.h, self.hy["norm_clip"], m.ptr(norm), m.stream))
         m.sync()
         grads = self._unflat(m.download(self.grads))
