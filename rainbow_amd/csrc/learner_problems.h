@@ -13,8 +13,16 @@
 #pragma once
 #include "gemm_core.h"
 
-// exact u8 -> x/255 (memory.py:137-138 `.div_(255)`): correctly rounded float32 division
-__device__ __forceinline__ float rb_unit(uint8_t u) { return __fdiv_rn((float)u, 255.0f); }
+// exact u8 -> x/255 (memory.py:137-138 `.div_(255)`) without a divide: one multiply by fl(1/255) plus one
+// Newton correction is the correctly rounded quotient for all 256 byte values (checked exhaustively in
+// tests/test_learner_emu.py::test_unit_conversion_is_exact).
+__device__ __forceinline__ float rb_unit(uint8_t u) {
+  const float x = (float)u;
+  const float inv = 1.0f / 255.0f;
+  const float q = x * inv;
+  const float r = fmaf(-255.0f, q, x);
+  return fmaf(r, inv, q);
+}
 
 template <int KS_, int S_, int IH_, int OH_>
 struct ConvGeom {
