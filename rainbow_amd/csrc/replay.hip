@@ -215,6 +215,75 @@ __global__ __launch_bounds__(256) void k_find(ReplayView v, const double* values
 }
 
 // ---------------------------------------------------------------------- sample --
+// Latency-optimised search used by the sampler: identical arithmetic to rb_tree_descend, but
+//  (a) the top of the tree (<= 4095 nodes = 16 KB, levels 0..11) is staged once in LDS, and
+//  (b) below that, three levels are fetched per memory round trip: the descendants of node u at
+//      depth j are the 2^j consecutive entries starting at (u+1)*2^j - 1, so 2+4+8 independent
+//      loads replace three dependent ones.  For the 1M-leaf tree: 11 LDS steps + 3 round trips
+//      instead of 20 dependent HBM/L2 loads.
+// Every load index is clamped to tree_len-1, which IS memory.py:70-71 on the leaf level and a
+// no-op above it.
+#define RB_TOP_NODES 4095
+
+__device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const float* s_top, int n_cached,
+                                                        int32_t levels, int64_t tree_len, double value) {
+  int64_t node = 0;
+  int32_t lv = 0;
+  const int64_t last = tree_len - 1;
+  for (; lv < levels; ++lv) {                       // LDS phase
+    int64_t left = 2 * node + 1, right = left + 1;
+    if (left > last) left = last;
+    if (right > last) right = last;
+    if (right >= n_cached) break;
+    const double lv_d = (double)s_top[left];
+    const bool go_right = value > lv_d;
+    node = go_right ? right : left;
+    if (go_right) value = __dsub_rn(value, lv_d);
+  }
+  while (lv < levels) {                             // global phase, up to 3 levels per round trip
+    const int32_t d = levels - lv < 3 ? levels - lv : 3;
+    float c1[2], c2[4], c3[8];
+    const int64_t b1 = 2 * node + 1, b2 = 4 * node + 3, b3 = 8 * node + 7;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { const int64_t q = b1 + t; c1[t] = tree[q > last ? last : q]; }
+    if (d >= 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const int64_t q = b2 + t; c2[t] = tree[q > last ? last : q]; }
+    }
+    if (d >= 3) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const int64_t q = b3 + t; c3[t] = tree[q > last ? last : q]; }
+    }
+    // depth 1
+    {
+      const double l = (double)c1[0];
+      const bool r = value > l;
+      if (r) value = __dsub_rn(value, l);
+      int64_t nx = b1 + (r ? 1 : 0);
+      node = nx > last ? last : nx;
+      int sel = r ? 1 : 0;
+      if (d >= 2) {
+        const double l2 = (double)(sel ? c2[2] : c2[0]);
+        const bool r2 = value > l2;
+        if (r2) value = __dsub_rn(value, l2);
+        nx = 2 * node + 1 + (r2 ? 1 : 0);
+        node = nx > last ? last : nx;
+        sel = sel * 2 + (r2 ? 1 : 0);
+        if (d >= 3) {
+          const float l3f = sel == 0 ? c3[0] : (sel == 1 ? c3[2] : (sel == 2 ? c3[4] : c3[6]));
+          const double l3 = (double)l3f;
+          const bool r3 = value > l3;
+          if (r3) value = __dsub_rn(value, l3);
+          nx = 2 * node + 1 + (r3 ? 1 : 0);
+          node = nx > last ? last : nx;
+        }
+      }
+    }
+    lv += d;
+  }
+  return node;
+}
+
 // ReplayMemory.sample on device (memory.py:124-155).  ONE workgroup, thread i = sample i
 // (batch <= 1024).  The rejection loop (memory.py:128-132) runs inside the kernel so the
 // steady-state learn step has no host round trip.
@@ -225,15 +294,19 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
                                                   float* weights_out) {
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
+  __shared__ float s_top[RB_TOP_NODES];
   const int i = (int)threadIdx.x;
   const bool active = i < batch;
   const int64_t C = v.capacity;
   const int h = v.history, n = v.n;
 
-  const float p_total = v.tree[0];                              // memory.py:149
+  const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
+  for (int t = i; t < n_cached; t += (int)blockDim.x) s_top[t] = v.tree[t];
   const int64_t w_index = v.hdr->index;
   const int32_t full = v.hdr->full;
   const uint64_t rng_base = v.hdr->rng_counter;
+  __syncthreads();
+  const float p_total = s_top[0];                               // memory.py:149
   // segment_length = p_total / batch_size: float32 / python int -> float32 (NEP 50)
   const float seg_f = __fdiv_rn(p_total, (float)batch);         // memory.py:125
   const double seg = (double)seg_f;
@@ -255,7 +328,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     const double sample = __dadd_rn(__dadd_rn(0.0, __dmul_rn(seg, u)), start);
     int valid = 1;
     if (active) {
-      leaf = rb_tree_descend(v.tree, v.levels, v.tree_start, v.tree_len, sample);   // memory.py:130
+      leaf = rb_tree_descend_fast(v.tree, s_top, n_cached, v.levels, v.tree_len, sample);   // memory.py:130
       prob = v.tree[leaf];
       const int64_t idx = leaf - v.tree_start;
       // memory.py:131
@@ -277,7 +350,6 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     unsigned long long first_bits = 0ull;  // h+n <= 64
     for (int t = 0; t < win_len; ++t) {
       const int64_t ring = rb_floor_mod(idx + (int64_t)(t - (h - 1)), C);
-      my_win[t] = (int32_t)ring;
       if (v.timestep[ring] == 0) first_bits |= 1ull << t;
     }
     unsigned long long blank = 0ull;
@@ -289,20 +361,24 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
       const bool b = ((blank >> (t - 1)) & 1ull) || ((first_bits >> t) & 1ull);
       if (b) blank |= 1ull << t;
     }
-    for (int t = 0; t < win_len; ++t)
-      if ((blank >> t) & 1ull) my_win[t] = -1;
+    for (int t = 0; t < win_len; ++t) {
+      const int64_t ring = rb_floor_mod(idx + (int64_t)(t - (h - 1)), C);
+      my_win[t] = ((blank >> t) & 1ull) ? -1 : (int32_t)ring;
+    }
     // slot h-1 is never blanked
     const int64_t ring_now = rb_floor_mod(idx, C);
     actions_out[i] = (int64_t)v.action[ring_now];                       // memory.py:140
     float R = 0.0f;                                                     // memory.py:142-143
     for (int k = 0; k < n; ++k) {
       const int t = h - 1 + k;
-      const float rew = ((blank >> t) & 1ull) ? 0.0f : v.reward[my_win[t] < 0 ? 0 : my_win[t]];
+      const int64_t ring = rb_floor_mod(idx + (int64_t)k, C);
+      const float rew = ((blank >> t) & 1ull) ? 0.0f : v.reward[ring];
       R = __fadd_rn(R, __fmul_rn(rew, scaling[k]));
     }
     returns_out[i] = R;
     const int t_last = h + n - 1;                                       // memory.py:145
-    nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (v.nonterminal[my_win[t_last]] ? 1.0f : 0.0f);
+    const int64_t ring_last = rb_floor_mod(idx + (int64_t)n, C);
+    nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (v.nonterminal[ring_last] ? 1.0f : 0.0f);
     tree_idx_out[i] = leaf;
     // probs / p_total ; capacity * probs ; ** -beta   (memory.py:151-153), all float32
     const float pn = __fdiv_rn(prob, p_total);
@@ -348,41 +424,75 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 // SegmentTree.update (memory.py:44-48) for n <= 1024 leaves in ONE workgroup.
 // Duplicate indices: numpy fancy assignment is last-write-wins (memory.py:45).
 // apply_pow: ReplayMemory.update_priorities' p = loss^w first (memory.py:158).
+//
+// Latency structure: the L ancestor sums are NOT walked through memory level by level (that is
+// L dependent round trips).  Each thread prefetches the sibling of its node on every level in one
+// batch of independent loads, then the walk to the root happens in registers; where two paths of
+// this batch meet, the sibling's fresh value is taken from LDS (published per level) instead of
+// the stale prefetched one.  Every parent is still fl32(left + right) of its current children
+// (memory.py:25), so the resulting floats are exactly the reference's.
+#define RB_MAX_LEVELS 31
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
                                                   int32_t apply_pow, double omega) {
-  __shared__ int64_t s_idx[1024];
+  __shared__ int s_node[2][1024];
+  __shared__ float s_val[2][1024];
   __shared__ float s_red[16];
   const int i = (int)threadIdx.x;
   const bool active = i < n;
-  int64_t node = active ? tree_idx[i] : -1;
+  int node = active ? (int)tree_idx[i] : -1;
+  // sibling prefetch for every level (stale where another updated path passes; fixed up from LDS)
+  float sib[RB_MAX_LEVELS];
+  {
+    int q = node;
+#pragma unroll
+    for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
+      if (active && lv < v.levels) {
+        const int sb = (q & 1) ? q + 1 : q - 1;
+        sib[lv] = v.tree[sb];
+        q = (q - 1) >> 1;
+      } else {
+        sib[lv] = 0.0f;
+      }
+    }
+  }
   float val = 0.0f;
   if (active) {
     val = values[i];
     if (apply_pow) val = (float)pow((double)val, omega);
   }
-  s_idx[i] = node;
+  const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47
+  s_node[0][i] = node;
+  s_val[0][i] = val;
   __syncthreads();
   if (active) {
-    bool last = true;
-    for (int j = i + 1; j < n; ++j)
-      if (s_idx[j] == node) { last = false; break; }
-    if (last) v.tree[node] = val;
+    for (int j = n - 1; j > i; --j)            // last occurrence wins (memory.py:45)
+      if (s_node[0][j] == node) { val = s_val[0][j]; break; }
+    v.tree[node] = val;
   }
-  const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47
-  __threadfence_block();
   __syncthreads();
-  // memory.py:28-33: parents of all indices, level by level, until the root is written
-  for (int32_t lv = 0; lv < v.levels; ++lv) {
-    if (active) {
-      node = (node - 1) / 2;
-      v.tree[node] = __fadd_rn(v.tree[2 * node + 1], v.tree[2 * node + 2]);
+#pragma unroll
+  for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
+    if (lv < v.levels) {                        // block-uniform
+      const int c = lv & 1;
+      s_node[c][i] = node;
+      s_val[c][i] = val;
+      __syncthreads();
+      if (active) {
+        const int sb = (node & 1) ? node + 1 : node - 1;
+        float sv = sib[lv];
+        for (int j = 0; j < n; ++j)
+          if (s_node[c][j] == sb) { sv = s_val[c][j]; break; }
+        const float left = (node & 1) ? val : sv;     // odd index = left child (2p+1)
+        const float right = (node & 1) ? sv : val;
+        val = __fadd_rn(left, right);                 // memory.py:25
+        node = (node - 1) >> 1;
+        v.tree[node] = val;
+      }
     }
-    __threadfence_block();
-    __syncthreads();
   }
   if (threadIdx.x == 0) {
     v.hdr->max = fmaxf(vmax, v.hdr->max);  // memory.py:48
-    v.hdr->total = v.tree[0];
+    v.hdr->total = val;                    // thread 0 ended at the root
   }
 }
 

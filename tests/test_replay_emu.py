@@ -22,3 +22,54 @@ def test_replay_kernels_match_reference_golden(emu, name):
     trace = scenarios.replay_scenario(ad, name)
     assert_trace_matches(trace, load_golden("replay_%s.npz" % name), label="emu/" + name)
     ad.close()
+
+
+@pytest.mark.parametrize("capacity", [6000, 20000])
+def test_sampler_deep_tree_matches_oracle(emu, capacity):
+    """Trees deeper than the LDS-cached top (4095 nodes): exercises the 3-levels-per-round-trip search and
+    the bulk append / ancestor rebuild against the oracle (indices bit-exact)."""
+    from oracle.replay_oracle import ReplayOracle
+    rs = np.random.RandomState(capacity)
+    ad = CAbiReplayAdapter(emu, NumpyMem(), capacity, 4, 3, 0.99, 0.5)
+    ora = ReplayOracle(capacity)
+    n = capacity + capacity // 3
+    term = rs.random_sample(n) < 0.01
+    ts = np.zeros(n, dtype=np.int32)
+    t = 0
+    for i in range(n):
+        ts[i] = t
+        t = 0 if term[i] else t + 1
+    actions = rs.randint(0, 6, n).astype(np.int32)
+    rewards = rs.choice([-1.0, 0.0, 1.0], size=n).astype(np.float32)
+    frame_pool = rs.randint(0, 256, size=(64, 84, 84)).astype(np.uint8)
+    for lo in range(0, n, 4000):
+        hi = min(n, lo + 4000)
+        frames = frame_pool[(np.arange(lo, hi) * 7) % 64]
+        ad.append_batch(frames, ts[lo:hi], actions[lo:hi], rewards[lo:hi], (~term[lo:hi]).astype(np.uint8))
+        ora.transitions.bulk_append(ts[lo:hi], frames, actions[lo:hi], rewards[lo:hi], ~term[lo:hi])
+    ora.t = t
+    tree_start = ora.transitions.tree_start
+    for r in range(6):
+        idx = rs.randint(0, capacity, 1024) + tree_start
+        vals = (rs.random_sample(1024) * 4 + 1e-3).astype(np.float32)
+        ad.update_leaves(idx, vals)
+        ora.transitions.set_leaves(idx, vals)
+    assert np.array_equal(ad.tree(), ora.transitions.tree)
+    hdr = ad.raw_header()
+    assert hdr.index == ora.transitions.index and bool(hdr.full) == ora.transitions.full
+    assert hdr.max == ora.transitions.max and hdr.total == ora.transitions.total()
+    for B in (32, 256):
+        uu = rs.random_sample((16, B))
+        got = ad.sample(B, uu, 0.6)
+        ora.priority_weight = 0.6
+        want = ora.sample_with_uniforms(B, uu)
+        assert np.array_equal(got["tree_idxs"], want["tree_idxs"])
+        assert np.array_equal(got["states"], want["states"]) and np.array_equal(got["next_states"], want["next_states"])
+        assert np.array_equal(got["actions"], want["actions"])
+        np.testing.assert_allclose(got["weights"], want["weights"], rtol=4 * 2.0 ** -23)
+        assert got["attempts"] == want["attempts"]
+    vals = rs.random_sample(512) * float(ora.transitions.total())
+    p, di, ti = ad.find(vals)
+    wp, wdi, wti = ora.transitions.find(vals)
+    assert np.array_equal(ti, wti) and np.array_equal(p, wp)
+    ad.close()
