@@ -1,0 +1,284 @@
+// conv_lds.h — convolution kernels with LDS-resident operands (model.py:56-58,61-62 and their
+// adjoints).
+//
+// At batch 32 the Rainbow conv stack is tiny per image (28 KB of u8 input, <= 51 KB activations,
+// <= 147 KB of weights per layer) and the generic implicit GEMM of gemm_core.h spends its time on
+// per-element im2col address arithmetic and dependent global loads, not on MFMAs.  Here a
+// workgroup stages what it needs ONCE with wide coalesced loads —
+//     the input patch of its output positions (u8 frames decoded to exact x/255 on the way in),
+//     a 32-channel slab of the weights, transposed to [k][32] so MFMA operand reads are
+//     bank-conflict free,
+//     a k -> patch-offset table (no div/mod in the inner loop),
+// — and then runs a pure LDS -> v_mfma_f32_32x32x2_f32 loop.  The four waves split K; their
+// accumulators are reduced through LDS in a fixed order (deterministic) and the epilogue (bias,
+// ReLU / ReLU mask) stores rows that are contiguous in the NCHW activation.
+#pragma once
+#include "learner_problems.h"
+
+struct ConvLdsFwdArgs {
+  int cin, cout;
+  int n_on;                  // images [0,n_on) use net 0, the rest net 1
+  const float* w[2];         // [cout][cin*KK]
+  const float* bias[2];
+  ImgSrc src;                // FIRST layer input
+  const float* in_f;         // later layers: [img][cin][IP]
+  float* out;                // [img][cout][P]
+};
+
+// ---- shared staging helpers ------------------------------------------------------------------
+// weights slab [32 rows starting at row0][K] (row-major, K % 4 == 0) -> s_w[k][33], rows >= rows_valid zeroed,
+// rows k in [K, KPAD) zeroed
+__device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, int row0, int rows_valid, int K, int KPAD) {
+  const int t = (int)threadIdx.x, T = (int)blockDim.x;
+  const int lane = t & 63, wave = t >> 6, nw = T >> 6;
+  if (K & 3) {                                       // odd history lengths: scalar staging
+    for (int m = wave; m < 32; m += nw)
+      for (int k = lane; k < K; k += 64) s_w[k * 33 + m] = m < rows_valid ? w[(int64_t)(row0 + m) * K + k] : 0.0f;
+  } else {
+    const int kq = K >> 2;
+    for (int m = wave; m < 32; m += nw) {
+      const float* src = w + (int64_t)(row0 + m) * K;
+      for (int q = lane; q < kq; q += 64) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (m < rows_valid) v = rb_ld4(src + 4 * q);
+        s_w[(4 * q + 0) * 33 + m] = v.x;
+        s_w[(4 * q + 1) * 33 + m] = v.y;
+        s_w[(4 * q + 2) * 33 + m] = v.z;
+        s_w[(4 * q + 3) * 33 + m] = v.w;
+      }
+    }
+  }
+  for (int e = t; e < (KPAD - K) * 32; e += T) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
+}
+
+// ================================================================================ forward ==
+// grid = (position chunks of 32*NT per image, cout / 32, images); block = 256.
+// PR = input rows staged per channel (covers the output rows of one position chunk).
+#define RB_CONV_WAVES 8
+#define RB_CONV_THREADS (64 * RB_CONV_WAVES)
+template <class G, int NT, int PR, int KMAX, bool FIRST>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
+  constexpr int KPAD = (KMAX + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES) * (2 * RB_CONV_WAVES);
+  constexpr int PLANE = PR * G::IH;                 // floats per channel in the patch
+  constexpr int CMAX = KMAX / G::KK;
+  constexpr int RED = RB_CONV_WAVES * NT * 16 * 64; // reduction scratch (floats), overlays s_w + s_patch
+  constexpr int OPS = KPAD * 33 + CMAX * PLANE;     // weights then patch, contiguous
+  constexpr int WSZ = OPS > RED ? OPS : RED;
+  __shared__ float s_all[WSZ];
+  __shared__ int s_koff[KPAD];
+  float* s_w = s_all;
+  float* s_patch = s_all + KPAD * 33;
+
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int img = (int)blockIdx.z;
+  const int net = img < a.n_on ? 0 : 1;
+  const int cout0 = (int)blockIdx.y * 32;
+  const int p0 = (int)blockIdx.x * (32 * NT);
+  const int cin = a.cin;
+  const int K = cin * G::KK;
+  const int oy0 = p0 / G::OH;
+  const int iy0 = oy0 * G::S;
+  int rows = G::IH - iy0;
+  if (rows > PR) rows = PR;
+
+  // ---- stage: weights (transposed), k -> patch offset table, input patch
+  rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
+  for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
+    const int kc = k < K ? k : K - 1;
+    const int c = kc / G::KK, r = kc % G::KK;
+    s_koff[k] = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
+  }
+  if (FIRST && !a.src.f32) {
+    const uint8_t* base = img < a.src.B ? a.src.u8_states + (int64_t)img * cin * G::IP
+                                        : a.src.u8_next + (int64_t)((img - a.src.B) % a.src.B) * cin * G::IP;
+    const int per_c = rows * G::IH;                 // bytes per channel, 16-byte multiple for the frame geometries
+    const int v16 = per_c >> 4;
+    for (int e = t; e < cin * v16; e += RB_CONV_THREADS) {
+      const int c = e / v16, q = e - c * v16;
+      const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)c * G::IP + iy0 * G::IH + q * 16);
+      float* d = s_patch + c * PLANE + q * 16;
+      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+    }
+    for (int e = t; e < cin * (per_c & 15); e += RB_CONV_THREADS) {   // (no tail for 84-wide frames; kept for generality)
+      const int c = e / (per_c & 15), q = (v16 << 4) + e % (per_c & 15);
+      s_patch[c * PLANE + q] = rb_unit(base[(int64_t)c * G::IP + iy0 * G::IH + q]);
+    }
+  } else {
+    const float* base = FIRST ? a.src.f32 + (int64_t)img * cin * G::IP : a.in_f + (int64_t)img * cin * G::IP;
+    const int per_c = rows * G::IH;
+    if ((per_c & 3) == 0 && ((iy0 * G::IH) & 3) == 0 && (G::IP & 3) == 0) {
+      const int v4 = per_c >> 2;
+      for (int e = t; e < cin * v4; e += RB_CONV_THREADS) {
+        const int c = e / v4, q = e - c * v4;
+        const float4 v = rb_ld4(base + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+        float* d = s_patch + c * PLANE + q * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    } else {
+      for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
+        const int c = e / per_c, q = e - c * per_c;
+        s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW)
+  const int KW = ((K + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES)) * 2;
+  const int kb = wave * KW;
+  int noff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int p = p0 + nt * 32 + (lane & 31);
+    if (p > G::P - 1) p = G::P - 1;                  // clamped lanes are never stored
+    noff[nt] = (p / G::OH - oy0) * G::S * G::IH + (p % G::OH) * G::S;
+  }
+  rb_f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+  const int kh = lane >> 5, ml = lane & 31;
+#pragma unroll 4
+  for (int kk = 0; kk < KW; kk += 2) {                // LDS reads of the unrolled steps are issued ahead of the MFMAs
+    const int k = kb + kk + kh;                       // < KPAD
+    const float av = s_w[k * 33 + ml];
+    const int ko = s_koff[k];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + ko], acc[nt]);
+  }
+  __syncthreads();                                    // everyone is done reading the operands: reuse them for the reduction
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_all[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
+  __syncthreads();
+  for (int idx = t; idx < NT * 16 * 64; idx += RB_CONV_THREADS) {
+    const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
+    float v = s_all[((0 * NT + nt) * 16 + r) * 64 + l];
+#pragma unroll
+    for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
+    const int m = cout0 + rb_mfma_row(r, l);
+    const int p = p0 + nt * 32 + (l & 31);
+    if (m < a.cout && p < G::P && p < p0 + 32 * NT)
+      a.out[((int64_t)img * a.cout + m) * G::P + p] = fmaxf(v + a.bias[net][m], 0.0f);
+  }
+}
+
+// ========================================================================= data gradient ==
+// dX[img][c][y][x] = relu'(x_act) * sum_{co,ky,kx} W[co][c][ky][kx] * dY[img][co][(y-ky)/S][(x-kx)/S]
+// decomposed by phase (y % S, x % S) so only real taps are visited.  The whole dY image sits in LDS.
+// grid = (phases S*S, cin / 32, images B); block = 256.
+struct ConvLdsDxArgs {
+  int cin, cout;
+  const float* w;        // [cout][cin][KS][KS]
+  const float* dy;       // [B][cout][P]
+  const float* x_act;    // [NI][cin][IP] (rows [0,B))
+  float* dx;             // [B][cin][IP]
+};
+
+template <class G, int NT, int COUT>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a) {
+  constexpr int TMAX = (G::KS + G::S - 1) / G::S;           // taps per dimension of a phase
+  constexpr int KMAX = COUT * TMAX * TMAX;
+  constexpr int KPAD = (KMAX + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES) * (2 * RB_CONV_WAVES);
+  constexpr int RED = RB_CONV_WAVES * NT * 16 * 64;
+  constexpr int OPS = KPAD * 33 + COUT * G::P;
+  constexpr int WSZ = OPS > RED ? OPS : RED;
+  __shared__ float s_all[WSZ];
+  float* s_w = s_all;
+  float* s_dy = s_all + KPAD * 33;
+  __shared__ int s_koff[KPAD];      // co*P - ty*OH - tx
+  __shared__ int s_ktap[KPAD];      // (ty << 8) | tx
+
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int img = (int)blockIdx.z;
+  const int c0 = (int)blockIdx.y * 32;
+  const int py = (int)blockIdx.x / G::S, px = (int)blockIdx.x % G::S;
+  const int nty = (G::KS - py + G::S - 1) / G::S, ntx = (G::KS - px + G::S - 1) / G::S;
+  const int nyy = (G::IH - py + G::S - 1) / G::S, nxx = (G::IH - px + G::S - 1) / G::S;
+  const int taps = nty * ntx;
+  const int K = a.cout * taps;
+  const int npos = nyy * nxx;
+
+  // ---- stage dY image, the phase's weight slab transposed to [k'][c], tap tables
+  {
+    const float* src = a.dy + (int64_t)img * a.cout * G::P;
+    const int n = a.cout * G::P;
+    for (int e = t; e < n; e += RB_CONV_THREADS) s_dy[e] = src[e];
+  }
+  for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
+    const int kc = k < K ? k : K - 1;
+    const int co = kc / taps, r = kc - co * taps;
+    const int ty = r / ntx, tx = r - ty * ntx;
+    s_koff[k] = co * G::P - ty * G::OH - tx;
+    s_ktap[k] = (ty << 8) | tx;
+  }
+  {   // phase slab of the weights, transposed to [k' = (co,ty,tx)][c]; thread = (c, co mod 16), no divisions
+    const int m = t & 31;
+    const bool cv = c0 + m < a.cin;
+    for (int co = t >> 5; co < a.cout; co += RB_CONV_THREADS / 32) {
+      const float* src = a.w + ((int64_t)co * a.cin + c0 + (cv ? m : 0)) * G::KK;
+      for (int ty = 0; ty < nty; ++ty)
+        for (int tx = 0; tx < ntx; ++tx)
+          s_w[(co * taps + ty * ntx + tx) * 33 + m] = cv ? src[(py + ty * G::S) * G::KS + px + tx * G::S] : 0.0f;
+    }
+    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
+  }
+  __syncthreads();
+
+  const int KW = ((K + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES)) * 2;
+  const int kb = wave * KW;
+  int nyx[NT], noff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = nt * 32 + (lane & 31);
+    if (n > npos - 1) n = npos - 1;
+    const int yy = n / nxx, xx = n - yy * nxx;
+    nyx[nt] = (yy << 8) | xx;
+    noff[nt] = yy * G::OH + xx;
+  }
+  rb_f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+  const int kh = lane >> 5, ml = lane & 31;
+#pragma unroll 4
+  for (int kk = 0; kk < KW; kk += 2) {
+    const int k = kb + kk + kh;
+    const float av = s_w[k * 33 + ml];
+    const int ko = s_koff[k], tap = s_ktap[k];
+    const int ty = tap >> 8, tx = tap & 255;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = (nyx[nt] >> 8) - ty, ox = (nyx[nt] & 255) - tx;
+      const bool ok = oy >= 0 && ox >= 0 && oy < G::OH && ox < G::OH;
+      const float bv = ok ? s_dy[ko + noff[nt]] : 0.0f;
+      acc[nt] = rb_mfma32(av, bv, acc[nt]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_all[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
+  __syncthreads();
+  for (int idx = t; idx < NT * 16 * 64; idx += RB_CONV_THREADS) {
+    const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
+    float v = s_all[((0 * NT + nt) * 16 + r) * 64 + l];
+#pragma unroll
+    for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
+    const int c = c0 + rb_mfma_row(r, l);
+    const int n = nt * 32 + (l & 31);
+    if (c < a.cin && n < npos) {
+      const int yy = n / nxx, xx = n - yy * nxx;
+      const int64_t o = ((int64_t)img * a.cin + c) * G::IP + (yy * G::S + py) * G::IH + xx * G::S + px;
+      a.dx[o] = a.x_act[o] > 0.0f ? v : 0.0f;
+    }
+  }
+}

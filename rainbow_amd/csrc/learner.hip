@@ -10,8 +10,12 @@
 // All contractions run on v_mfma_f32_32x32x2_f32 through gemm_core.h (exact f32: parity with
 // the float32 reference is the contract); everything else is fused into their operand
 // gathers / epilogues (learner_problems.h).
+#include "conv_lds.h"
 #include "learner_problems.h"
+#include "noisy_linear.h"
 #include "rb_common.h"
+
+#include <stdlib.h>
 
 #include <math.h>
 #include <string.h>
@@ -130,6 +134,8 @@ struct rb_learner {
   float* zero_noise;    // [n_noise] zeros (eval mode, model.py:46)
   float* norm_part;     // [1024]
   int hs, xs, ws[3];    // split counts
+  int fast_fc;          // streamed 16x16x4 noisy-linear kernels usable (alignment preconditions hold)
+  int fast_conv;        // LDS-resident conv kernels usable (history <= 4, standard channel counts)
   float gamma_n;        // float32(discount ** n)        agent.py:79
   float delta_z;        // float32((Vmax - Vmin)/(Z-1))   agent.py:19,82
 };
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(256) void k_reduce_conv_dw(const float* part, int s
   const int64_t total = (int64_t)cout * (K + 1);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.0f;
-    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];
+#pragma unroll 8
+    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];   // independent loads, fixed add order
     const int co = (int)(i / (K + 1)), col = (int)(i % (K + 1));
     if (col < K) gw[(int64_t)co * K + col] = acc;
     else gb[co] = acc;
@@ -217,152 +224,167 @@ __device__ __forceinline__ float rb_dueling_q(const float* lg, const float* mean
   return (lg[z] + lg[Z + a * Z + z]) - mean_a[z];
 }
 
+// One WAVE per sample (4 samples per 256-thread workgroup): every reduction over the atoms is a
+// wave64 butterfly, each lane keeps "its" atoms z = lane, lane+64, ... in registers, and only the
+// projection's scatter (atom j lands in bins l_j / u_j) goes through LDS.
+#define RB_ZI (RB_MAX_ATOMS / 64)
 __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
                                                const float* returns, const float* nonterminals, const float* weights,
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
                                                int32_t* a_star_out, float* loss_out, float* dlogits) {
-  __shared__ float s_mean[RB_MAX_ATOMS];
-  __shared__ float s_p[RB_MAX_ATOMS];        // probabilities (reused)
-  __shared__ float s_logp[RB_MAX_ATOMS];
-  __shared__ float s_m[RB_MAX_ATOMS];
-  __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS];
-  __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
-  __shared__ float s_ev[RB_MAX_ACTIONS];
-  __shared__ float s_red[16];
-  __shared__ int s_astar;
-  const int b = (int)blockIdx.x;
-  const int t = (int)threadIdx.x;
+  __shared__ float s_lo[4][RB_MAX_ATOMS], s_hi[4][RB_MAX_ATOMS];
+  __shared__ int s_l[4][RB_MAX_ATOMS], s_u[4][RB_MAX_ATOMS];
+  const int lane = rb_lane(), wave = rb_wave();
+  const int b_raw = (int)blockIdx.x * 4 + wave;
+  const bool live = b_raw < B;                       // wave-uniform; dead waves compute on sample B-1 and store nothing
+  const int b = live ? b_raw : B - 1;
   const int NZ = Z + A * Z;
-  const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
-  const float inv_unused = 0.0f; (void)inv_unused;
+  const float inv_A = 1.0f;  (void)inv_A;
+
+  float sup[RB_ZI];
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = z < Z ? support[z] : 0.0f; }
+
+  // dueling mean over actions for this lane's atoms: a.mean(1)            model.py:75
+  auto mean_of = [&](const float* lg, float* mean) {
+#pragma unroll
+    for (int i = 0; i < RB_ZI; ++i) {
+      const int z = lane + 64 * i;
+      float acc = 0.0f;
+      if (z < Z)
+        for (int a = 0; a < A; ++a) acc += lg[Z + a * Z + z];
+      mean[i] = acc / (float)A;
+    }
+  };
+  // softmax pieces of action a: fills e[i] = exp(q - max) for this lane's atoms, returns the wave-wide sum
+  auto softmax_of = [&](const float* lg, const float* mean, int a, float* e, float* max_out) {
+    float q[RB_ZI];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < RB_ZI; ++i) {
+      const int z = lane + 64 * i;
+      q[i] = z < Z ? (lg[z] + lg[Z + a * Z + z]) - mean[i] : -INFINITY;   // q = v + a - mean_a(a)
+      mx = fmaxf(mx, q[i]);
+    }
+    mx = rb_wave_max(mx);
+    float se = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RB_ZI; ++i) {
+      const int z = lane + 64 * i;
+      e[i] = z < Z ? expf(q[i] - mx) : 0.0f;
+      q[i] = z < Z ? q[i] - mx : 0.0f;
+      se += e[i];
+    }
+    *max_out = mx;
+    return rb_wave_sum(se);
+  };
 
   // ---------------- double-Q selection on online(next_states)   agent.py:71-73
   const float* lg_n = logits + (int64_t)(B + b) * NZ;
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    float acc = 0.0f;
-    for (int a = 0; a < A; ++a) acc += lg_n[Z + a * Z + z];
-    s_mean[z] = acc / (float)A;                                   // a.mean(1)
-  }
-  __syncthreads();
-  for (int a = wave; a < A; a += nw) {                            // one wave per action
-    float mx = -INFINITY;
-    for (int z = lane; z < Z; z += 64) mx = fmaxf(mx, rb_dueling_q(lg_n, s_mean, Z, a, z));
-    mx = rb_wave_max(mx);
-    float se = 0.0f, sv = 0.0f;
-    for (int z = lane; z < Z; z += 64) {
-      const float e = expf(rb_dueling_q(lg_n, s_mean, Z, a, z) - mx);
-      se += e;
-      sv += support[z] * e;
-    }
-    se = rb_wave_sum(se);
+  float mean[RB_ZI], e[RB_ZI];
+  mean_of(lg_n, mean);
+  int a_star = 0;
+  float best = -INFINITY;
+  for (int a = 0; a < A; ++a) {
+    float mx;
+    const float se = softmax_of(lg_n, mean, a, e, &mx);
+    float sv = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RB_ZI; ++i) sv += sup[i] * e[i];
     sv = rb_wave_sum(sv);
-    if (lane == 0) s_ev[a] = sv / se;                             // sum_z z * p(z)
+    const float ev = sv / se;                                     // sum_z z * p(z)
+    if (ev > best) { best = ev; a_star = a; }                     // argmax, first maximum
   }
-  __syncthreads();
-  if (t == 0) {
-    int best = 0;
-    float bv = s_ev[0];
-    for (int a = 1; a < A; ++a)
-      if (s_ev[a] > bv) { bv = s_ev[a]; best = a; }               // argmax, first maximum
-    s_astar = best;
-    a_star_out[b] = best;
-  }
-  __syncthreads();
-  const int a_star = s_astar;
+  if (live && lane == 0) a_star_out[b] = a_star;
 
   // ---------------- target(next_states)[a*] probabilities        agent.py:75-76
   const float* lg_t = logits + (int64_t)(2 * B + b) * NZ;
-  __syncthreads();
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    float acc = 0.0f;
-    for (int a = 0; a < A; ++a) acc += lg_t[Z + a * Z + z];
-    s_mean[z] = acc / (float)A;
-  }
-  __syncthreads();
+  mean_of(lg_t, mean);
+  float p[RB_ZI];
   {
-    float mx = -INFINITY;
-    for (int z = t; z < Z; z += (int)blockDim.x) mx = fmaxf(mx, rb_dueling_q(lg_t, s_mean, Z, a_star, z));
-    mx = rb_block_max(mx, s_red);
-    float se = 0.0f;
-    for (int z = t; z < Z; z += (int)blockDim.x) {
-      const float e = expf(rb_dueling_q(lg_t, s_mean, Z, a_star, z) - mx);
-      s_p[z] = e;
-      se += e;
-    }
-    se = rb_block_sum(se, s_red);
-    for (int z = t; z < Z; z += (int)blockDim.x) {
-      const float p = s_p[z] / se;
-      s_p[z] = p;
-      pns_a_out[(int64_t)b * Z + z] = p;
+    float mx;
+    const float se = softmax_of(lg_t, mean, a_star, e, &mx);
+#pragma unroll
+    for (int i = 0; i < RB_ZI; ++i) {
+      const int z = lane + 64 * i;
+      p[i] = e[i] / se;
+      if (live && z < Z) pns_a_out[(int64_t)b * Z + z] = p[i];
     }
   }
-  __syncthreads();
 
   // ---------------- C51 projection                               agent.py:79-92
   const float R = returns[b], nt = nonterminals[b];
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    float Tz = R + (nt * gamma_n) * support[z];                   // agent.py:79
-    Tz = fminf(fmaxf(Tz, v_min), v_max);                          // agent.py:80
-    const float bq = (Tz - v_min) / delta_z;                      // agent.py:82
-    int l = (int)floorf(bq), u = (int)ceilf(bq);                  // agent.py:83
-    if (u > 0 && l == u) l -= 1;                                  // agent.py:85
-    if (l < Z - 1 && l == u) u += 1;                              // agent.py:86
-    s_l[z] = l; s_u[z] = u;
-    s_lo[z] = s_p[z] * ((float)u - bq);                           // agent.py:91
-    s_hi[z] = s_p[z] * (bq - (float)l);                           // agent.py:92
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) {
+    const int z = lane + 64 * i;
+    if (z < Z) {
+      float Tz = R + (nt * gamma_n) * sup[i];                     // agent.py:79
+      Tz = fminf(fmaxf(Tz, v_min), v_max);                        // agent.py:80
+      const float bq = (Tz - v_min) / delta_z;                    // agent.py:82
+      int l = (int)floorf(bq), u = (int)ceilf(bq);                // agent.py:83
+      if (u > 0 && l == u) l -= 1;                                // agent.py:85
+      if (l < Z - 1 && l == u) u += 1;                            // agent.py:86
+      s_l[wave][z] = l; s_u[wave][z] = u;
+      s_lo[wave][z] = p[i] * ((float)u - bq);                     // agent.py:91
+      s_hi[wave][z] = p[i] * (bq - (float)l);                     // agent.py:92
+    }
   }
   __syncthreads();
-  for (int k = t; k < Z; k += (int)blockDim.x) {
+  float m[RB_ZI];
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) {
+    const int k = lane + 64 * i;
     float acc = 0.0f;
-    for (int j = 0; j < Z; ++j)                                   // first index_add_ (l bins), in j order
-      if (s_l[j] == k) acc += s_lo[j];
-    for (int j = 0; j < Z; ++j)                                   // then the u bins
-      if (s_u[j] == k) acc += s_hi[j];
-    s_m[k] = acc;
-    m_out[(int64_t)b * Z + k] = acc;
+    if (k < Z) {
+      for (int j = 0; j < Z; ++j)                                 // first index_add_ (l bins), in j order
+        if (s_l[wave][j] == k) acc += s_lo[wave][j];
+      for (int j = 0; j < Z; ++j)                                 // then the u bins
+        if (s_u[wave][j] == k) acc += s_hi[wave][j];
+      if (live) m_out[(int64_t)b * Z + k] = acc;
+    }
+    m[i] = acc;
   }
-  __syncthreads();
 
-  // ---------------- online(states): log p(s_t, a_t)              agent.py:66-67
+  // ---------------- online(states): log p(s_t, a_t), loss        agent.py:66-67,94
   const float* lg_s = logits + (int64_t)b * NZ;
   const int act = (int)actions[b];
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    float acc = 0.0f;
-    for (int a = 0; a < A; ++a) acc += lg_s[Z + a * Z + z];
-    s_mean[z] = acc / (float)A;
-  }
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int z = t; z < Z; z += (int)blockDim.x) mx = fmaxf(mx, rb_dueling_q(lg_s, s_mean, Z, act, z));
-  mx = rb_block_max(mx, s_red);
-  float se = 0.0f;
-  for (int z = t; z < Z; z += (int)blockDim.x) se += expf(rb_dueling_q(lg_s, s_mean, Z, act, z) - mx);
-  se = rb_block_sum(se, s_red);
+  mean_of(lg_s, mean);
+  float mx;
+  const float se = softmax_of(lg_s, mean, act, e, &mx);
   const float lse = logf(se);
+  float logp[RB_ZI];
   float part_loss = 0.0f, part_m = 0.0f;
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    const float lp = (rb_dueling_q(lg_s, s_mean, Z, act, z) - mx) - lse;   // log_softmax
-    s_logp[z] = lp;
-    log_ps_a_out[(int64_t)b * Z + z] = lp;
-    part_loss += s_m[z] * lp;
-    part_m += s_m[z];
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) {
+    const int z = lane + 64 * i;
+    // log_softmax = (q - max) - log(sum exp(q - max))
+    const float qm = z < Z ? ((lg_s[z] + lg_s[Z + act * Z + z]) - mean[i]) - mx : 0.0f;
+    logp[i] = qm - lse;
+    if (z < Z) {
+      if (live) log_ps_a_out[(int64_t)b * Z + z] = logp[i];
+      part_loss += m[i] * logp[i];
+      part_m += m[i];
+    }
   }
-  const float dot = rb_block_sum(part_loss, s_red);
-  const float msum = rb_block_sum(part_m, s_red);
-  if (t == 0) loss_out[b] = -dot;                                  // agent.py:94
-  __syncthreads();
+  const float dot = rb_wave_sum(part_loss);
+  const float msum = rb_wave_sum(part_m);
+  if (live && lane == 0) loss_out[b] = -dot;                       // agent.py:94
 
   // ---------------- backward of mean(w * loss) to the logits     agent.py:96
   // d/dq[z] = (w/B) * (p[z] * sum(m) - m[z]) on the taken action; dueling adjoint:
   // dv[z] = g[z] ; da[a'][z] = (delta(a',act) - 1/A) * g[z]
   const float coef = weights[b] / (float)B;
   float* dl = dlogits + (int64_t)b * NZ;
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    const float g = coef * (expf(s_logp[z]) * msum - s_m[z]);
-    dl[z] = g;
-    const float ga = g / (float)A;
-    for (int a = 0; a < A; ++a) dl[Z + a * Z + z] = (a == act ? g : 0.0f) - ga;
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) {
+    const int z = lane + 64 * i;
+    if (live && z < Z) {
+      const float g = coef * (expf(logp[i]) * msum - m[i]);
+      dl[z] = g;
+      const float ga = g / (float)A;
+      for (int a = 0; a < A; ++a) dl[Z + a * Z + z] = (a == act ? g : 0.0f) - ga;
+    }
   }
 }
 
@@ -467,14 +489,47 @@ static int launch_conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const I
   return RB_OK;
 }
 
+template <class G, int NT, int PR, int KMAX, bool FIRST>
+static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
+                               const NetPtrs& tg, hipStream_t stream) {
+  const ConvLayer& c = l->L.conv[layer];
+  ConvLdsFwdArgs a;
+  a.cin = c.cin; a.cout = c.cout; a.n_on = n_on;
+  a.w[0] = on.conv_w[layer]; a.w[1] = tg.conv_w[layer]; a.bias[0] = on.conv_b[layer]; a.bias[1] = tg.conv_b[layer];
+  a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
+  RB_LAUNCH((k_conv_fwd_lds<G, NT, PR, KMAX, FIRST>),
+            dim3((unsigned)rb_div_up(G::P, 32 * NT), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
+            dim3(RB_CONV_THREADS), stream, a);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
 static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                     const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
+  if (l->fast_conv) {
+    if (c.ks == 8) return launch_conv_fwd_lds<GeomC1, 2, 20, 256, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ks == 4) return launch_conv_fwd_lds<GeomC2, 3, 20, 512, false>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ks == 3) return launch_conv_fwd_lds<GeomC3, 2, 9, 576, false>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ih == 84) return launch_conv_fwd_lds<GeomD1, 2, 20, 100, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    return launch_conv_fwd_lds<GeomD2, 1, 16, 800, false>(l, layer, n_on, n_tg, src, on, tg, stream);
+  }
   if (c.ks == 8) return launch_conv_fwd<GeomC1>(l, layer, n_on, n_tg, src, on, tg, stream);
   if (c.ks == 4) return launch_conv_fwd<GeomC2>(l, layer, n_on, n_tg, src, on, tg, stream);
   if (c.ks == 3) return launch_conv_fwd<GeomC3>(l, layer, n_on, n_tg, src, on, tg, stream);
   if (c.ih == 84) return launch_conv_fwd<GeomD1>(l, layer, n_on, n_tg, src, on, tg, stream);
   return launch_conv_fwd<GeomD2>(l, layer, n_on, n_tg, src, on, tg, stream);
+}
+
+static NlWeights nl_h(const NetPtrs& p) {
+  NlWeights w;
+  w.mu = p.h_mu; w.sigma = p.h_sigma; w.eout = p.h_eout; w.ein = p.h_ein; w.bmu = p.h_bmu; w.bsigma = p.h_bsigma;
+  return w;
+}
+static NlWeights nl_z(const NetPtrs& p) {
+  NlWeights w;
+  w.mu = p.z_mu; w.sigma = p.z_sigma; w.eout = p.z_eout; w.ein = p.z_ein; w.bmu = p.z_bmu; w.bsigma = p.z_bsigma;
+  return w;
 }
 
 // Forward of n_on online images + n_tg target images up to the logits.
@@ -487,12 +542,48 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     if (rc != RB_OK) return rc;
   }
   const float* feat = l->act[L.nconv - 1];
+  const int m_max = n_on > n_tg ? n_on : n_tg;
+  const unsigned mchunks = (unsigned)rb_div_up(m_max, 64);
+  if (l->fast_fc) {
+    // hidden layer: both streams, both nets, weights streamed once (noisy_linear.h)
+    NlFwdArgs a;
+    a.x = feat; a.ldx = L.F;
+    a.m_base[0] = 0; a.m_cnt[0] = n_on; a.m_base[1] = n_on; a.m_cnt[1] = n_tg;
+    a.w[0] = nl_h(on); a.w[1] = nl_h(tg);
+    a.K = L.F; a.n_groups = 2;
+    const int tiles_per_stream = (int)rb_div_up(L.H, 32);
+    a.grp[0] = NlRowGroup{0, L.H, 0, 0, 0};
+    a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, tiles_per_stream};
+    const int chunks = L.F / 16;
+    a.chunks_per_split = (int)rb_div_up(chunks, l->hs);
+    const int splits = (int)rb_div_up(chunks, a.chunks_per_split);
+    a.out = l->hpart; a.ld_out = 2 * L.H; a.rows_total = NI; a.add_bias = 0; a.relu = 0;
+    RB_LAUNCH(k_nl_fwd, dim3((unsigned)(2 * tiles_per_stream), (unsigned)splits, 2 * mchunks), dim3(64 * RB_NL_FWD_WAVES), stream, a);
+    RB_LAUNCH_CHECK();
+    const int64_t total = (int64_t)NI * 2 * L.H;
+    RB_LAUNCH(k_fc_h_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->hpart, splits, NI,
+              2 * L.H, n_on, on, tg, l->h);
+    RB_LAUNCH_CHECK();
+    // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused, no split
+    NlFwdArgs z;
+    z.x = l->h; z.ldx = 2 * L.H;
+    z.m_base[0] = 0; z.m_cnt[0] = n_on; z.m_base[1] = n_on; z.m_cnt[1] = n_tg;
+    z.w[0] = nl_z(on); z.w[1] = nl_z(tg);
+    z.K = L.H; z.n_groups = 2;
+    const int vt = (int)rb_div_up(L.Z, 32), at = (int)rb_div_up(L.NZ - L.Z, 32);
+    z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
+    z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt};
+    z.chunks_per_split = L.H / 16;
+    z.out = l->logits; z.ld_out = L.NZ; z.rows_total = NI; z.add_bias = 1; z.relu = 0;
+    RB_LAUNCH(k_nl_fwd, dim3((unsigned)(vt + at), 1, 2 * mchunks), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    RB_LAUNCH_CHECK();
+    return RB_OK;
+  }
   {
     FcHFwdProb p;
     p.F = L.F; p.H = L.H; p.NI = NI; p.splits = l->hs;
     p.n_img[0] = n_on; p.n_img[1] = n_tg; p.img_base[0] = 0; p.img_base[1] = n_on;
     p.feat = feat; p.net[0] = on; p.net[1] = tg; p.part = l->hpart;
-    const int m_max = n_on > n_tg ? n_on : n_tg;
     RB_LAUNCH((k_gemm<2, 2, FcHFwdProb>),
               dim3((unsigned)rb_div_up(m_max, 64), (unsigned)rb_div_up(2 * L.H, 64), (unsigned)(2 * l->hs)), dim3(256),
               stream, p);
@@ -507,7 +598,6 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     p.H = L.H; p.Z = L.Z; p.NZ = L.NZ;
     p.n_img[0] = n_on; p.n_img[1] = n_tg; p.img_base[0] = 0; p.img_base[1] = n_on;
     p.h = l->h; p.net[0] = on; p.net[1] = tg; p.logits = l->logits;
-    const int m_max = n_on > n_tg ? n_on : n_tg;
     RB_LAUNCH((k_gemm<1, 1, FcZFwdProb>),
               dim3((unsigned)rb_div_up(m_max, 32), (unsigned)rb_div_up(L.NZ - L.Z, 32), 4), dim3(64), stream, p);
     RB_LAUNCH_CHECK();
@@ -538,10 +628,21 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   }
   RB_LAUNCH_CHECK();
   const int64_t total = (int64_t)c.cout * (K + 1);
-  RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream,
+  RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 64)), dim3(64), stream,
             (const float*)l->dw_part[layer], splits, c.cout, K, gw, gb);
   RB_LAUNCH_CHECK();
-  if (layer > 0) {
+  if constexpr (G::IH == 84) {
+    // first-layer geometries never need a data gradient (frames are not differentiated)
+  } else if (layer > 0 && l->fast_conv) {
+    ConvLdsDxArgs a;
+    a.cin = c.cin; a.cout = c.cout;
+    a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
+    constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
+    constexpr int NT = (NPOS + 31) / 32;
+    RB_LAUNCH((k_conv_dx_lds<G, NT, 64>), dim3((unsigned)(G::S * G::S), (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B),
+              dim3(RB_CONV_THREADS), stream, a);
+    RB_LAUNCH_CHECK();
+  } else if (layer > 0) {
     ConvDxProb<G> p;
     p.B = L.B; p.cin = c.cin; p.cout = c.cout;
     p.w = l->p_online + L.conv_w[layer]; p.dy = l->dact[layer]; p.x_act = l->act[layer - 1]; p.dx = l->dact[layer - 1];
@@ -692,8 +793,16 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->delta_z = (float)(((double)cfg->v_max - (double)cfg->v_min) / (double)(cfg->atoms - 1));
   const int B = L.B, NI = 3 * B;
   // split-K factors: aim for >= ~2 workgroups per CU on the 256-CU part
-  l->hs = pick_splits(rb_div_up(2 * B, 64) * rb_div_up(2 * L.H, 64) * 2, (L.F + 15) / 16, 512);
-  l->xs = pick_splits(rb_div_up(B, 32) * rb_div_up(L.F, 64), (2 * L.H + 15) / 16, 512);
+  const char* generic_only = getenv("RB_GENERIC_GEMM_ONLY");   // A/B switch: force the gemm_core fallback
+  l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
+  l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
+  if (l->fast_fc) {
+    l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
+    l->xs = pick_splits(rb_div_up(L.F, 64) * rb_div_up(B, 64), 2 * L.H / 16, 512);
+  } else {
+    l->hs = pick_splits(rb_div_up(2 * B, 64) * rb_div_up(2 * L.H, 64) * 2, (L.F + 15) / 16, 512);
+    l->xs = pick_splits(rb_div_up(B, 32) * rb_div_up(L.F, 64), (2 * L.H + 15) / 16, 512);
+  }
   for (int i = 0; i < L.nconv; ++i) {
     const ConvLayer& c = L.conv[i];
     const int64_t tiles = i == 0 ? rb_div_up(c.cout, 32) * rb_div_up(c.K() + 1, 64)
@@ -784,12 +893,63 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
   const NetPtrs tg = net_ptrs(L, l->p_target, l->n_target);
   int rc = forward(l, 2 * B, B, src, on, tg, stream);
   if (rc != RB_OK) return rc;
-  RB_LAUNCH(k_head, dim3((unsigned)B), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
+  RB_LAUNCH(k_head, dim3((unsigned)rb_div_up(B, 4)), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
             l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B))
+  const float* feat = l->act[L.nconv - 1];
+  if (l->fast_fc) {
+    {   // fc_z weight + bias grads
+      NlDwArgs a;
+      a.dy = l->dlogits; a.x = l->h; a.ldy = L.NZ; a.ldx = 2 * L.H; a.M = B; a.K = L.H; a.n_prob = 2;
+      const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
+      a.prob[0] = NlDwProblem{0, L.Z, 0, 0, 0};
+      a.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
+      a.g_mu = l->grads + L.z_mu; a.g_sigma = l->grads + L.z_sigma; a.g_bmu = l->grads + L.z_bmu;
+      a.g_bsigma = l->grads + L.z_bsigma; a.eout = on.z_eout; a.ein = on.z_ein;
+      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.H, 256), (unsigned)(vt + at)), dim3(256), stream, a);
+      RB_LAUNCH_CHECK();
+    }
+    {   // fc_z input grads + hidden ReLU mask -> dh
+      NlDxArgs a;
+      a.dy = l->dlogits; a.ldy = L.NZ; a.M = B; a.w = nl_z(on); a.K = L.H; a.n_prob = 2;
+      a.prob[0] = NlDxProblem{0, L.Z, 1 << 30, 0, 0, 0};
+      a.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
+      a.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
+      a.out = l->dh; a.ld_out = 2 * L.H; a.mask_src = l->h;
+      RB_LAUNCH(k_nl_dx, dim3((unsigned)rb_div_up(L.H, 64), 1, 2 * (unsigned)rb_div_up(B, 64)), dim3(256), stream, a);
+      RB_LAUNCH_CHECK();
+    }
+    {   // fc_h weight + bias grads
+      NlDwArgs a;
+      a.dy = l->dh; a.x = feat; a.ldy = 2 * L.H; a.ldx = L.F; a.M = B; a.K = L.F; a.n_prob = 2;
+      const int ht = (int)rb_div_up(L.H, 16);
+      a.prob[0] = NlDwProblem{0, L.H, 0, 0, 0};
+      a.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
+      a.g_mu = l->grads + L.h_mu; a.g_sigma = l->grads + L.h_sigma; a.g_bmu = l->grads + L.h_bmu;
+      a.g_bsigma = l->grads + L.h_bsigma; a.eout = on.h_eout; a.ein = on.h_ein;
+      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.F, 256), (unsigned)(2 * ht)), dim3(256), stream, a);
+      RB_LAUNCH_CHECK();
+    }
+    {   // fc_h input grads, split over the 2H reduction rows -> partials -> ReLU-masked dfeat
+      NlDxArgs a;
+      a.dy = l->dh; a.ldy = 2 * L.H; a.M = B; a.w = nl_h(on); a.K = L.F; a.n_prob = 1;
+      a.prob[0] = NlDxProblem{0, 2 * L.H, L.H, 0, L.F, 0};
+      a.prob[1] = a.prob[0];
+      a.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
+      const int splits = (int)rb_div_up(2 * L.H, a.rows_per_split);
+      a.out = l->dfeat_part; a.ld_out = L.F; a.mask_src = nullptr;
+      RB_LAUNCH(k_nl_dx, dim3((unsigned)rb_div_up(L.F, 64), (unsigned)splits, (unsigned)rb_div_up(B, 64)), dim3(256),
+                stream, a);
+      RB_LAUNCH_CHECK();
+      const int64_t total = (int64_t)B * L.F;
+      RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
+                splits, total, feat, l->dact[L.nconv - 1]);
+      RB_LAUNCH_CHECK();
+    }
+  } else {
   FcGradOut gz;
   gz.g_mu = l->grads + L.z_mu; gz.g_sigma = l->grads + L.z_sigma; gz.g_bmu = l->grads + L.z_bmu;
   gz.g_bsigma = l->grads + L.z_bsigma; gz.eout = on.z_eout; gz.ein = on.z_ein;
@@ -807,7 +967,6 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
               stream, p);
     RB_LAUNCH_CHECK();
   }
-  const float* feat = l->act[L.nconv - 1];
   {
     FcHDwProb p;
     p.B = B; p.H = L.H; p.F = L.F; p.dh = l->dh; p.feat = feat;
@@ -827,6 +986,7 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
     RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
               l->xs, total, feat, l->dact[L.nconv - 1]);
     RB_LAUNCH_CHECK();
+  }
   }
   for (int layer = L.nconv - 1; layer >= 0; --layer) {
     rc = conv_bwd(l, layer, states_dev, stream);

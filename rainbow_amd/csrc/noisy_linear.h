@@ -1,0 +1,377 @@
+// noisy_linear.h — the NoisyLinear layers (model.py:10-46) for skinny batches, streamed
+// straight from HBM into v_mfma_f32_16x16x4_f32.
+//
+// Why a dedicated family: with M = B..3B rows (32..96) against [1024 x 3136] weights the hidden
+// layer is a weight-bandwidth problem — 51 MB of mu/sigma per forward, 26 MB per input-gradient
+// pass, 26 MB of gradient written — and each weight is used once per block, so an LDS round trip
+// buys nothing (guide: "operand streamed once per block and not shared across waves: load
+// straight to VGPRs").  The 16x16x4 MFMA shape is chosen for the LOADS, not the math: its B
+// operand wants lane l to hold column l&15 for k-slot l>>4, so with one float4 per lane
+//   * forward (k contiguous in memory):   4 lanes x 16 B = 64 contiguous bytes per weight row,
+//   * input/weight gradients (output columns contiguous): 16 lanes x 16 B = 256 B per row,
+// and four MFMAs consume the float4 (the k / column permutation inside a step is irrelevant to a
+// sum).  Noisy weights are formed in registers, W = mu + sigma * (eps_out * eps_in), with the
+// reference's rounding order (model.py:39,44); eps_w is never materialised.
+//
+// Preconditions (checked by the host; the generic gemm_core path remains the fallback):
+// K % 16 == 0, all leading dimensions and offsets multiples of 4 floats.
+#pragma once
+#include "rb_device.h"
+
+struct NlWeights {
+  const float* mu;      // [N][K]
+  const float* sigma;   // [N][K]
+  const float* eout;    // [N]
+  const float* ein;     // [streams][K] (offset per row group)
+  const float* bmu;     // [N]
+  const float* bsigma;  // [N]
+};
+
+// W = mu + sigma * (eo * ein), component-wise, three separately rounded operations
+__device__ __forceinline__ float4 rb_noisy4(float4 mu, float4 sg, float eo, float4 e) {
+  float4 w;
+  w.x = mu.x + sg.x * (eo * e.x);
+  w.y = mu.y + sg.y * (eo * e.y);
+  w.z = mu.z + sg.z * (eo * e.z);
+  w.w = mu.w + sg.w * (eo * e.w);
+  return w;
+}
+
+// ============================================================================ forward ==
+// out[m][n] = sum_k x[m][x_off + k] * W[n][k]  (+ bias, ReLU optional when not split)
+struct NlRowGroup {
+  int row_begin, row_cnt;   // weight rows of this stream
+  int x_off, ein_off;       // column offset into x, offset into ein
+  int tile_begin;           // first 32-row tile index of this group in grid.x
+};
+struct NlFwdArgs {
+  const float* x;
+  int ldx;
+  int m_base[2], m_cnt[2];  // activation rows of net 0 / net 1
+  NlWeights w[2];
+  int K;
+  int n_groups;
+  NlRowGroup grp[2];
+  int chunks_per_split;     // 16-wide k chunks per block (grid.y = splits)
+  float* out;               // split: part[s][rows_total][ld_out] ; else out[rows_total][ld_out]
+  int ld_out, rows_total;
+  int add_bias, relu;       // only with a single split
+};
+
+// grid = (32-row tiles, k splits, 2 * m-chunks of 64 rows), block = 512 (8 waves split the k range).
+// Each wave keeps the NEXT 16-wide k chunk's loads in flight while the MFMAs of the current one run.
+#define RB_NL_FWD_WAVES 8
+__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd(NlFwdArgs a) {
+  __shared__ float s_red[RB_NL_FWD_WAVES][32][64];
+  const int lane = rb_lane(), wave = rb_wave();
+  const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
+  const int M = a.m_cnt[net];
+  const int m0 = mc * 64;
+  if (m0 >= M) return;                                   // block-uniform
+  const int mt_cnt = (M - m0 >= 64) ? 4 : (M - m0 + 15) / 16;
+  const int g = (a.n_groups > 1 && (int)blockIdx.x >= a.grp[1].tile_begin) ? 1 : 0;
+  const NlRowGroup grp = a.grp[g];
+  const int row0 = grp.row_begin + ((int)blockIdx.x - grp.tile_begin) * 32;
+  const int row_end = grp.row_begin + grp.row_cnt;
+  const NlWeights w = a.w[net];
+  const int K = a.K;
+
+  const int total_chunks = K / 16;
+  const int c_begin = (int)blockIdx.y * a.chunks_per_split;
+  int c_end = c_begin + a.chunks_per_split;
+  if (c_end > total_chunks) c_end = total_chunks;
+  const int per_wave = (c_end - c_begin + RB_NL_FWD_WAVES - 1) / RB_NL_FWD_WAVES;
+  int wc0 = c_begin + wave * per_wave, wc1 = wc0 + per_wave;
+  if (wc1 > c_end) wc1 = c_end;
+
+  const int r = lane & 15, q = lane >> 4;
+  const float* mu_p[2];
+  const float* sg_p[2];
+  float eo[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int row = row0 + 16 * t + r;
+    if (row > row_end - 1) row = row_end - 1;
+    mu_p[t] = w.mu + (int64_t)row * K;
+    sg_p[t] = w.sigma + (int64_t)row * K;
+    eo[t] = w.eout[row];
+  }
+  const float* x_p[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int m = m0 + 16 * mt + r;
+    if (m > M - 1) m = M - 1;
+    x_p[mt] = a.x + (int64_t)(a.m_base[net] + m) * a.ldx + grp.x_off;
+  }
+  const float* ein_p = w.ein + grp.ein_off;
+
+  rb_f32x4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][t][e] = 0.0f;
+
+  float4 n_e, n_mu[2], n_sg[2], n_x[4];
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) n_x[mt] = zero4;
+  auto issue = [&](int c) {
+    const int k4 = c * 16 + 4 * q;
+    n_e = rb_ld4(ein_p + k4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { n_mu[t] = rb_ld4(mu_p[t] + k4); n_sg[t] = rb_ld4(sg_p[t] + k4); }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      if (mt < mt_cnt) n_x[mt] = rb_ld4(x_p[mt] + k4);
+  };
+  if (wc0 < wc1) issue(wc0);
+  for (int c = wc0; c < wc1; ++c) {
+    float4 w4[2], x4[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w4[t] = rb_noisy4(n_mu[t], n_sg[t], eo[t], n_e);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) x4[mt] = n_x[mt];
+    if (c + 1 < wc1) issue(c + 1);                       // next chunk's loads fly under these MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (mt < mt_cnt) {                                 // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[mt][t] = rb_mfma16(x4[mt].x, w4[t].x, acc[mt][t]);
+          acc[mt][t] = rb_mfma16(x4[mt].y, w4[t].y, acc[mt][t]);
+          acc[mt][t] = rb_mfma16(x4[mt].z, w4[t].z, acc[mt][t]);
+          acc[mt][t] = rb_mfma16(x4[mt].w, w4[t].w, acc[mt][t]);
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the four k sub-ranges through LDS, fixed order
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_red[wave][(mt * 2 + t) * 4 + e][lane] = acc[mt][t][e];
+  __syncthreads();
+  const int slots = mt_cnt * 8;
+  for (int idx = (int)threadIdx.x; idx < slots * 64; idx += 64 * RB_NL_FWD_WAVES) {
+    const int slot = idx >> 6, l = idx & 63;
+    float v = s_red[0][slot][l];
+#pragma unroll
+    for (int wv = 1; wv < RB_NL_FWD_WAVES; ++wv) v += s_red[wv][slot][l];
+    const int mt = slot >> 3, t = (slot >> 2) & 1, e = slot & 3;
+    const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
+    const int n = row0 + 16 * t + (l & 15);
+    if (m < M && n < row_end) {
+      float o = v;
+      if (a.add_bias) o += w.bmu[n] + w.bsigma[n] * w.eout[n];      // model.py:44
+      if (a.relu) o = fmaxf(o, 0.0f);
+      a.out[((int64_t)blockIdx.y * a.rows_total + a.m_base[net] + m) * a.ld_out + n] = o;
+    }
+  }
+}
+
+// ====================================================================== input gradient ==
+// dx[m][out_off + k] = sum_{n in rows} dy[m][n] * W[n][k]      (adjoint of the forward)
+struct NlDxProblem {
+  int row_begin, row_cnt;    // reduction range (weight rows)
+  int ein_split_row;         // rows >= this use ein_off1 (fc_h: the advantage stream), else ein_off0
+  int ein_off0, ein_off1;
+  int out_off;               // column offset in dx
+};
+struct NlDxArgs {
+  const float* dy;           // [M][ldy]
+  int ldy, M;
+  NlWeights w;
+  int K;                     // output columns of one problem
+  int n_prob;
+  NlDxProblem prob[2];
+  int rows_per_split;        // reduction rows per block (multiple of 16); grid.y = splits
+  float* out;                // split: part[s][M][ld_out]; else dx[M][ld_out]
+  int ld_out;
+  const float* mask_src;     // non-split only: dx = mask_src > 0 ? v : 0  (ReLU adjoint), same indexing as out
+};
+
+// grid = (64-column tiles, row splits, n_prob * m-chunks of 64), block = 256 (4 waves split the rows)
+__global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
+  __shared__ float s_red[4][64][64];
+  const int lane = rb_lane(), wave = rb_wave();
+  const int pi = (int)blockIdx.z % a.n_prob, mc = (int)blockIdx.z / a.n_prob;
+  const NlDxProblem pr = a.prob[pi];
+  const int m0 = mc * 64;
+  if (m0 >= a.M) return;
+  const int mt_cnt = (a.M - m0 >= 64) ? 4 : (a.M - m0 + 15) / 16;
+  const int K = a.K;
+  const int kt = (int)blockIdx.x * 64;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  int rb = pr.row_begin + (int)blockIdx.y * a.rows_per_split;
+  int re = rb + a.rows_per_split;
+  if (re > row_end) re = row_end;
+  if (rb >= re) return;                                  // block-uniform
+  const int per_wave = (((re - rb) + 3) / 4 + 3) / 4 * 4;  // rows per wave, multiple of 4
+  int wr0 = rb + wave * per_wave, wr1 = wr0 + per_wave;
+  if (wr1 > re) wr1 = re;
+
+  const int c = lane & 15, q = lane >> 4;
+  int col4 = kt + 4 * c;
+  if (col4 > K - 4) col4 = K - 4;                        // clamped lanes are never stored
+  const float4 e0 = rb_ld4(a.w.ein + pr.ein_off0 + col4);
+  const float4 e1 = rb_ld4(a.w.ein + pr.ein_off1 + col4);
+
+  rb_f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][j][e] = 0.0f;
+
+  for (int nb = wr0; nb < wr1; nb += 16) {               // 4 row-steps of loads in flight per iteration
+    float4 w4[4];
+    float av[4][4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int n = nb + 4 * st + q;
+      const bool nv = n < wr1;
+      const int nc = nv ? n : wr1 - 1;
+      w4[st] = rb_noisy4(rb_ld4(a.w.mu + (int64_t)nc * K + col4), rb_ld4(a.w.sigma + (int64_t)nc * K + col4),
+                         a.w.eout[nc], nc >= pr.ein_split_row ? e1 : e0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 16 * mt + c;
+        av[st][mt] = (mt < mt_cnt && nv && m < a.M) ? a.dy[(int64_t)m * a.ldy + n] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      if (nb + 4 * st < wr1) {                             // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (mt < mt_cnt) {
+            acc[mt][0] = rb_mfma16(av[st][mt], w4[st].x, acc[mt][0]);
+            acc[mt][1] = rb_mfma16(av[st][mt], w4[st].y, acc[mt][1]);
+            acc[mt][2] = rb_mfma16(av[st][mt], w4[st].z, acc[mt][2]);
+            acc[mt][3] = rb_mfma16(av[st][mt], w4[st].w, acc[mt][3]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
+  __syncthreads();
+  const int slots = mt_cnt * 4;                          // (mt, e) pairs; j is the float4 lane
+  for (int idx = (int)threadIdx.x; idx < slots * 64; idx += 256) {
+    const int slot = idx >> 6, l = idx & 63;
+    float4 v;
+    float* vv = &v.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = slot * 4 + j;
+      vv[j] = ((s_red[0][s][l] + s_red[1][s][l]) + s_red[2][s][l]) + s_red[3][s][l];
+    }
+    const int mt = slot >> 2, e = slot & 3;
+    const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
+    const int k = kt + 4 * (l & 15);
+    if (m < a.M && k < K) {
+      const int64_t o = ((int64_t)blockIdx.y * a.M + m) * a.ld_out + pr.out_off + k;
+      if (a.mask_src) {
+        const float4 ms = rb_ld4(a.mask_src + o);
+        v.x = ms.x > 0.0f ? v.x : 0.0f;
+        v.y = ms.y > 0.0f ? v.y : 0.0f;
+        v.z = ms.z > 0.0f ? v.z : 0.0f;
+        v.w = ms.w > 0.0f ? v.w : 0.0f;
+      }
+      rb_st4(a.out + o, v);
+    }
+  }
+}
+
+// ===================================================================== weight gradient ==
+// g_mu[n][k] = sum_m dy[m][n] * x[m][x_off + k] ; g_sigma = g_mu * (eps_out[n]*eps_in[k]) ;
+// g_bmu[n] = sum_m dy[m][n] ; g_bsigma = g_bmu * eps_out[n].   One writer per element.
+struct NlDwProblem {
+  int row_begin, row_cnt;    // weight rows == columns of dy
+  int x_off, ein_off;
+  int tile_begin;            // first 16-row tile index in grid.y
+};
+struct NlDwArgs {
+  const float* dy;           // [M][ldy]
+  const float* x;            // [M][ldx]
+  int ldy, ldx, M, K;
+  int n_prob;
+  NlDwProblem prob[2];
+  float *g_mu, *g_sigma, *g_bmu, *g_bsigma;
+  const float *eout, *ein;
+};
+
+// grid = (256-column tiles, 16-row tiles), block = 256: wave w owns columns [256*bx + 64*w, +64)
+__global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
+  const int lane = rb_lane(), wave = rb_wave();
+  const int kt = (int)blockIdx.x * 256 + wave * 64;
+  if (kt >= a.K) return;                                 // wave-uniform, no barriers below
+  const int g = (a.n_prob > 1 && (int)blockIdx.y >= a.prob[1].tile_begin) ? 1 : 0;
+  const NlDwProblem pr = a.prob[g];
+  const int row0 = pr.row_begin + ((int)blockIdx.y - pr.tile_begin) * 16;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  const int c = lane & 15, q = lane >> 4;
+  int col4 = kt + 4 * c;
+  const bool cv = col4 < a.K;
+  if (!cv) col4 = a.K - 4;
+  int arow = row0 + c;
+  const bool av_ok = arow < row_end;
+  if (!av_ok) arow = row_end - 1;
+
+  rb_f32x4 acc[4], accb;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+  const bool do_bias = kt == 0;
+  for (int mb = 0; mb < a.M; mb += 32) {                  // 8 reduction steps of loads in flight per iteration
+    float avs[8];
+    float4 xs[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int m = mb + 4 * st + q;
+      const bool mv = m < a.M;
+      const int mcl = mv ? m : a.M - 1;
+      avs[st] = (mv && av_ok) ? a.dy[(int64_t)mcl * a.ldy + arow] : 0.0f;
+      xs[st] = rb_ld4(a.x + (int64_t)mcl * a.ldx + pr.x_off + col4);
+      if (!mv) { xs[st].x = 0.0f; xs[st].y = 0.0f; xs[st].z = 0.0f; xs[st].w = 0.0f; }
+    }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      if (mb + 4 * st < a.M) {                             // uniform
+        acc[0] = rb_mfma16(avs[st], xs[st].x, acc[0]);
+        acc[1] = rb_mfma16(avs[st], xs[st].y, acc[1]);
+        acc[2] = rb_mfma16(avs[st], xs[st].z, acc[2]);
+        acc[3] = rb_mfma16(avs[st], xs[st].w, acc[3]);
+        if (do_bias) accb = rb_mfma16(avs[st], 1.0f, accb);   // wave-uniform
+      }
+    }
+  }
+  const float4 e4 = rb_ld4(a.ein + pr.ein_off + col4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    if (n < row_end) {
+      const float eo = a.eout[n];
+      if (cv) {
+        float4 gm, gs;
+        gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
+        gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
+        rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
+        rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+      }
+      if (do_bias && c == 0) {
+        a.g_bmu[n] = accb[e];
+        a.g_bsigma[n] = accb[e] * eo;
+      }
+    }
+  }
+}

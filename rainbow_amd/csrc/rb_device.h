@@ -42,7 +42,21 @@ __device__ __forceinline__ rb_f32x16 rb_mfma32(float a, float b, rb_f32x16 c) {
 #endif
 }
 
+// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16).  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+// D[r] sits at row 4*(l>>4) + r, col l&15.  32-cycle issue, 40-cycle dependent latency.
+__device__ __forceinline__ rb_f32x4 rb_mfma16(float a, float b, rb_f32x4 c) {
+#if defined(RB_HOST_INTERP)
+  return hipemu_mfma_f32_16x16x4f32(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ int rb_mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// 16-byte global/LDS accesses (pointers must be 16-byte aligned)
+__device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int rb_wave() { return (int)(threadIdx.x >> 6); }

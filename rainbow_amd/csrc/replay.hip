@@ -427,15 +427,42 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 //
 // Latency structure: the L ancestor sums are NOT walked through memory level by level (that is
 // L dependent round trips).  Each thread prefetches the sibling of its node on every level in one
-// batch of independent loads, then the walk to the root happens in registers; where two paths of
-// this batch meet, the sibling's fresh value is taken from LDS (published per level) instead of
-// the stale prefetched one.  Every parent is still fl32(left + right) of its current children
-// (memory.py:25), so the resulting floats are exactly the reference's.
+// batch of independent loads, then walks to the root in registers.  Where two paths of this batch
+// meet, the sibling's FRESH value must be used instead of the prefetched one: every level
+// publishes (node -> value) in an LDS hash table (open addressing, 2048 slots for <= 1024 keys,
+// three tables in rotation so one barrier per level suffices) and looks its sibling up there —
+// O(1) LDS probes per level instead of scanning the batch.  Every parent is still
+// fl32(left + right) of its current children (memory.py:25): same floats as the reference.
 #define RB_MAX_LEVELS 31
+#define RB_HASH_SLOTS 2048
+
+__device__ __forceinline__ int rb_hash_slot(int node) {
+  return (int)(((unsigned)node * 2654435761u) >> 21);   // top 11 bits
+}
+__device__ __forceinline__ int rb_hash_insert(int* keys, int node) {
+  int h = rb_hash_slot(node);
+  for (;;) {
+    const int prev = atomicCAS(&keys[h], -1, node);
+    if (prev == -1 || prev == node) return h;
+    h = (h + 1) & (RB_HASH_SLOTS - 1);
+  }
+}
+__device__ __forceinline__ int rb_hash_find(const int* keys, int node) {
+  int h = rb_hash_slot(node);
+  for (;;) {
+    const int k = keys[h];
+    if (k == node) return h;
+    if (k == -1) return -1;
+    h = (h + 1) & (RB_HASH_SLOTS - 1);
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
                                                   int32_t apply_pow, double omega) {
-  __shared__ int s_node[2][1024];
-  __shared__ float s_val[2][1024];
+  __shared__ int s_key[4][RB_HASH_SLOTS];     // [3] = leaf de-duplication table
+  __shared__ float s_tv[3][RB_HASH_SLOTS];
+  __shared__ int s_pos[RB_HASH_SLOTS];
+  __shared__ float s_vi[1024];
   __shared__ float s_red[16];
   const int i = (int)threadIdx.x;
   const bool active = i < n;
@@ -455,38 +482,49 @@ __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tr
       }
     }
   }
+  for (int t = i; t < RB_HASH_SLOTS; t += (int)blockDim.x) {
+    s_key[0][t] = -1; s_key[1][t] = -1; s_key[2][t] = -1; s_key[3][t] = -1;
+    s_pos[t] = -1;
+  }
   float val = 0.0f;
   if (active) {
     val = values[i];
     if (apply_pow) val = (float)pow((double)val, omega);
   }
-  const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47
-  s_node[0][i] = node;
-  s_val[0][i] = val;
-  __syncthreads();
+  s_vi[i] = val;
+  const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47 (+ barrier)
+  int slot = -1;
   if (active) {
-    for (int j = n - 1; j > i; --j)            // last occurrence wins (memory.py:45)
-      if (s_node[0][j] == node) { val = s_val[0][j]; break; }
-    v.tree[node] = val;
+    slot = rb_hash_insert(s_key[3], node);
+    atomicMax(&s_pos[slot], i);                // last occurrence wins (memory.py:45)
   }
   __syncthreads();
+  if (active) {
+    val = s_vi[s_pos[slot]];
+    v.tree[node] = val;
+  }
+  int prev_slot = -1;
 #pragma unroll
   for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
     if (lv < v.levels) {                        // block-uniform
-      const int c = lv & 1;
-      s_node[c][i] = node;
-      s_val[c][i] = val;
+      const int c = lv % 3;
+      int my = -1;
+      if (active) {
+        my = rb_hash_insert(s_key[c], node);
+        s_tv[c][my] = val;                      // paths on the same node carry the same value
+      }
       __syncthreads();
       if (active) {
+        if (prev_slot >= 0) s_key[(lv + 2) % 3][prev_slot] = -1;   // retire level lv-1's entry (all its lookups are done)
         const int sb = (node & 1) ? node + 1 : node - 1;
-        float sv = sib[lv];
-        for (int j = 0; j < n; ++j)
-          if (s_node[c][j] == sb) { sv = s_val[c][j]; break; }
+        const int f = rb_hash_find(s_key[c], sb);
+        const float sv = f >= 0 ? s_tv[c][f] : sib[lv];
         const float left = (node & 1) ? val : sv;     // odd index = left child (2p+1)
         const float right = (node & 1) ? sv : val;
         val = __fadd_rn(left, right);                 // memory.py:25
         node = (node - 1) >> 1;
         v.tree[node] = val;
+        prev_slot = my;
       }
     }
   }
@@ -691,7 +729,8 @@ int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, cons
   RB_REQUIRE(batch >= 1 && batch <= r->max_batch, "rb_replay_sample: batch must be in [1,%d]", r->max_batch);
   RB_REQUIRE(max_attempts >= 1, "rb_replay_sample: max_attempts must be >= 1");
   const ReplayView v = view_of(r);
-  const int threads = (int)(rb_div_up(batch, 64) * 64);
+  int threads = (int)(rb_div_up(batch, 64) * 64);
+  if (threads < 256) threads = 256;   // enough lanes to stage the 16 KB tree top into LDS in one sweep
   // weights ** -beta: python float exponent is cast to float32 by numpy (NEP 50 weak scalar)
   const float neg_beta = (float)(-priority_weight);
   RB_LAUNCH(k_sample, dim3(1), dim3(threads), stream, v, batch, neg_beta, unit_uniforms_dev, max_attempts, r->seed,

@@ -114,6 +114,7 @@ inline int __any(int pred) { return __ballot(pred) != 0ull; }
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
@@ -142,6 +143,34 @@ inline rb_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, rb_f32x16 c) {
       float av, bv;
       std::memcpy(&av, &sa[k * 32 + row], 4);
       std::memcpy(&bv, &sb[k * 32 + col], 4);
+      acc = std::fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return c;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i][k] in lane k*16+i, B[k][j] in lane k*16+j (k<4), D[r]: row = 4*(lane>>4)+r, col = lane&15
+inline rb_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, rb_f32x4 c) {
+  uint64_t* sa = hipemu::wave_slots(0);
+  uint64_t* sb = hipemu::wave_slots(1);
+  const int lane = hipemu::lane_id();
+  uint64_t ra = 0, rb = 0;
+  std::memcpy(&ra, &a, 4);
+  std::memcpy(&rb, &b, 4);
+  sa[lane] = ra;
+  sb[lane] = rb;
+  hipemu::wave_barrier();
+  if (hipemu::wave_width() != 64) { std::fprintf(stderr, "hipemu: MFMA in a partial wave\n"); std::abort(); }
+  const int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      std::memcpy(&av, &sa[k * 16 + row], 4);
+      std::memcpy(&bv, &sb[k * 16 + col], 4);
       acc = std::fmaf(av, bv, acc);
     }
     c[r] = acc;
