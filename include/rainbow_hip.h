@@ -124,6 +124,11 @@ int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight,
                      int64_t* actions_dev, float* returns_dev, float* nonterminals_dev,
                      float* weights_dev, rb_stream_t stream);
 
+/* Graph replay support: when set (non-NULL), rb_replay_sample reads -beta (float32, i.e.
+ * float32(-priority_weight), memory.py:153) from this DEVICE location instead of its by-value
+ * argument, so main.py:161's per-step annealing works under a captured hipGraph.           */
+int rb_replay_set_beta_source(rb_replay_t* r, const float* neg_beta_dev);
+
 /* SegmentTree.update (memory.py:44-48): raw leaf values, duplicates last-write-wins. */
 int rb_replay_update_leaves(rb_replay_t* r, const int64_t* tree_idx_dev, const float* values_dev,
                             int32_t n, rb_stream_t stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rb_replay_find": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rb_replay_sample": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rb_replay_set_beta_source": (c_int, [c_void_p, c_void_p]),
     "rb_replay_update_leaves": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_update_priorities": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_state_at": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

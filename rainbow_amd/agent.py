@@ -89,14 +89,23 @@ class Agent:
 
         self.params.requires_grad_(True)
         self.params.grad = self.grads
+        # capturable: the step counter lives on the device so the whole learn step can be replayed as one hipGraph
         try:
-            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps, fused=True)
+            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps, fused=True,
+                                              capturable=True)
         except (TypeError, RuntimeError):
-            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps)
+            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps, capturable=True)
+        self._graph = None
+        self._graph_mem = None
+        self._eager_steps = 0
+        self._use_graph = os.environ.get("RAINBOW_AMD_GRAPH", "1") != "0"
         self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
         self._norm = torch.zeros(1, dtype=torch.float32, device=d)
         self._act_out = torch.zeros(1, dtype=torch.int32, device=d)
         self._q_out = torch.zeros(1, dtype=torch.float32, device=d)
+        self._side = torch.cuda.Stream(device=d)          # priority write-back overlaps clip + Adam
+        self._ev_loss = torch.cuda.Event()
+        self._ev_upd = torch.cuda.Event()
         self._world = rdist.world_size()
         if self._world > 1:   # identical replicas: rank 0's initial parameters everywhere
             rdist.broadcast_parameters(self.params.detach(), 0)
@@ -190,8 +199,37 @@ class Agent:
         self._forward_single(state)
         return float(self._q_out.item())
 
+    GRAPH_WARMUP = 3   # eager steps before the learn step is captured into a hipGraph
+
     def learn(self, mem, _target_raw_normals=None, _unit_uniforms=None):
-        """agent.py:61-100."""
+        """agent.py:61-100.  With a rainbow_amd ReplayMemory the whole step (sample .. priority update) is
+        device-resident; after GRAPH_WARMUP eager calls it is captured once into a hipGraph and replayed
+        (set RAINBOW_AMD_GRAPH=0 to stay eager).  The injected-randomness arguments are parity-test hooks."""
+        injected = _target_raw_normals is not None or _unit_uniforms is not None
+        if (self._use_graph and not injected and self._world == 1 and isinstance(mem, ReplayMemory)):
+            if self._graph is not None and self._graph_mem is mem:
+                mem._sync_beta()
+                self._graph.replay()
+                return
+            if self._eager_steps >= self.GRAPH_WARMUP:
+                self._capture(mem)
+                return
+            self._eager_steps += 1
+        self._learn_eager(mem, _target_raw_normals, _unit_uniforms)
+
+    def _capture(self, mem):
+        dev = self.device
+        mem._sync_beta()
+        torch.cuda.synchronize(dev)
+        self._gstream = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self._gstream):
+            self._learn_eager(mem, None, None)
+        self._graph, self._graph_mem = graph, mem
+        torch.cuda.synchronize(dev)     # the capture itself does not execute the step
+        self._graph.replay()
+
+    def _learn_eager(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
         if device_mem:
@@ -211,15 +249,27 @@ class Agent:
         L.check(self._lib, self._lib.rb_learner_learn(
             self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
             nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), self._stream()))   # agent.py:66-96
+        overlap = device_mem and os.environ.get("RB_SIDE_STREAMS", "0") == "1"   # opt-in, see learner.hip
+        if overlap:
+            # agent.py:100 without the D2H sync: the new priorities depend only on (idxs, loss), so the sum-tree
+            # update runs on a side stream next to clip + Adam; the main stream re-joins before the next sample.
+            main = torch.cuda.current_stream(self.device)
+            self._ev_loss.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_loss)
+                mem.update_priorities(idxs, self._loss)
+                self._ev_upd.record(self._side)
         if self._world > 1:   # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
             rdist.average_gradients(self.grads)
         L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
                                                           self._stream()))                # agent.py:97
         self.optimiser.step()                                                              # agent.py:98
-        if device_mem:
+        if overlap:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_upd)
+        elif device_mem:
             mem.update_priorities(idxs, self._loss)                                        # agent.py:100, no D2H
         else:
-            mem.update_priorities(idxs, self._loss.detach().cpu().numpy())
+            mem.update_priorities(idxs, self._loss.detach().cpu().numpy())                 # agent.py:100
 
     def update_target_net(self):
         """agent.py:102-103."""

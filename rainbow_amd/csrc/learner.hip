@@ -133,9 +133,14 @@ struct rb_learner {
   float* support;       // [Z]
   float* zero_noise;    // [n_noise] zeros (eval mode, model.py:46)
   float* norm_part;     // [1024]
+  unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   int hs, xs, ws[3];    // split counts
   int fast_fc;          // streamed 16x16x4 noisy-linear kernels usable (alignment preconditions hold)
   int fast_conv;        // LDS-resident conv kernels usable (history <= 4, standard channel counts)
+  // backward fork/join: weight-gradient kernels run on side streams next to the input-gradient chain
+  int use_side;
+  hipStream_t side[2];
+  hipEvent_t ev[8];
   float gamma_n;        // float32(discount ** n)        agent.py:79
   float delta_z;        // float32((Vmax - Vmin)/(Z-1))   agent.py:19,82
 };
@@ -148,7 +153,11 @@ struct NoiseMap {
   int64_t seg_begin[9];   // prefix of draw counts: hv_in, hv_out, ha_in, ha_out, zv_in, zv_out, za_in, za_out
   int64_t dst[8];         // destination offsets in the noise buffer
 };
-__global__ __launch_bounds__(256) void k_noise(float* noise, const float* raw, NoiseMap map, uint64_t seed, uint64_t epoch) {
+// The Philox epoch is DEVICE state (ctr[0]) so that a captured hipGraph draws fresh noise on every replay; the
+// last workgroup to finish (ticket in ctr[1]) advances it — every block has read the epoch before it takes a ticket.
+__global__ __launch_bounds__(256) void k_noise(float* noise, const float* raw, NoiseMap map, uint64_t seed,
+                                                unsigned long long* ctr) {
+  const uint64_t epoch = ctr[0];
   const int64_t total = map.seg_begin[8];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float x;
@@ -168,6 +177,15 @@ __global__ __launch_bounds__(256) void k_noise(float* noise, const float* raw, N
 #pragma unroll
     for (int q = 1; q < 8; ++q) seg += (i >= map.seg_begin[q]) ? 1 : 0;
     noise[map.dst[seg] + (i - map.seg_begin[seg])] = f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long ticket = atomicAdd(&ctr[1], 1ull);
+    if (ticket == (unsigned long long)gridDim.x - 1ull) {
+      ctr[0] = epoch + 1;
+      ctr[1] = 0;
+    }
   }
 }
 
@@ -605,15 +623,17 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
   return RB_OK;
 }
 
+// mode bit 0: weight/bias grads (+ split reduction); bit 1: data grads into dact[layer-1]
 template <class G>
-static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream) {
+static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream, int mode) {
   const Layout& L = l->L;
   const ConvLayer& c = L.conv[layer];
   const int K = c.K();
   float* gw = l->grads + L.conv_w[layer];
   float* gb = l->grads + L.conv_b[layer];
   const int splits = l->ws[layer];
-  if (layer == 0) {
+  if (!(mode & 1)) {
+  } else if (layer == 0) {
     ConvDwProb<G, true> p;
     p.B = L.B; p.cin = c.cin; p.cout = c.cout; p.splits = splits;
     p.dy = l->dact[0]; p.x_u8 = states; p.x_f = nullptr; p.part = l->dw_part[0];
@@ -626,11 +646,14 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     RB_LAUNCH((k_gemm<2, 2, ConvDwProb<G, false>>),
               dim3((unsigned)rb_div_up(c.cout, 64), (unsigned)rb_div_up(K + 1, 64), (unsigned)splits), dim3(256), stream, p);
   }
-  RB_LAUNCH_CHECK();
-  const int64_t total = (int64_t)c.cout * (K + 1);
-  RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 64)), dim3(64), stream,
-            (const float*)l->dw_part[layer], splits, c.cout, K, gw, gb);
-  RB_LAUNCH_CHECK();
+  if (mode & 1) {
+    RB_LAUNCH_CHECK();
+    const int64_t total = (int64_t)c.cout * (K + 1);
+    RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 64)), dim3(64), stream,
+              (const float*)l->dw_part[layer], splits, c.cout, K, gw, gb);
+    RB_LAUNCH_CHECK();
+  }
+  if (!(mode & 2)) return RB_OK;
   if constexpr (G::IH == 84) {
     // first-layer geometries never need a data gradient (frames are not differentiated)
   } else if (layer > 0 && l->fast_conv) {
@@ -661,13 +684,13 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   return RB_OK;
 }
 
-static int conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream) {
+static int conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream, int mode) {
   const ConvLayer& c = l->L.conv[layer];
-  if (c.ks == 8) return launch_conv_bwd<GeomC1>(l, layer, states, stream);
-  if (c.ks == 4) return launch_conv_bwd<GeomC2>(l, layer, states, stream);
-  if (c.ks == 3) return launch_conv_bwd<GeomC3>(l, layer, states, stream);
-  if (c.ih == 84) return launch_conv_bwd<GeomD1>(l, layer, states, stream);
-  return launch_conv_bwd<GeomD2>(l, layer, states, stream);
+  if (c.ks == 8) return launch_conv_bwd<GeomC1>(l, layer, states, stream, mode);
+  if (c.ks == 4) return launch_conv_bwd<GeomC2>(l, layer, states, stream, mode);
+  if (c.ks == 3) return launch_conv_bwd<GeomC3>(l, layer, states, stream, mode);
+  if (c.ih == 84) return launch_conv_bwd<GeomD1>(l, layer, states, stream, mode);
+  return launch_conv_bwd<GeomD2>(l, layer, states, stream, mode);
 }
 
 // torch.linspace(start, end, steps) float32 semantics (agent.py:18): step = (end-start)/(steps-1);
@@ -770,6 +793,11 @@ int rb_learner_destroy(rb_learner_t* l) {
   for (float** p : owned)
     if (*p) (void)hipFree(*p);
   if (l->a_star) (void)hipFree(l->a_star);
+  if (l->noise_ctr) (void)hipFree(l->noise_ctr);
+  if (l->use_side) {
+    for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
+    for (int i = 0; i < 8; ++i) if (l->ev[i]) (void)hipEventDestroy(l->ev[i]);
+  }
   delete l;
   return RB_OK;
 }
@@ -837,7 +865,19 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->support, (int64_t)L.Z);
   RB_ALLOC(l->zero_noise, L.n_noise);
   RB_ALLOC(l->norm_part, 1024);
+  RB_ALLOC(l->noise_ctr, 4);
 #undef RB_ALLOC
+  RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
+  {
+    // measured on MI355X (gpurun_out/ab.log, round 1): cross-stream fork/join costs more than the overlap buys at
+    // batch 32 (eager 357 -> 380 us, graph 364 -> 430 us), so the side streams are opt-in.
+    const char* want_side = getenv("RB_SIDE_STREAMS");
+    l->use_side = (want_side && want_side[0] == '1') ? 1 : 0;
+    if (l->use_side) {
+      for (int i = 0; i < 2; ++i) RB_HIP_TRY(hipStreamCreateWithFlags(&l->side[i], hipStreamNonBlocking));
+      for (int i = 0; i < 8; ++i) RB_HIP_TRY(hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming));
+    }
+  }
   float sup[RB_MAX_ATOMS];
   linspace_f32(cfg->v_min, cfg->v_max, L.Z, sup);
   RB_HIP_TRY(hipMemcpy(l->support, sup, L.Z * sizeof(float), hipMemcpyHostToDevice));
@@ -857,9 +897,8 @@ int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_norm
   map.seg_begin[0] = 0;
   for (int i = 0; i < 8; ++i) { map.seg_begin[i + 1] = map.seg_begin[i] + counts[i]; map.dst[i] = dst[i]; }
   float* noise = which == 0 ? l->n_online : l->n_target;
-  const uint64_t epoch = ++l->noise_epoch;
   RB_LAUNCH(k_noise, dim3((unsigned)rb_div_up(map.seg_begin[8], 256)), dim3(256), stream, noise, raw_normals_dev, map,
-            l->seed, epoch);
+            l->seed, l->noise_ctr);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }
@@ -898,9 +937,23 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
             l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
   RB_LAUNCH_CHECK();
 
-  // ---- backward (online net, images [0,B))
+  // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
+  // critical path; every weight-gradient kernel only feeds the optimiser, so those are forked onto two side
+  // streams (events below; captured as parallel graph branches under stream capture) and joined at the end.
+  const bool side = l->use_side && l->fast_fc;
+  hipStream_t s_fc = side ? l->side[0] : stream;     // fc weight grads
+  hipStream_t s_cv = side ? l->side[1] : stream;     // conv weight grads
+  int ev_i = 0;
+  auto fork = [&](hipStream_t to) -> int {
+    if (!side) return RB_OK;
+    RB_HIP_TRY(hipEventRecord(l->ev[ev_i], stream));
+    RB_HIP_TRY(hipStreamWaitEvent(to, l->ev[ev_i], 0));
+    ++ev_i;
+    return RB_OK;
+  };
   const float* feat = l->act[L.nconv - 1];
   if (l->fast_fc) {
+    if ((rc = fork(s_fc)) != RB_OK) return rc;
     {   // fc_z weight + bias grads
       NlDwArgs a;
       a.dy = l->dlogits; a.x = l->h; a.ldy = L.NZ; a.ldx = 2 * L.H; a.M = B; a.K = L.H; a.n_prob = 2;
@@ -909,7 +962,7 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
       a.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
       a.g_mu = l->grads + L.z_mu; a.g_sigma = l->grads + L.z_sigma; a.g_bmu = l->grads + L.z_bmu;
       a.g_bsigma = l->grads + L.z_bsigma; a.eout = on.z_eout; a.ein = on.z_ein;
-      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.H, 256), (unsigned)(vt + at)), dim3(256), stream, a);
+      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.H, 256), (unsigned)(vt + at)), dim3(256), s_fc, a);
       RB_LAUNCH_CHECK();
     }
     {   // fc_z input grads + hidden ReLU mask -> dh
@@ -922,6 +975,7 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
       RB_LAUNCH(k_nl_dx, dim3((unsigned)rb_div_up(L.H, 64), 1, 2 * (unsigned)rb_div_up(B, 64)), dim3(256), stream, a);
       RB_LAUNCH_CHECK();
     }
+    if ((rc = fork(s_fc)) != RB_OK) return rc;
     {   // fc_h weight + bias grads
       NlDwArgs a;
       a.dy = l->dh; a.x = feat; a.ldy = 2 * L.H; a.ldx = L.F; a.M = B; a.K = L.F; a.n_prob = 2;
@@ -930,7 +984,7 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
       a.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
       a.g_mu = l->grads + L.h_mu; a.g_sigma = l->grads + L.h_sigma; a.g_bmu = l->grads + L.h_bmu;
       a.g_bsigma = l->grads + L.h_bsigma; a.eout = on.h_eout; a.ein = on.h_ein;
-      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.F, 256), (unsigned)(2 * ht)), dim3(256), stream, a);
+      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.F, 256), (unsigned)(2 * ht)), dim3(256), s_fc, a);
       RB_LAUNCH_CHECK();
     }
     {   // fc_h input grads, split over the 2H reduction rows -> partials -> ReLU-masked dfeat
@@ -989,8 +1043,15 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
   }
   }
   for (int layer = L.nconv - 1; layer >= 0; --layer) {
-    rc = conv_bwd(l, layer, states_dev, stream);
-    if (rc != RB_OK) return rc;
+    if ((rc = fork(s_cv)) != RB_OK) return rc;                        // dact[layer] is final on the main stream
+    if ((rc = conv_bwd(l, layer, states_dev, s_cv, 1)) != RB_OK) return rc;       // weight grads: side stream
+    if (layer > 0 && (rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;   // data grads: main
+  }
+  if (side) {   // join
+    RB_HIP_TRY(hipEventRecord(l->ev[6], s_fc));
+    RB_HIP_TRY(hipEventRecord(l->ev[7], s_cv));
+    RB_HIP_TRY(hipStreamWaitEvent(stream, l->ev[6], 0));
+    RB_HIP_TRY(hipStreamWaitEvent(stream, l->ev[7], 0));
   }
   return RB_OK;
 }

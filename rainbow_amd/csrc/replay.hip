@@ -38,6 +38,7 @@ struct rb_replay {
   int32_t* win;         // [max_batch][h+n] ring index of each window slot, -1 = blank
   float* scaling_dev;
   int32_t max_batch;
+  const float* neg_beta_dev;   // optional device-resident -beta (graph replay: no by-value argument may change)
   // host mirror of the deterministic part of the header
   int64_t host_index;
   int32_t host_full;
@@ -287,8 +288,8 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
 // ReplayMemory.sample on device (memory.py:124-155).  ONE workgroup, thread i = sample i
 // (batch <= 1024).  The rejection loop (memory.py:128-132) runs inside the kernel so the
 // steady-state learn step has no host round trip.
-__global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, float neg_beta_f32,
-                                                  const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
+__global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
+                                                  const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
                                                   float* weights_out) {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
   const bool active = i < batch;
   const int64_t C = v.capacity;
   const int h = v.history, n = v.n;
+  const float neg_beta_f32 = neg_beta_ptr ? *neg_beta_ptr : neg_beta_arg;
 
   const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
   for (int t = i; t < n_cached; t += (int)blockDim.x) s_top[t] = v.tree[t];
@@ -587,6 +589,7 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   r->tree_len = r->tree_start + capacity;
   for (int k = 0; k < multi_step; ++k) r->scaling[k] = (float)pow(discount, (double)k);  // memory.py:101
   r->max_batch = 1024;
+  r->neg_beta_dev = nullptr;
   r->host_index = 0; r->host_full = 0;
   r->tree = nullptr; r->frames = nullptr; r->timestep = nullptr; r->action = nullptr; r->reward = nullptr;
   r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr;
@@ -710,6 +713,12 @@ int rb_replay_append_batch(rb_replay_t* r, const uint8_t* frames_dev, const int3
   return RB_OK;
 }
 
+int rb_replay_set_beta_source(rb_replay_t* r, const float* neg_beta_dev) {
+  RB_REQUIRE(r != nullptr, "rb_replay_set_beta_source: NULL handle");
+  r->neg_beta_dev = neg_beta_dev;
+  return RB_OK;
+}
+
 int rb_replay_find(rb_replay_t* r, const double* values_dev, int32_t n, float* probs_dev, int64_t* data_idx_dev,
                    int64_t* tree_idx_dev, rb_stream_t stream) {
   RB_REQUIRE(r && values_dev && probs_dev && data_idx_dev && tree_idx_dev, "rb_replay_find: NULL argument");
@@ -733,7 +742,7 @@ int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, cons
   if (threads < 256) threads = 256;   // enough lanes to stage the 16 KB tree top into LDS in one sweep
   // weights ** -beta: python float exponent is cast to float32 by numpy (NEP 50 weak scalar)
   const float neg_beta = (float)(-priority_weight);
-  RB_LAUNCH(k_sample, dim3(1), dim3(threads), stream, v, batch, neg_beta, unit_uniforms_dev, max_attempts, r->seed,
+  RB_LAUNCH(k_sample, dim3(1), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
             r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev);
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {

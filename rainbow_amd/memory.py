@@ -68,6 +68,18 @@ class ReplayMemory:
         self.transitions = _TransitionsView(self)
         self._out = {}
         self.current_idx = 0
+        self._init_beta_source()
+
+    def _init_beta_source(self):
+        # -beta lives in HBM so a captured hipGraph sees main.py:161's annealing (by-value kernel arguments freeze)
+        self._neg_beta_dev = torch.full((1,), -float(self.priority_weight), dtype=torch.float32, device=self.device)
+        self._neg_beta_val = float(self.priority_weight)
+        L.check(self._lib, self._lib.rb_replay_set_beta_source(self._h, self._neg_beta_dev.data_ptr()))
+
+    def _sync_beta(self):
+        if float(self.priority_weight) != self._neg_beta_val:
+            self._neg_beta_val = float(self.priority_weight)
+            self._neg_beta_dev.fill_(-self._neg_beta_val)     # float32(-beta): NEP-50 weak scalar, memory.py:153
 
     # ------------------------------------------------------------------ plumbing
     def __del__(self):
@@ -133,6 +145,8 @@ class ReplayMemory:
         returns f32[B], nonterminals f32[B], weights f32[B]).  Asynchronous.  unit_uniforms (float64 device
         tensor [attempts,B]) injects the sampler's random numbers for parity tests."""
         o = self._buffers(batch_size)
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_beta()
         uu_ptr, attempts = None, self.MAX_ATTEMPTS
         if unit_uniforms is not None:
             self._uu = unit_uniforms.to(device=self.device, dtype=torch.float64).contiguous()
@@ -221,7 +235,8 @@ class ReplayMemory:
                     header=bytes(hdr))
 
     def __getstate__(self):
-        st = {k: v for k, v in self.__dict__.items() if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd")}
+        st = {k: v for k, v in self.__dict__.items()
+              if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev", "_neg_beta_val")}
         st["device"] = str(self.device)
         st["_dump"] = self._dump()
         return st
@@ -245,4 +260,5 @@ class ReplayMemory:
         L.check(self._lib, self._lib.rb_copy_to_device(b.header_dev, hdr.ctypes.data, hdr.nbytes, self._stream()))
         self.transitions = _TransitionsView(self)
         self._out = {}
+        self._init_beta_source()
         self._header()   # resynchronise the library's host mirror of index/full

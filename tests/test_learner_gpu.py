@@ -157,3 +157,40 @@ def test_compat_path_with_foreign_replay(hip):
     agent.learn(fm)
     assert isinstance(fm.got[1], np.ndarray) and fm.got[1].shape == (6,) and np.all(np.isfinite(fm.got[1]))
     assert np.all(fm.got[1] > 0)
+
+
+def test_graph_replay_matches_eager(hip, monkeypatch):
+    """Agent.learn captured into a hipGraph must follow the eager trajectory (same device Philox streams)."""
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+
+    def run(graph):
+        monkeypatch.setenv("RAINBOW_AMD_GRAPH", "1" if graph else "0")
+        args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
+        env = types.SimpleNamespace(action_space=lambda: 4)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        agent = Agent(args, env)
+        mem = ReplayMemory(args, 2048, seed=17)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        rs = np.random.RandomState(1)
+        for _ in range(2):
+            mem.append_batch(torch.randint(0, 256, (1500, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
+                             rs.randint(0, 4, 1500), rs.choice([-1.0, 0.0, 1.0], size=1500), rs.random_sample(1500) < 0.01)
+        losses = []
+        for k in range(12):
+            mem.priority_weight = min(1.0, 0.4 + 0.05 * k)      # annealed beta must reach the captured sampler
+            agent.reset_noise()
+            agent.learn(mem)
+            losses.append(agent._loss.clone())
+            if k == 6:
+                agent.update_target_net()
+        torch.cuda.synchronize()
+        assert (agent._graph is not None) == graph
+        return torch.stack(losses).cpu().numpy(), agent.params.detach().cpu().numpy(), mem._grab("tree")
+
+    le, pe, te = run(False)
+    lg, pg, tg = run(True)
+    np.testing.assert_allclose(lg, le, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pg, pe, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tg, te, rtol=1e-4)
