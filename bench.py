@@ -90,14 +90,11 @@ def kernel_table(cfg):
     wh = 2 * H * F * 4                      # one of mu / sigma of the fused hidden layer, bytes
     return {
         # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident
-        "FcHFwdProb": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4, unit="GB/s"),
+        "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4, unit="GB/s"),
         # hidden layer weight grads: writes d_mu + d_sigma once
-        "FcHDwProb": dict(bound="hbm", work=2 * wh + B * (F + 2 * H) * 4, unit="GB/s"),
+        "fc_h_dw": dict(bound="hbm", work=2 * wh + B * (F + 2 * H) * 4, unit="GB/s"),
         # hidden layer input grads: streams mu+sigma of the online net once
-        "FcHDxProb": dict(bound="hbm", work=2 * wh, unit="GB/s"),
-        # first conv forward over 3B images: fp32 MFMA flops
-        "ConvFwdProb<G, true>": dict(bound="mfma", work=2.0 * 3 * B * 400 * 32 * 256 if F == 3136 else 2.0 * 3 * B * 256 * 32 * 100,
-                                     unit="TFLOP/s"),
+        "fc_h_dx": dict(bound="hbm", work=2 * wh, unit="GB/s"),
     }
 
 
@@ -157,11 +154,15 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="pong-canonical-b32", choices=sorted(CONFIGS))
-    ap.add_argument("--roofline-kernel", default="FcHFwdProb")
+    ap.add_argument("--roofline-kernel", default="fc_h_fwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the learn step as one captured hipGraph (no per-kernel HIP-event timing then; measured "
+                         "within 2%% of eager on MI355X, profiles/round1_launch_ab.txt)")
     opt = ap.parse_args()
 
+    os.environ["RAINBOW_AMD_GRAPH"] = "1" if opt.graph else "0"
     import __graft_entry__
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,7 +203,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     ktab = kernel_table(cfg)
-    kname = opt.roofline_kernel if opt.roofline_kernel in ktab else "FcHFwdProb"
+    kname = opt.roofline_kernel if opt.roofline_kernel in ktab else "fc_h_fwd"
     lib.rb_profile_select(kname.encode())
     if world > 1:
         torch.distributed.barrier()
@@ -259,8 +260,12 @@ def main():
                 achieved, peak = k["work"] / avg_s / 1e9, HBM_PEAK_GBS
             else:
                 achieved, peak = k["work"] / avg_s / 1e12, F32_MFMA_PEAK_TF
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")   # rocprofv3 --pmc passes (tools/gpu_pmc.sh), per launch
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": kname, "bound": k["bound"], "achieved": achieved, "peak": peak, "unit": k["unit"],
-                               "frac": achieved / peak, "traffic": None, "avg_us": avg_s * 1e6,
+                               "frac": achieved / peak, "traffic": traffic, "avg_us": avg_s * 1e6,
                                "launches": launches.value, "algorithmic_work_per_launch": k["work"]}
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(cfg)

@@ -282,3 +282,111 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
     }
   }
 }
+
+// ======================================================================= weight gradient ==
+// First-layer weight gradient (the one the generic path is worst at: 12800 reduction positions,
+// u8 operand): part[slice][co][col] = sum_{pos in chunk} dY[img][co][pos] * X[img][c][oy*S+ky][ox*S+kx],
+// slice = (image, chunk of RC output rows); col == K is the bias column (sum of dY).
+// The 8 waves own disjoint 32-wide column tiles of the [32 x K] output, so there is NO cross-wave
+// reduction: each wave runs the full position loop for its tile(s) out of LDS.
+// grid = (chunks per image, cout / 32, images B); block = 512.
+struct ConvLdsDwArgs {
+  int cin, cout;
+  const float* dy;         // [B][cout][P]
+  const uint8_t* x_u8;     // FIRST: states [B][cin][IP]
+  const float* x_f;        // else previous activation [NI][cin][IP], rows [0,B)
+  float* part;             // [B * chunks][cout][K+1]
+};
+
+template <class G, int RC, int KMAX, bool FIRST>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a) {
+  constexpr int PC = RC * G::OH;                      // positions per chunk
+  constexpr int PCP = (PC + 1) / 2 * 2;               // padded to the MFMA k granule
+  constexpr int PR = (RC - 1) * G::S + G::KS;         // input rows per chunk
+  constexpr int PLANE = PR * G::IH;
+  constexpr int CMAX = KMAX / G::KK;
+  __shared__ float s_a[PCP * 33];                     // dY^T: [pos][co]
+  __shared__ float s_patch[CMAX * PLANE];
+  __shared__ int s_poff[PCP];
+
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int img = (int)blockIdx.z, co0 = (int)blockIdx.y * 32, chunk = (int)blockIdx.x;
+  const int cin = a.cin, K = cin * G::KK;
+  const int oy0 = chunk * RC;
+  const int p0 = oy0 * G::OH;
+  int npos = G::P - p0;
+  if (npos > PC) npos = PC;
+  const int iy0 = oy0 * G::S;
+  int rows = G::IH - iy0;
+  if (rows > PR) rows = PR;
+
+  // ---- stage dY^T (zero beyond the chunk), position offsets, input patch
+  for (int e = t; e < 32 * PCP; e += RB_CONV_THREADS) {
+    const int m = e / PCP, p = e - m * PCP;          // p fastest: coalesced along positions
+    float v = 0.0f;
+    if (p < npos && co0 + m < a.cout) v = a.dy[((int64_t)img * a.cout + co0 + m) * G::P + p0 + p];
+    s_a[p * 33 + m] = v;
+  }
+  for (int p = t; p < PCP; p += RB_CONV_THREADS) {
+    const int pc = p < npos ? p : npos - 1;
+    s_poff[p] = (pc / G::OH) * G::S * G::IH + (pc % G::OH) * G::S;
+  }
+  if (FIRST) {
+    const uint8_t* base = a.x_u8 + (int64_t)img * cin * G::IP;
+    const int per_c = rows * G::IH;
+    const int v16 = per_c >> 4;
+    for (int e = t; e < cin * v16; e += RB_CONV_THREADS) {
+      const int c = e / v16, q = e - c * v16;
+      const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)c * G::IP + iy0 * G::IH + q * 16);
+      float* d = s_patch + c * PLANE + q * 16;
+      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+    }
+    const int tail = per_c & 15;
+    for (int e = t; e < cin * tail; e += RB_CONV_THREADS) {
+      const int c = e / tail, q = (v16 << 4) + e % tail;
+      s_patch[c * PLANE + q] = rb_unit(base[(int64_t)c * G::IP + iy0 * G::IH + q]);
+    }
+  } else {
+    const float* base = a.x_f + (int64_t)img * cin * G::IP;
+    const int per_c = rows * G::IH;
+    for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
+      const int c = e / per_c, q = e - c * per_c;
+      s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+    }
+  }
+  __syncthreads();
+
+  float* out = a.part + (((int64_t)img * gridDim.x + chunk) * a.cout) * (K + 1);
+  // bias column: sum over the chunk's positions, fixed order
+  if (t < 32 && co0 + t < a.cout) {
+    float acc = 0.0f;
+    for (int p = 0; p < npos; ++p) acc += s_a[p * 33 + t];
+    out[(int64_t)(co0 + t) * (K + 1) + K] = acc;
+  }
+  const int ntiles = (K + 31) / 32;
+  const int kh = lane >> 5, nl = lane & 31;
+  for (int tile = wave; tile < ntiles; tile += RB_CONV_WAVES) {   // wave-uniform
+    int col = tile * 32 + nl;
+    const bool cv = col < K;
+    if (!cv) col = K - 1;
+    const int c = col / G::KK, r = col % G::KK;
+    const int koff = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
+    rb_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll 4
+    for (int p = 0; p < PCP; p += 2) {
+      const int pp = p + kh;
+      acc = rb_mfma32(s_a[pp * 33 + nl], s_patch[koff + s_poff[pp]], acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = co0 + rb_mfma_row(q, lane);
+      if (cv && m < a.cout) out[(int64_t)m * (K + 1) + tile * 32 + nl] = acc[q];
+    }
+  }
+}

@@ -576,7 +576,8 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     a.chunks_per_split = (int)rb_div_up(chunks, l->hs);
     const int splits = (int)rb_div_up(chunks, a.chunks_per_split);
     a.out = l->hpart; a.ld_out = 2 * L.H; a.rows_total = NI; a.add_bias = 0; a.relu = 0;
-    RB_LAUNCH(k_nl_fwd, dim3((unsigned)(2 * tiles_per_stream), (unsigned)splits, 2 * mchunks), dim3(64 * RB_NL_FWD_WAVES), stream, a);
+    RB_LAUNCH_T("fc_h_fwd:k_nl_fwd", k_nl_fwd, dim3((unsigned)(2 * tiles_per_stream), (unsigned)splits, 2 * mchunks),
+                dim3(64 * RB_NL_FWD_WAVES), stream, a);
     RB_LAUNCH_CHECK();
     const int64_t total = (int64_t)NI * 2 * L.H;
     RB_LAUNCH(k_fc_h_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->hpart, splits, NI,
@@ -593,7 +594,7 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt};
     z.chunks_per_split = L.H / 16;
     z.out = l->logits; z.ld_out = L.NZ; z.rows_total = NI; z.add_bias = 1; z.relu = 0;
-    RB_LAUNCH(k_nl_fwd, dim3((unsigned)(vt + at), 1, 2 * mchunks), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd", k_nl_fwd, dim3((unsigned)(vt + at), 1, 2 * mchunks), dim3(64 * RB_NL_FWD_WAVES), stream, z);
     RB_LAUNCH_CHECK();
     return RB_OK;
   }
@@ -632,7 +633,17 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   float* gw = l->grads + L.conv_w[layer];
   float* gb = l->grads + L.conv_b[layer];
   const int splits = l->ws[layer];
+  int lds_slices = 0;
   if (!(mode & 1)) {
+  } else if (layer == 0 && l->fast_conv && (G::IH == 84)) {
+    constexpr int RC = G::KS == 8 ? 5 : 4;            // output rows per chunk (100 / 64 positions)
+    constexpr int KMAXW = 4 * G::KK;
+    constexpr int CHUNKS = (G::OH + RC - 1) / RC;
+    ConvLdsDwArgs a;
+    a.cin = c.cin; a.cout = c.cout; a.dy = l->dact[0]; a.x_u8 = states; a.x_f = nullptr; a.part = l->dw_part[0];
+    RB_LAUNCH((k_conv_dw_lds<G, RC, KMAXW, true>), dim3((unsigned)CHUNKS, (unsigned)rb_div_up(c.cout, 32), (unsigned)L.B),
+              dim3(RB_CONV_THREADS), stream, a);
+    lds_slices = L.B * CHUNKS;
   } else if (layer == 0) {
     ConvDwProb<G, true> p;
     p.B = L.B; p.cin = c.cin; p.cout = c.cout; p.splits = splits;
@@ -650,7 +661,7 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     RB_LAUNCH_CHECK();
     const int64_t total = (int64_t)c.cout * (K + 1);
     RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 64)), dim3(64), stream,
-              (const float*)l->dw_part[layer], splits, c.cout, K, gw, gb);
+              (const float*)l->dw_part[layer], lds_slices ? lds_slices : splits, c.cout, K, gw, gb);
     RB_LAUNCH_CHECK();
   }
   if (!(mode & 2)) return RB_OK;
@@ -850,7 +861,11 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     const ConvLayer& c = L.conv[i];
     RB_ALLOC(l->act[i], (int64_t)NI * c.cout * c.P());
     RB_ALLOC(l->dact[i], (int64_t)B * c.cout * c.P());
-    RB_ALLOC(l->dw_part[i], (int64_t)l->ws[i] * c.cout * (c.K() + 1));
+    {
+      int64_t slices = l->ws[i];
+      if (i == 0 && slices < (int64_t)B * 5) slices = (int64_t)B * 5;   // LDS first-layer kernel: B images x <=5 row chunks
+      RB_ALLOC(l->dw_part[i], slices * c.cout * (c.K() + 1));
+    }
   }
   RB_ALLOC(l->hpart, (int64_t)l->hs * NI * 2 * L.H);
   RB_ALLOC(l->h, (int64_t)NI * 2 * L.H);
@@ -984,7 +999,7 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
       a.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
       a.g_mu = l->grads + L.h_mu; a.g_sigma = l->grads + L.h_sigma; a.g_bmu = l->grads + L.h_bmu;
       a.g_bsigma = l->grads + L.h_bsigma; a.eout = on.h_eout; a.ein = on.h_ein;
-      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.F, 256), (unsigned)(2 * ht)), dim3(256), s_fc, a);
+      RB_LAUNCH_T("fc_h_dw:k_nl_dw", k_nl_dw, dim3((unsigned)rb_div_up(L.F, 256), (unsigned)(2 * ht)), dim3(256), s_fc, a);
       RB_LAUNCH_CHECK();
     }
     {   // fc_h input grads, split over the 2H reduction rows -> partials -> ReLU-masked dfeat
@@ -995,8 +1010,8 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
       a.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
       const int splits = (int)rb_div_up(2 * L.H, a.rows_per_split);
       a.out = l->dfeat_part; a.ld_out = L.F; a.mask_src = nullptr;
-      RB_LAUNCH(k_nl_dx, dim3((unsigned)rb_div_up(L.F, 64), (unsigned)splits, (unsigned)rb_div_up(B, 64)), dim3(256),
-                stream, a);
+      RB_LAUNCH_T("fc_h_dx:k_nl_dx", k_nl_dx, dim3((unsigned)rb_div_up(L.F, 64), (unsigned)splits, (unsigned)rb_div_up(B, 64)),
+                  dim3(256), stream, a);
       RB_LAUNCH_CHECK();
       const int64_t total = (int64_t)B * L.F;
       RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,

@@ -11,6 +11,7 @@
 #include "hipemu.h"
 #define RB_LAUNCH(kern, grid, block, stream, ...) \
   hipemu::launch([&]() { kern(__VA_ARGS__); }, (grid), (block))
+#define RB_LAUNCH_T(tag, kern, grid, block, stream, ...) RB_LAUNCH(kern, grid, block, stream, __VA_ARGS__)
 #else
 #include <hip/hip_runtime.h>
 typedef float rb_f32x16 __attribute__((ext_vector_type(16)));
@@ -19,12 +20,14 @@ typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
 bool rb_prof_begin(const char* kernel_expr, hipStream_t stream);
 void rb_prof_end(hipStream_t stream);
 extern int g_rb_prof_on;
-#define RB_LAUNCH(kern, grid, block, stream, ...)                                               \
+// RB_LAUNCH_T: same, with an explicit profiling tag (a kernel used for several layers gets one tag per layer)
+#define RB_LAUNCH_T(tag, kern, grid, block, stream, ...)                                        \
   do {                                                                                          \
-    const bool rb_pf_ = g_rb_prof_on && rb_prof_begin(#kern, (hipStream_t)(stream));            \
+    const bool rb_pf_ = g_rb_prof_on && rb_prof_begin(tag, (hipStream_t)(stream));              \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__);           \
     if (rb_pf_) rb_prof_end((hipStream_t)(stream));                                             \
   } while (0)
+#define RB_LAUNCH(kern, grid, block, stream, ...) RB_LAUNCH_T(#kern, kern, grid, block, stream, __VA_ARGS__)
 #endif
 
 #include <stdint.h>
