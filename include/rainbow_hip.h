@@ -82,6 +82,8 @@ typedef struct {
   int32_t* timestep_dev;  int32_t* action_dev;
   float* reward_dev;      uint8_t* nonterminal_dev;
   rb_replay_header_t* header_dev;
+  int32_t* window_dev;    /* [max_batch][history+multi_step] ring index of every window slot of the last sample */
+  int32_t window_len;
 } rb_replay_buffers_t;
 
 /* ReplayMemory.__init__ + SegmentTree.__init__  (memory.py:92-102, 13-20).
@@ -202,6 +204,16 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
                      const int64_t* actions_dev, const float* returns_dev,
                      const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
                      rb_stream_t stream);
+
+/* Same step, zero-copy input: instead of gathered stacks the first conv layer reads its frames
+ * straight from the replay ring (rb_replay_buffers_t.frames_dev) through the window table the
+ * last rb_replay_sample wrote (rb_replay_buffers_t.window_dev: [B][history+multi_step] ring
+ * indices, -1 = blanked frame, memory.py:112-121).  Call rb_replay_sample with states_dev =
+ * next_states_dev = NULL to skip the gather.                                                 */
+int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const int32_t* windows_dev,
+                             int32_t window_len, const int64_t* actions_dev, const float* returns_dev,
+                             const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
+                             rb_stream_t stream);
 
 /* clip_grad_norm_ (agent.py:97): global L2 norm of grads_dev, scale in place by
  * max_norm/(norm+1e-6) when that is < 1.  norm_dev (f32[1], may be NULL) gets ||g||. */

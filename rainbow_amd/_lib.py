@@ -23,7 +23,8 @@ class ReplayHeader(C.Structure):
 class ReplayBuffers(C.Structure):
     _fields_ = [("sum_tree_dev", c_void_p), ("tree_len", c_int64), ("tree_start", c_int64),
                 ("frames_dev", c_void_p), ("timestep_dev", c_void_p), ("action_dev", c_void_p),
-                ("reward_dev", c_void_p), ("nonterminal_dev", c_void_p), ("header_dev", c_void_p)]
+                ("reward_dev", c_void_p), ("nonterminal_dev", c_void_p), ("header_dev", c_void_p),
+                ("window_dev", c_void_p), ("window_len", c_int32)]
 
 
 class LearnerConfig(C.Structure):
@@ -69,6 +70,8 @@ SIGNATURES = {
     "rb_learner_act": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "rb_learner_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
+    "rb_learner_learn_windows": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
     "rb_learner_clip_grad": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rb_learner_sync_target": (c_int, [c_void_p, c_void_p]),
     "rb_learner_debug_read": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),

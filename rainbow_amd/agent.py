@@ -232,8 +232,9 @@ class Agent:
     def _learn_eager(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
+        zero_copy = device_mem and self._cfg.history <= 4 and mem.history == self._cfg.history and mem.n == self.n
         if device_mem:
-            o = mem.sample_device(B, _unit_uniforms)                                       # agent.py:63
+            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy)                 # agent.py:63
             idxs, states, next_states = o["tree_idxs"], o["states"], o["next_states"]
             actions, returns, nonterminals, weights = o["actions"], o["returns"], o["nonterminals"], o["weights"]
         else:   # foreign replay with the reference's API: float32 /255 states come back; re-quantise (exact for k/255)
@@ -246,9 +247,15 @@ class Agent:
             nonterminals = nonterminals.to(device=d, dtype=torch.float32).reshape(B).contiguous()
             weights = weights.to(device=d, dtype=torch.float32).contiguous()
         self._reset_target_noise(_target_raw_normals)                                      # agent.py:74
-        L.check(self._lib, self._lib.rb_learner_learn(
-            self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
-            nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), self._stream()))   # agent.py:66-96
+        if zero_copy:   # conv1 reads the frames straight out of the HBM ring: no stack gather at all
+            frames, windows, wlen = mem.frame_source()
+            L.check(self._lib, self._lib.rb_learner_learn_windows(
+                self._h, frames, windows, wlen, actions.data_ptr(), returns.data_ptr(), nonterminals.data_ptr(),
+                weights.data_ptr(), self._loss.data_ptr(), self._stream()))
+        else:
+            L.check(self._lib, self._lib.rb_learner_learn(
+                self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
+                nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), self._stream()))   # agent.py:66-96
         overlap = device_mem and os.environ.get("RB_SIDE_STREAMS", "0") == "1"   # opt-in, see learner.hip
         if overlap:
             # agent.py:100 without the D2H sync: the new priorities depend only on (idxs, loss), so the sum-tree

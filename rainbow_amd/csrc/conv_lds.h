@@ -23,6 +23,7 @@ struct ConvLdsFwdArgs {
   ImgSrc src;                // FIRST layer input
   const float* in_f;         // later layers: [img][cin][IP]
   float* out;                // [img][cout][P]
+  int ablate;                // profiling experiments only (RB_ABLATE): 1 skip MFMA loop, 2 skip staging, 4 skip reduction
 };
 
 // ---- shared staging helpers ------------------------------------------------------------------
@@ -35,16 +36,46 @@ __device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, i
     for (int m = wave; m < 32; m += nw)
       for (int k = lane; k < K; k += 64) s_w[k * 33 + m] = m < rows_valid ? w[(int64_t)(row0 + m) * K + k] : 0.0f;
   } else {
+    // all of a wave's float4 loads are issued before the first LDS store (one memory round trip, not one per row)
     const int kq = K >> 2;
-    for (int m = wave; m < 32; m += nw) {
-      const float* src = w + (int64_t)(row0 + m) * K;
-      for (int q = lane; q < kq; q += 64) {
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (m < rows_valid) v = rb_ld4(src + 4 * q);
-        s_w[(4 * q + 0) * 33 + m] = v.x;
-        s_w[(4 * q + 1) * 33 + m] = v.y;
-        s_w[(4 * q + 2) * 33 + m] = v.z;
-        s_w[(4 * q + 3) * 33 + m] = v.w;
+    constexpr int RMAX = 4, QMAX = 4;                // 32 rows / 8 waves, K <= 1024
+    float4 v[RMAX][QMAX];
+    if (nw * RMAX >= 32 && kq <= 64 * QMAX) {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const int m = wave + r * nw;
+#pragma unroll
+        for (int i = 0; i < QMAX; ++i) {
+          const int q = lane + 64 * i;
+          v[r][i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (m < rows_valid && q < kq) v[r][i] = rb_ld4(w + (int64_t)(row0 + m) * K + 4 * q);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const int m = wave + r * nw;
+#pragma unroll
+        for (int i = 0; i < QMAX; ++i) {
+          const int q = lane + 64 * i;
+          if (m < 32 && q < kq) {
+            s_w[(4 * q + 0) * 33 + m] = v[r][i].x;
+            s_w[(4 * q + 1) * 33 + m] = v[r][i].y;
+            s_w[(4 * q + 2) * 33 + m] = v[r][i].z;
+            s_w[(4 * q + 3) * 33 + m] = v[r][i].w;
+          }
+        }
+      }
+    } else {
+      for (int m = wave; m < 32; m += nw) {
+        const float* src = w + (int64_t)(row0 + m) * K;
+        for (int q = lane; q < kq; q += 64) {
+          float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (m < rows_valid) x = rb_ld4(src + 4 * q);
+          s_w[(4 * q + 0) * 33 + m] = x.x;
+          s_w[(4 * q + 1) * 33 + m] = x.y;
+          s_w[(4 * q + 2) * 33 + m] = x.z;
+          s_w[(4 * q + 3) * 33 + m] = x.w;
+        }
       }
     }
   }
@@ -82,46 +113,86 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
   if (rows > PR) rows = PR;
 
   // ---- stage: weights (transposed), k -> patch offset table, input patch
+  if (!(a.ablate & 2))
   rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
     const int c = kc / G::KK, r = kc % G::KK;
     s_koff[k] = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
   }
-  if (FIRST && !a.src.f32) {
-    const uint8_t* base = img < a.src.B ? a.src.u8_states + (int64_t)img * cin * G::IP
-                                        : a.src.u8_next + (int64_t)((img - a.src.B) % a.src.B) * cin * G::IP;
+  if (a.ablate & 2) {
+  } else if (FIRST && !a.src.f32) {
     const int per_c = rows * G::IH;                 // bytes per channel, 16-byte multiple for the frame geometries
     const int v16 = per_c >> 4;
-    for (int e = t; e < cin * v16; e += RB_CONV_THREADS) {
-      const int c = e / v16, q = e - c * v16;
-      const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)c * G::IP + iy0 * G::IH + q * 16);
-      float* d = s_patch + c * PLANE + q * 16;
-      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    const int total16 = cin * v16;
+    for (int e0 = 0; e0 < total16; e0 += 2 * RB_CONV_THREADS) {        // both 16-byte loads of a thread are in flight together
+      uint4 raw[2];
 #pragma unroll
-      for (int wd = 0; wd < 4; ++wd)
+      for (int i = 0; i < 2; ++i) {
+        const int e = e0 + i * RB_CONV_THREADS + t;
+        raw[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+          if (fp) raw[i] = *reinterpret_cast<const uint4*>(fp + iy0 * G::IH + q * 16);
+        }
+      }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+      for (int i = 0; i < 2; ++i) {
+        const int e = e0 + i * RB_CONV_THREADS + t;
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          float* d = s_patch + c * PLANE + q * 16;
+          const unsigned wds[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+        }
+      }
     }
     for (int e = t; e < cin * (per_c & 15); e += RB_CONV_THREADS) {   // (no tail for 84-wide frames; kept for generality)
       const int c = e / (per_c & 15), q = (v16 << 4) + e % (per_c & 15);
-      s_patch[c * PLANE + q] = rb_unit(base[(int64_t)c * G::IP + iy0 * G::IH + q]);
+      const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+      s_patch[c * PLANE + q] = fp ? rb_unit(fp[iy0 * G::IH + q]) : 0.0f;
     }
   } else {
     const float* base = FIRST ? a.src.f32 + (int64_t)img * cin * G::IP : a.in_f + (int64_t)img * cin * G::IP;
     const int per_c = rows * G::IH;
     if ((per_c & 3) == 0 && ((iy0 * G::IH) & 3) == 0 && (G::IP & 3) == 0) {
       const int v4 = per_c >> 2;
-      for (int e = t; e < cin * v4; e += RB_CONV_THREADS) {
-        const int c = e / v4, q = e - c * v4;
-        const float4 v = rb_ld4(base + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
-        float* d = s_patch + c * PLANE + q * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      const int total = cin * v4;
+      for (int e0 = 0; e0 < total; e0 += 8 * RB_CONV_THREADS) {       // 8 float4 loads in flight per thread
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          if (e < total) { const int c = e / v4, q = e - c * v4; v[i] = rb_ld4(base + (int64_t)c * G::IP + iy0 * G::IH + q * 4); }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          if (e < total) {
+            const int c = e / v4, q = e - c * v4;
+            float* d = s_patch + c * PLANE + q * 4;
+            d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+          }
+        }
       }
     } else {
-      for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
-        const int c = e / per_c, q = e - c * per_c;
-        s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+      const int total = cin * per_c;
+      for (int e0 = 0; e0 < total; e0 += 12 * RB_CONV_THREADS) {      // 12 scalar loads in flight per thread
+        float v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          if (e < total) { const int c = e / per_c, q = e - c * per_c; v[i] = base[(int64_t)c * G::IP + iy0 * G::IH + q]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          if (e < total) { const int c = e / per_c, q = e - c * per_c; s_patch[c * PLANE + q] = v[i]; }
+        }
       }
     }
   }
@@ -143,8 +214,9 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
   const int kh = lane >> 5, ml = lane & 31;
+  const int KWE = (a.ablate & 1) ? 0 : KW;
 #pragma unroll 4
-  for (int kk = 0; kk < KW; kk += 2) {                // LDS reads of the unrolled steps are issued ahead of the MFMAs
+  for (int kk = 0; kk < KWE; kk += 2) {               // LDS reads of the unrolled steps are issued ahead of the MFMAs
     const int k = kb + kk + kh;                       // < KPAD
     const float av = s_w[k * 33 + ml];
     const int ko = s_koff[k];
@@ -160,8 +232,10 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
   for (int idx = t; idx < NT * 16 * 64; idx += RB_CONV_THREADS) {
     const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
     float v = s_all[((0 * NT + nt) * 16 + r) * 64 + l];
+    if (!(a.ablate & 4)) {
 #pragma unroll
     for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
+    }
     const int m = cout0 + rb_mfma_row(r, l);
     const int p = p0 + nt * 32 + (l & 31);
     if (m < a.cout && p < G::P && p < p0 + 32 * NT)
@@ -209,7 +283,13 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   {
     const float* src = a.dy + (int64_t)img * a.cout * G::P;
     const int n = a.cout * G::P;
-    for (int e = t; e < n; e += RB_CONV_THREADS) s_dy[e] = src[e];
+    for (int e0 = 0; e0 < n; e0 += 12 * RB_CONV_THREADS) {             // 12 loads in flight per thread
+      float v[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { const int e = e0 + i * RB_CONV_THREADS + t; if (e < n) v[i] = src[e]; }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { const int e = e0 + i * RB_CONV_THREADS + t; if (e < n) s_dy[e] = v[i]; }
+    }
   }
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
@@ -221,11 +301,26 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   {   // phase slab of the weights, transposed to [k' = (co,ty,tx)][c]; thread = (c, co mod 16), no divisions
     const int m = t & 31;
     const bool cv = c0 + m < a.cin;
-    for (int co = t >> 5; co < a.cout; co += RB_CONV_THREADS / 32) {
-      const float* src = a.w + ((int64_t)co * a.cin + c0 + (cv ? m : 0)) * G::KK;
-      for (int ty = 0; ty < nty; ++ty)
-        for (int tx = 0; tx < ntx; ++tx)
-          s_w[(co * taps + ty * ntx + tx) * 33 + m] = cv ? src[(py + ty * G::S) * G::KS + px + tx * G::S] : 0.0f;
+    constexpr int TAPS_MAX = TMAX * TMAX, CO_STEP = RB_CONV_THREADS / 32, CO_IT = (COUT + CO_STEP - 1) / CO_STEP;
+    float v[CO_IT][TAPS_MAX];                          // every load of this thread is issued before the first LDS store
+#pragma unroll
+    for (int it = 0; it < CO_IT; ++it) {
+      const int co = (t >> 5) + it * CO_STEP;
+      const float* src = a.w + ((int64_t)(co < a.cout ? co : 0) * a.cin + c0 + (cv ? m : 0)) * G::KK;
+#pragma unroll
+      for (int ty = 0; ty < TMAX; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TMAX; ++tx)
+          v[it][ty * TMAX + tx] = (cv && co < a.cout && ty < nty && tx < ntx) ? src[(py + ty * G::S) * G::KS + px + tx * G::S] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < CO_IT; ++it) {
+      const int co = (t >> 5) + it * CO_STEP;
+#pragma unroll
+      for (int ty = 0; ty < TMAX; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TMAX; ++tx)
+          if (co < a.cout && ty < nty && tx < ntx) s_w[(co * taps + ty * ntx + tx) * 33 + m] = v[it][ty * TMAX + tx];
     }
     for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
   }
@@ -293,7 +388,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 struct ConvLdsDwArgs {
   int cin, cout;
   const float* dy;         // [B][cout][P]
-  const uint8_t* x_u8;     // FIRST: states [B][cin][IP]
+  ImgSrc src;              // FIRST: the state stacks (images [0,B))
   const float* x_f;        // else previous activation [NI][cin][IP], rows [0,B)
   float* part;             // [B * chunks][cout][K+1]
 };
@@ -332,23 +427,40 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a
     s_poff[p] = (pc / G::OH) * G::S * G::IH + (pc % G::OH) * G::S;
   }
   if (FIRST) {
-    const uint8_t* base = a.x_u8 + (int64_t)img * cin * G::IP;
     const int per_c = rows * G::IH;
     const int v16 = per_c >> 4;
-    for (int e = t; e < cin * v16; e += RB_CONV_THREADS) {
-      const int c = e / v16, q = e - c * v16;
-      const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)c * G::IP + iy0 * G::IH + q * 16);
-      float* d = s_patch + c * PLANE + q * 16;
-      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    const int total16 = cin * v16;
+    for (int e0 = 0; e0 < total16; e0 += 2 * RB_CONV_THREADS) {        // both 16-byte loads of a thread are in flight together
+      uint4 raw[2];
 #pragma unroll
-      for (int wd = 0; wd < 4; ++wd)
+      for (int i = 0; i < 2; ++i) {
+        const int e = e0 + i * RB_CONV_THREADS + t;
+        raw[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+          if (fp) raw[i] = *reinterpret_cast<const uint4*>(fp + iy0 * G::IH + q * 16);
+        }
+      }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+      for (int i = 0; i < 2; ++i) {
+        const int e = e0 + i * RB_CONV_THREADS + t;
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          float* d = s_patch + c * PLANE + q * 16;
+          const unsigned wds[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+        }
+      }
     }
     const int tail = per_c & 15;
     for (int e = t; e < cin * tail; e += RB_CONV_THREADS) {
       const int c = e / tail, q = (v16 << 4) + e % tail;
-      s_patch[c * PLANE + q] = rb_unit(base[(int64_t)c * G::IP + iy0 * G::IH + q]);
+      const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+      s_patch[c * PLANE + q] = fp ? rb_unit(fp[iy0 * G::IH + q]) : 0.0f;
     }
   } else {
     const float* base = a.x_f + (int64_t)img * cin * G::IP;

@@ -22,6 +22,7 @@
 
 #include <new>
 
+#define RB_HEAD_MAX_NZ 1408   // 3 logit rows of this many floats live in the head kernel's LDS (18 actions x 51 atoms = 969)
 typedef ConvGeom<8, 4, 84, 20> GeomC1;   // model.py:56
 typedef ConvGeom<4, 2, 20, 9> GeomC2;    // model.py:57
 typedef ConvGeom<3, 1, 9, 7> GeomC3;     // model.py:58
@@ -53,6 +54,7 @@ static int make_layout(const rb_learner_config_t* c, Layout* L) {
   RB_REQUIRE(c->batch >= 1 && c->batch <= 1024, "batch must be in [1,1024]");
   RB_REQUIRE(c->atoms >= 2 && c->atoms <= 256, "atoms must be in [2,256]");
   RB_REQUIRE(c->actions >= 1 && c->actions <= 64, "actions must be in [1,64]");
+  RB_REQUIRE(c->atoms * (c->actions + 1) <= RB_HEAD_MAX_NZ, "atoms*(actions+1) must be <= %d (head kernel LDS rows)", RB_HEAD_MAX_NZ);
   RB_REQUIRE(c->history >= 1 && c->history <= 16, "history must be in [1,16]");
   RB_REQUIRE(c->hidden >= 1 && c->hidden <= 8192, "hidden must be in [1,8192]");
   RB_REQUIRE(c->architecture == 0 || c->architecture == 1, "architecture must be 0 (canonical) or 1 (data-efficient)");
@@ -135,6 +137,8 @@ struct rb_learner {
   float* norm_part;     // [1024]
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   int hs, xs, ws[3];    // split counts
+  int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
+  ImgSrc cur_src;       // input frames of the learn step in flight
   int fast_fc;          // streamed 16x16x4 noisy-linear kernels usable (alignment preconditions hold)
   int fast_conv;        // LDS-resident conv kernels usable (history <= 4, standard channel counts)
   // backward fork/join: weight-gradient kernels run on side streams next to the input-gradient chain
@@ -228,6 +232,35 @@ __global__ __launch_bounds__(256) void k_reduce_conv_dw(const float* part, int s
   }
 }
 
+// all conv layers' split slices in ONE launch (saves two dependent ~5 us launches per step)
+struct ReduceLayer {
+  const float* part;
+  float *gw, *gb;
+  int slices, cout, K;
+  int64_t begin;          // first flat output index of this layer in the fused index space
+};
+struct ReduceAllArgs {
+  ReduceLayer layer[3];
+  int n_layers;
+  int64_t total;
+};
+__global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total) return;
+  int li = 0;
+  if (a.n_layers > 1 && i >= a.layer[1].begin) li = 1;
+  if (a.n_layers > 2 && i >= a.layer[2].begin) li = 2;
+  const ReduceLayer L = a.layer[li];
+  const int64_t j = i - L.begin;
+  const int64_t per = (int64_t)L.cout * (L.K + 1);
+  float acc = 0.0f;
+#pragma unroll 8
+  for (int s = 0; s < L.slices; ++s) acc += L.part[(int64_t)s * per + j];   // independent loads, fixed add order
+  const int co = (int)(j / (L.K + 1)), col = (int)(j % (L.K + 1));
+  if (col < L.K) L.gw[(int64_t)co * L.K + col] = acc;
+  else L.gb[co] = acc;
+}
+
 // ------------------------------------------------------------------------- head --
 // One workgroup (256 threads) per sample b.  Dueling combine (model.py:74-75), log-softmax of
 // the taken action (agent.py:66-67), double-Q argmax on the online net (agent.py:71-73), target
@@ -242,30 +275,18 @@ __device__ __forceinline__ float rb_dueling_q(const float* lg, const float* mean
   return (lg[z] + lg[Z + a * Z + z]) - mean_a[z];
 }
 
-// One WAVE per sample (4 samples per 256-thread workgroup): every reduction over the atoms is a
-// wave64 butterfly, each lane keeps "its" atoms z = lane, lane+64, ... in registers, and only the
-// projection's scatter (atom j lands in bins l_j / u_j) goes through LDS.
+// One 256-thread workgroup per sample.  The three logit rows (3*(Z + A*Z) floats) are pulled into LDS with one
+// coalesced sweep; after that the kernel touches global memory only for its outputs.  Work is spread over the four
+// waves: the A actions of the double-Q selection go round-robin over the waves; then wave 0 does the target
+// softmax + projection inputs while wave 1 does the online log-softmax of the taken action in parallel.  Every
+// reduction over atoms is a wave64 butterfly (each lane owns atoms z = lane, lane+64, ...).
 #define RB_ZI (RB_MAX_ATOMS / 64)
-__global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
-                                               const float* returns, const float* nonterminals, const float* weights,
-                                               const float* support, float v_min, float v_max, float gamma_n,
-                                               float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
-                                               int32_t* a_star_out, float* loss_out, float* dlogits) {
-  __shared__ float s_lo[4][RB_MAX_ATOMS], s_hi[4][RB_MAX_ATOMS];
-  __shared__ int s_l[4][RB_MAX_ATOMS], s_u[4][RB_MAX_ATOMS];
-  const int lane = rb_lane(), wave = rb_wave();
-  const int b_raw = (int)blockIdx.x * 4 + wave;
-  const bool live = b_raw < B;                       // wave-uniform; dead waves compute on sample B-1 and store nothing
-  const int b = live ? b_raw : B - 1;
-  const int NZ = Z + A * Z;
-  const float inv_A = 1.0f;  (void)inv_A;
+#define RB_MAX_NZ RB_HEAD_MAX_NZ
 
-  float sup[RB_ZI];
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = z < Z ? support[z] : 0.0f; }
-
+struct HeadWave {
+  int lane;
   // dueling mean over actions for this lane's atoms: a.mean(1)            model.py:75
-  auto mean_of = [&](const float* lg, float* mean) {
+  __device__ void mean_of(const float* lg, int Z, int A, float* mean) const {
 #pragma unroll
     for (int i = 0; i < RB_ZI; ++i) {
       const int z = lane + 64 * i;
@@ -274,135 +295,162 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
         for (int a = 0; a < A; ++a) acc += lg[Z + a * Z + z];
       mean[i] = acc / (float)A;
     }
-  };
-  // softmax pieces of action a: fills e[i] = exp(q - max) for this lane's atoms, returns the wave-wide sum
-  auto softmax_of = [&](const float* lg, const float* mean, int a, float* e, float* max_out) {
-    float q[RB_ZI];
+  }
+  // e[i] = exp(q - max), qm[i] = q - max for this lane's atoms; returns the wave-wide sum of e
+  __device__ float softmax_of(const float* lg, int Z, const float* mean, int a, float* e, float* qm) const {
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < RB_ZI; ++i) {
       const int z = lane + 64 * i;
-      q[i] = z < Z ? (lg[z] + lg[Z + a * Z + z]) - mean[i] : -INFINITY;   // q = v + a - mean_a(a)
-      mx = fmaxf(mx, q[i]);
+      qm[i] = z < Z ? (lg[z] + lg[Z + a * Z + z]) - mean[i] : -INFINITY;   // q = v + a - mean_a(a)
+      mx = fmaxf(mx, qm[i]);
     }
     mx = rb_wave_max(mx);
     float se = 0.0f;
 #pragma unroll
     for (int i = 0; i < RB_ZI; ++i) {
       const int z = lane + 64 * i;
-      e[i] = z < Z ? expf(q[i] - mx) : 0.0f;
-      q[i] = z < Z ? q[i] - mx : 0.0f;
+      qm[i] = z < Z ? qm[i] - mx : 0.0f;
+      e[i] = z < Z ? expf(qm[i]) : 0.0f;
       se += e[i];
     }
-    *max_out = mx;
     return rb_wave_sum(se);
-  };
+  }
+};
 
-  // ---------------- double-Q selection on online(next_states)   agent.py:71-73
-  const float* lg_n = logits + (int64_t)(B + b) * NZ;
-  float mean[RB_ZI], e[RB_ZI];
-  mean_of(lg_n, mean);
-  int a_star = 0;
-  float best = -INFINITY;
-  for (int a = 0; a < A; ++a) {
-    float mx;
-    const float se = softmax_of(lg_n, mean, a, e, &mx);
+__global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
+                                               const float* returns, const float* nonterminals, const float* weights,
+                                               const float* support, float v_min, float v_max, float gamma_n,
+                                               float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
+                                               int32_t* a_star_out, float* loss_out, float* dlogits, int ablate) {
+  __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
+  __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
+  __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
+  __shared__ float s_ev[RB_MAX_ACTIONS];
+  __shared__ float s_scal[2];                        // sum(m), -loss
+  const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
+  const int b = (int)blockIdx.x;
+  const int NZ = Z + A * Z;
+  for (int i = t; i < NZ; i += 256) {
+    s_lg[0][i] = logits[(int64_t)b * NZ + i];
+    s_lg[1][i] = logits[(int64_t)(B + b) * NZ + i];
+    s_lg[2][i] = logits[(int64_t)(2 * B + b) * NZ + i];
+  }
+  const float R = returns[b], nt = nonterminals[b], wgt = weights[b];
+  const int act = (int)actions[b];
+  __syncthreads();
+  if (ablate & 32) { if (t == 0) loss_out[b] = s_lg[0][0] + R + nt + wgt + (float)act; return; }
+  HeadWave hw;
+  hw.lane = lane;
+  float sup[RB_ZI];
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = z < Z ? support[z] : 0.0f; }
+  float mean[RB_ZI], e[RB_ZI], qm[RB_ZI];
+
+  // ---------------- double-Q selection on online(next_states)   agent.py:71-73   (actions round-robin over waves)
+  hw.mean_of(s_lg[1], Z, A, mean);
+  for (int a = wave; a < ((ablate & 8) ? 0 : A); a += 4) {
+    const float se = hw.softmax_of(s_lg[1], Z, mean, a, e, qm);
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < RB_ZI; ++i) sv += sup[i] * e[i];
     sv = rb_wave_sum(sv);
-    const float ev = sv / se;                                     // sum_z z * p(z)
-    if (ev > best) { best = ev; a_star = a; }                     // argmax, first maximum
+    if (lane == 0) s_ev[a] = sv / se;                             // sum_z z * p(z)
   }
-  if (live && lane == 0) a_star_out[b] = a_star;
-
-  // ---------------- target(next_states)[a*] probabilities        agent.py:75-76
-  const float* lg_t = logits + (int64_t)(2 * B + b) * NZ;
-  mean_of(lg_t, mean);
-  float p[RB_ZI];
+  __syncthreads();
+  int a_star = 0;
   {
-    float mx;
-    const float se = softmax_of(lg_t, mean, a_star, e, &mx);
+    float best = s_ev[0];
+    for (int a = 1; a < A; ++a)
+      if (s_ev[a] > best) { best = s_ev[a]; a_star = a; }         // argmax, first maximum
+  }
+  if (t == 0) a_star_out[b] = a_star;
+
+  if (wave == 0) {
+    // ---------------- target(next_states)[a*] probabilities      agent.py:75-76, projection inputs agent.py:79-86
+    hw.mean_of(s_lg[2], Z, A, mean);
+    const float se = hw.softmax_of(s_lg[2], Z, mean, a_star, e, qm);
 #pragma unroll
     for (int i = 0; i < RB_ZI; ++i) {
       const int z = lane + 64 * i;
-      p[i] = e[i] / se;
-      if (live && z < Z) pns_a_out[(int64_t)b * Z + z] = p[i];
+      if (z < Z) {
+        const float p = e[i] / se;
+        pns_a_out[(int64_t)b * Z + z] = p;
+        float Tz = R + (nt * gamma_n) * sup[i];                   // agent.py:79
+        Tz = fminf(fmaxf(Tz, v_min), v_max);                      // agent.py:80
+        const float bq = (Tz - v_min) / delta_z;                  // agent.py:82
+        int l = (int)floorf(bq), u = (int)ceilf(bq);              // agent.py:83
+        if (u > 0 && l == u) l -= 1;                              // agent.py:85
+        if (l < Z - 1 && l == u) u += 1;                          // agent.py:86
+        s_l[z] = l; s_u[z] = u;
+        s_lo[z] = p * ((float)u - bq);                            // agent.py:91
+        s_hi[z] = p * (bq - (float)l);                            // agent.py:92
+      }
     }
-  }
-
-  // ---------------- C51 projection                               agent.py:79-92
-  const float R = returns[b], nt = nonterminals[b];
+  } else if (wave == 1) {
+    // ---------------- online(states): log p(s_t, a_t)            agent.py:66-67
+    hw.mean_of(s_lg[0], Z, A, mean);
+    const float se = hw.softmax_of(s_lg[0], Z, mean, act, e, qm);
+    const float lse = logf(se);
 #pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) {
-    const int z = lane + 64 * i;
-    if (z < Z) {
-      float Tz = R + (nt * gamma_n) * sup[i];                     // agent.py:79
-      Tz = fminf(fmaxf(Tz, v_min), v_max);                        // agent.py:80
-      const float bq = (Tz - v_min) / delta_z;                    // agent.py:82
-      int l = (int)floorf(bq), u = (int)ceilf(bq);                // agent.py:83
-      if (u > 0 && l == u) l -= 1;                                // agent.py:85
-      if (l < Z - 1 && l == u) u += 1;                            // agent.py:86
-      s_l[wave][z] = l; s_u[wave][z] = u;
-      s_lo[wave][z] = p[i] * ((float)u - bq);                     // agent.py:91
-      s_hi[wave][z] = p[i] * (bq - (float)l);                     // agent.py:92
+    for (int i = 0; i < RB_ZI; ++i) {
+      const int z = lane + 64 * i;
+      if (z < Z) {
+        const float lp = qm[i] - lse;                             // log_softmax = (q - max) - log(sum exp(q - max))
+        s_logp[z] = lp;
+        log_ps_a_out[(int64_t)b * Z + z] = lp;
+      }
     }
   }
   __syncthreads();
-  float m[RB_ZI];
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) {
-    const int k = lane + 64 * i;
-    float acc = 0.0f;
-    if (k < Z) {
-      for (int j = 0; j < Z; ++j)                                 // first index_add_ (l bins), in j order
-        if (s_l[wave][j] == k) acc += s_lo[wave][j];
-      for (int j = 0; j < Z; ++j)                                 // then the u bins
-        if (s_u[wave][j] == k) acc += s_hi[wave][j];
-      if (live) m_out[(int64_t)b * Z + k] = acc;
+  // ---------------- scatter into atom bins in the reference's accumulation order   agent.py:89-92
+  // b is monotone in the atom index (support increasing, nt*gamma^n >= 0), so equal l (and equal u) form
+  // contiguous runs: the first atom of a run owns its bin and adds the run left to right — exactly the order of
+  // the reference's first index_add_ (all l bins, j ascending) followed by the second (u bins) on the same m.
+  for (int k = t; k < Z; k += 256) s_m[k] = 0.0f;
+  __syncthreads();
+  if (!(ablate & 16)) {
+    for (int j = t; j < Z; j += 256) {
+      const int key = s_l[j];
+      if (j == 0 || s_l[j - 1] != key) {
+        float acc = 0.0f;
+        for (int jj = j; jj < Z && s_l[jj] == key; ++jj) acc += s_lo[jj];
+        s_m[key] = acc;
+      }
     }
-    m[i] = acc;
-  }
-
-  // ---------------- online(states): log p(s_t, a_t), loss        agent.py:66-67,94
-  const float* lg_s = logits + (int64_t)b * NZ;
-  const int act = (int)actions[b];
-  mean_of(lg_s, mean);
-  float mx;
-  const float se = softmax_of(lg_s, mean, act, e, &mx);
-  const float lse = logf(se);
-  float logp[RB_ZI];
-  float part_loss = 0.0f, part_m = 0.0f;
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) {
-    const int z = lane + 64 * i;
-    // log_softmax = (q - max) - log(sum exp(q - max))
-    const float qm = z < Z ? ((lg_s[z] + lg_s[Z + act * Z + z]) - mean[i]) - mx : 0.0f;
-    logp[i] = qm - lse;
-    if (z < Z) {
-      if (live) log_ps_a_out[(int64_t)b * Z + z] = logp[i];
-      part_loss += m[i] * logp[i];
-      part_m += m[i];
+    __syncthreads();
+    for (int j = t; j < Z; j += 256) {
+      const int key = s_u[j];
+      if (j == 0 || s_u[j - 1] != key) {
+        float acc = s_m[key];
+        for (int jj = j; jj < Z && s_u[jj] == key; ++jj) acc += s_hi[jj];
+        s_m[key] = acc;
+      }
     }
   }
-  const float dot = rb_wave_sum(part_loss);
-  const float msum = rb_wave_sum(part_m);
-  if (live && lane == 0) loss_out[b] = -dot;                       // agent.py:94
-
+  __syncthreads();
+  for (int k = t; k < Z; k += 256) m_out[(int64_t)b * Z + k] = s_m[k];
+  if (wave == 0) {                                                // loss = -sum m * log p   agent.py:94
+    float pl = 0.0f, pm = 0.0f;
+    for (int z = lane; z < Z; z += 64) { pl += s_m[z] * s_logp[z]; pm += s_m[z]; }
+    pl = rb_wave_sum(pl);
+    pm = rb_wave_sum(pm);
+    if (lane == 0) { s_scal[0] = pm; s_scal[1] = pl; loss_out[b] = -pl; }
+  }
+  __syncthreads();
   // ---------------- backward of mean(w * loss) to the logits     agent.py:96
   // d/dq[z] = (w/B) * (p[z] * sum(m) - m[z]) on the taken action; dueling adjoint:
   // dv[z] = g[z] ; da[a'][z] = (delta(a',act) - 1/A) * g[z]
-  const float coef = weights[b] / (float)B;
+  const float coef = wgt / (float)B;
+  const float msum = s_scal[0];
   float* dl = dlogits + (int64_t)b * NZ;
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) {
-    const int z = lane + 64 * i;
-    if (live && z < Z) {
-      const float g = coef * (expf(logp[i]) * msum - m[i]);
-      dl[z] = g;
-      const float ga = g / (float)A;
-      for (int a = 0; a < A; ++a) dl[Z + a * Z + z] = (a == act ? g : 0.0f) - ga;
-    }
+  for (int i = t; i < NZ; i += 256) {
+    const int z = i < Z ? i : (i - Z) % Z;
+    const float g = coef * (expf(s_logp[z]) * msum - s_m[z]);
+    float o;
+    if (i < Z) o = g;
+    else o = ((i - Z) / Z == act ? g : 0.0f) - g / (float)A;
+    dl[i] = o;
   }
 }
 
@@ -515,6 +563,10 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.cin = c.cin; a.cout = c.cout; a.n_on = n_on;
   a.w[0] = on.conv_w[layer]; a.w[1] = tg.conv_w[layer]; a.bias[0] = on.conv_b[layer]; a.bias[1] = tg.conv_b[layer];
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
+  {
+    static const char* ab = getenv("RB_ABLATE");
+    a.ablate = ab ? atoi(ab) : 0;
+  }
   RB_LAUNCH((k_conv_fwd_lds<G, NT, PR, KMAX, FIRST>),
             dim3((unsigned)rb_div_up(G::P, 32 * NT), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
             dim3(RB_CONV_THREADS), stream, a);
@@ -640,7 +692,7 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     constexpr int KMAXW = 4 * G::KK;
     constexpr int CHUNKS = (G::OH + RC - 1) / RC;
     ConvLdsDwArgs a;
-    a.cin = c.cin; a.cout = c.cout; a.dy = l->dact[0]; a.x_u8 = states; a.x_f = nullptr; a.part = l->dw_part[0];
+    a.cin = c.cin; a.cout = c.cout; a.dy = l->dact[0]; a.src = l->cur_src; a.x_f = nullptr; a.part = l->dw_part[0];
     RB_LAUNCH((k_conv_dw_lds<G, RC, KMAXW, true>), dim3((unsigned)CHUNKS, (unsigned)rb_div_up(c.cout, 32), (unsigned)L.B),
               dim3(RB_CONV_THREADS), stream, a);
     lds_slices = L.B * CHUNKS;
@@ -659,10 +711,8 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   }
   if (mode & 1) {
     RB_LAUNCH_CHECK();
-    const int64_t total = (int64_t)c.cout * (K + 1);
-    RB_LAUNCH(k_reduce_conv_dw, dim3((unsigned)rb_div_up(total, 64)), dim3(64), stream,
-              (const float*)l->dw_part[layer], lds_slices ? lds_slices : splits, c.cout, K, gw, gb);
-    RB_LAUNCH_CHECK();
+    l->dw_slices[layer] = lds_slices ? lds_slices : splits;   // summed by k_reduce_conv_dw_all after the last layer
+    (void)gw; (void)gb;
   }
   if (!(mode & 2)) return RB_OK;
   if constexpr (G::IH == 84) {
@@ -923,7 +973,8 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
   RB_REQUIRE(l && state_dev, "rb_learner_act: NULL argument");
   const Layout& L = l->L;
   ImgSrc src;
-  src.u8_states = nullptr; src.u8_next = nullptr; src.f32 = state_dev; src.B = 1;
+  memset(&src, 0, sizeof(src));
+  src.f32 = state_dev; src.B = 1;
   const NetPtrs on = net_ptrs(L, l->p_online, noisy ? l->n_online : l->zero_noise);
   int rc = forward(l, 1, 0, src, on, on, (hipStream_t)stream);
   if (rc != RB_OK) return rc;
@@ -933,23 +984,51 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
   return RB_OK;
 }
 
+static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_dev, const int64_t* actions_dev,
+                      const float* returns_dev, const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
+                      hipStream_t stream);
+
 int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* next_states_dev,
                      const int64_t* actions_dev, const float* returns_dev, const float* nonterminals_dev,
                      const float* weights_dev, float* loss_dev, rb_stream_t stream_) {
   RB_REQUIRE(l && states_dev && next_states_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev && loss_dev,
              "rb_learner_learn: NULL argument");
-  hipStream_t stream = (hipStream_t)stream_;
+  ImgSrc src;
+  memset(&src, 0, sizeof(src));
+  src.u8_states = states_dev; src.u8_next = next_states_dev; src.B = l->L.B;
+  return learn_impl(l, src, states_dev, actions_dev, returns_dev, nonterminals_dev, weights_dev, loss_dev, (hipStream_t)stream_);
+}
+
+int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const int32_t* windows_dev, int32_t window_len,
+                             const int64_t* actions_dev, const float* returns_dev, const float* nonterminals_dev,
+                             const float* weights_dev, float* loss_dev, rb_stream_t stream_) {
+  RB_REQUIRE(l && frames_dev && windows_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev && loss_dev,
+             "rb_learner_learn_windows: NULL argument");
+  RB_REQUIRE(window_len == l->L.hist + l->cfg.multi_step, "rb_learner_learn_windows: window_len must be history + multi_step");
+  if (!l->fast_conv) {
+    rb_set_error("rb_learner_learn_windows: zero-copy frames need the LDS conv kernels (history <= 4); gather the stacks and "
+                 "call rb_learner_learn instead");
+    return RB_ERR_STATE;
+  }
+  ImgSrc src;
+  memset(&src, 0, sizeof(src));
+  src.B = l->L.B; src.ring = frames_dev; src.win = windows_dev; src.win_len = window_len; src.n_step = l->cfg.multi_step;
+  return learn_impl(l, src, nullptr, actions_dev, returns_dev, nonterminals_dev, weights_dev, loss_dev, (hipStream_t)stream_);
+}
+
+static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_dev, const int64_t* actions_dev,
+                      const float* returns_dev, const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
+                      hipStream_t stream) {
   const Layout& L = l->L;
   const int B = L.B;
-  ImgSrc src;
-  src.u8_states = states_dev; src.u8_next = next_states_dev; src.f32 = nullptr; src.B = B;
+  l->cur_src = src;
   const NetPtrs on = net_ptrs(L, l->p_online, l->n_online);
   const NetPtrs tg = net_ptrs(L, l->p_target, l->n_target);
   int rc = forward(l, 2 * B, B, src, on, tg, stream);
   if (rc != RB_OK) return rc;
-  RB_LAUNCH(k_head, dim3((unsigned)rb_div_up(B, 4)), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
+  RB_LAUNCH(k_head, dim3((unsigned)B), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, getenv("RB_ABLATE") ? atoi(getenv("RB_ABLATE")) : 0);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
@@ -1061,6 +1140,19 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
     if ((rc = fork(s_cv)) != RB_OK) return rc;                        // dact[layer] is final on the main stream
     if ((rc = conv_bwd(l, layer, states_dev, s_cv, 1)) != RB_OK) return rc;       // weight grads: side stream
     if (layer > 0 && (rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;   // data grads: main
+  }
+  {   // one fixed-order reduction of every conv layer's split slices into the gradient buffer
+    ReduceAllArgs ra;
+    int64_t off = 0;
+    for (int layer = 0; layer < L.nconv; ++layer) {
+      const ConvLayer& c = L.conv[layer];
+      ra.layer[layer] = ReduceLayer{l->dw_part[layer], l->grads + L.conv_w[layer], l->grads + L.conv_b[layer],
+                                    l->dw_slices[layer], c.cout, c.K(), off};
+      off += (int64_t)c.cout * (c.K() + 1);
+    }
+    ra.n_layers = L.nconv; ra.total = off;
+    RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(off, 64)), dim3(64), s_cv, ra);
+    RB_LAUNCH_CHECK();
   }
   if (side) {   // join
     RB_HIP_TRY(hipEventRecord(l->ev[6], s_fc));

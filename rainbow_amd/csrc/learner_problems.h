@@ -36,7 +36,24 @@ struct ImgSrc {
   const uint8_t* u8_next;         // [B][cin][84*84]   images [B,2B) and [2B,3B)
   const float* f32;               // act(): [n][cin][84*84] already in [0,1]
   int B;
+  // zero-copy mode: frames are read straight from the replay ring through the sampler's window table
+  // (memory.py:112-121: slot c of the state stack, slot n+c of the next-state stack, -1 = blanked frame)
+  const uint8_t* ring;            // [capacity][84*84] or NULL
+  const int32_t* win;             // [B][win_len]
+  int win_len, n_step;
 };
+
+// frame (img, channel c) as a u8 pointer, or nullptr for a blanked frame
+__device__ __forceinline__ const uint8_t* rb_frame_ptr(const ImgSrc& s, int img, int c, int cin, int ip) {
+  if (s.ring) {
+    const int sample = img < s.B ? img : (img - s.B) % s.B;
+    const int slot = img < s.B ? c : s.n_step + c;
+    const int32_t idx = s.win[(int64_t)sample * s.win_len + slot];
+    return idx < 0 ? nullptr : s.ring + (int64_t)idx * ip;
+  }
+  const uint8_t* base = img < s.B ? s.u8_states + (int64_t)img * cin * ip : s.u8_next + (int64_t)((img - s.B) % s.B) * cin * ip;
+  return base + (int64_t)c * ip;
+}
 
 struct NetPtrs {
   const float* conv_w[3];

@@ -647,6 +647,7 @@ int rb_replay_buffers(rb_replay_t* r, rb_replay_buffers_t* o) {
   o->sum_tree_dev = r->tree; o->tree_len = r->tree_len; o->tree_start = r->tree_start;
   o->frames_dev = r->frames; o->timestep_dev = r->timestep; o->action_dev = r->action;
   o->reward_dev = r->reward; o->nonterminal_dev = r->nonterminal; o->header_dev = r->hdr;
+  o->window_dev = r->win; o->window_len = r->history + r->n;
   return RB_OK;
 }
 

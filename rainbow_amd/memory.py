@@ -140,10 +140,18 @@ class ReplayMemory:
                                                             rw_d.data_ptr(), nt_d.data_ptr(), n, self._stream()))
         torch.cuda.current_stream(d).synchronize()   # the temporaries above must outlive the kernels
 
-    def sample_device(self, batch_size, unit_uniforms=None):
+    def frame_source(self):
+        """(frames_ptr, windows_ptr, window_len): lets the learner read frames straight from the ring (zero-copy)."""
+        if not hasattr(self, "_bufs"):
+            self._bufs = L.ReplayBuffers()
+            L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(self._bufs)))
+        return self._bufs.frames_dev, self._bufs.window_dev, int(self._bufs.window_len)
+
+    def sample_device(self, batch_size, unit_uniforms=None, gather=True):
         """Device-resident batch: dict(tree_idxs i64[B], states u8[B,h,84,84], next_states u8, actions i64[B],
         returns f32[B], nonterminals f32[B], weights f32[B]).  Asynchronous.  unit_uniforms (float64 device
-        tensor [attempts,B]) injects the sampler's random numbers for parity tests."""
+        tensor [attempts,B]) injects the sampler's random numbers for parity tests.  gather=False skips the
+        frame-stack copies (states/next_states are then stale): the consumer reads the ring via frame_source()."""
         o = self._buffers(batch_size)
         if not torch.cuda.is_current_stream_capturing():
             self._sync_beta()
@@ -153,7 +161,8 @@ class ReplayMemory:
             uu_ptr, attempts = self._uu.data_ptr(), int(self._uu.shape[0])
         L.check(self._lib, self._lib.rb_replay_sample(
             self._h, int(batch_size), float(self.priority_weight), uu_ptr, attempts, o["tree_idxs"].data_ptr(),
-            o["states"].data_ptr(), o["next_states"].data_ptr(), o["actions"].data_ptr(), o["returns"].data_ptr(),
+            o["states"].data_ptr() if gather else None, o["next_states"].data_ptr() if gather else None,
+            o["actions"].data_ptr(), o["returns"].data_ptr(),
             o["nonterminals"].data_ptr(), o["weights"].data_ptr(), self._stream()))
         return o
 
@@ -236,7 +245,7 @@ class ReplayMemory:
 
     def __getstate__(self):
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev", "_neg_beta_val")}
+              if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev", "_neg_beta_val", "_bufs")}
         st["device"] = str(self.device)
         st["_dump"] = self._dump()
         return st

@@ -42,3 +42,43 @@ def test_unit_conversion_is_exact():
     r = (np.float64(-255.0) * q.astype(np.float64) + x.astype(np.float64)).astype(np.float32)
     q2 = (r.astype(np.float64) * np.float64(inv) + q.astype(np.float64)).astype(np.float32)
     assert np.array_equal(q2, x / np.float32(255))
+
+
+def test_zero_copy_windows_equals_gathered_stacks(emu):
+    """rb_learner_learn_windows (conv1 reads the replay ring through the sampler's window table) must give
+    bit-identical loss and gradients to rb_learner_learn on the gathered stacks, incl. blanked frames."""
+    import ctypes as C
+    from cabi_adapter import CAbiReplayAdapter
+    from rainbow_amd import _lib as L
+    name = "dataeff"
+    c = scenarios.LEARN_CONFIGS[name]
+    B, h, n = c["batch"], c["history"], c["multi_step"]
+    mem = NumpyMem()
+    rp = CAbiReplayAdapter(emu, mem, 512, h, n, c["discount"], 0.5)
+    rs = np.random.RandomState(3)
+    for _ in range(600):
+        rp.append(scenarios.synth_state(rs, h, 0), int(rs.randint(0, c["actions"])), float(rs.choice([-1.0, 0.0, 1.0])),
+                  bool(rs.random_sample() < 0.1))
+    out = rp.sample(B, rs.random_sample((32, B)), 0.5)
+    assert (out["states"].reshape(B, h, -1).max(axis=2) == 0).any(), "scenario must contain a blanked frame"
+    ad = CAbiLearnAdapter(emu, mem, name)
+    ad.load(O.init_params(ad_cfg := O.Config(**c), 1), O.init_params(ad_cfg, 2))
+    draws = O.noise_draw_count(ad_cfg)
+    ad.reset_noise_online(rs.randn(draws).astype(np.float32))
+    raw_tg = mem.upload(rs.randn(draws).astype(np.float32))
+    L.check(emu, emu.rb_learner_reset_noise(ad.h, 1, mem.ptr(raw_tg), None))
+    bufs = {k: mem.upload(v) for k, v in dict(states=out["states"], next_states=out["next_states"], actions=out["actions"],
+                                               returns=out["returns"], nonterminals=out["nonterminals"].reshape(B),
+                                               weights=out["weights"]).items()}
+    loss_a, loss_b = mem.empty((B,), np.float32), mem.empty((B,), np.float32)
+    L.check(emu, emu.rb_learner_learn(ad.h, mem.ptr(bufs["states"]), mem.ptr(bufs["next_states"]), mem.ptr(bufs["actions"]),
+                                      mem.ptr(bufs["returns"]), mem.ptr(bufs["nonterminals"]), mem.ptr(bufs["weights"]),
+                                      mem.ptr(loss_a), None))
+    grads_a = ad.grads.copy()
+    ad.grads[:] = 0
+    L.check(emu, emu.rb_learner_learn_windows(ad.h, rp.bufs.frames_dev, rp.bufs.window_dev, rp.bufs.window_len,
+                                              mem.ptr(bufs["actions"]), mem.ptr(bufs["returns"]), mem.ptr(bufs["nonterminals"]),
+                                              mem.ptr(bufs["weights"]), mem.ptr(loss_b), None))
+    assert np.array_equal(loss_a, loss_b)
+    assert np.array_equal(grads_a, ad.grads)
+    ad.close(); rp.close()
