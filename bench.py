@@ -92,9 +92,8 @@ def kernel_table(cfg):
         # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident
         "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4, unit="GB/s"),
         # hidden layer weight grads: writes d_mu + d_sigma once
-        "fc_h_dw": dict(bound="hbm", work=2 * wh + B * (F + 2 * H) * 4, unit="GB/s"),
-        # hidden layer input grads: streams mu+sigma of the online net once
-        "fc_h_dx": dict(bound="hbm", work=2 * wh, unit="GB/s"),
+        # hidden layer backward (one launch): streams mu+sigma of the online net once (dX), writes d_mu + d_sigma once (dW)
+        "fc_h_bwd": dict(bound="hbm", work=2 * wh + 2 * wh + B * (F + 2 * H) * 4, unit="GB/s"),
     }
 
 

@@ -183,7 +183,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
 int rb_learner_destroy(rb_learner_t* l);
 
 /* DQN.reset_noise (model.py:82-85, 36-40).  which: 0 online (agent.py:49-50),
- * 1 target (agent.py:74).  raw_normals_dev: NULL = device Philox + Box-Muller;
+ * 1 target (agent.py:74), 2 both in one launch (online first; device RNG only).
+ * raw_normals_dev: NULL = device Philox + Box-Muller;
  * else N(0,1) draws in the reference's order (per layer randn(in) then randn(out);
  * layers fc_h_v, fc_h_a, fc_z_v, fc_z_a) — parity hook.                             */
 int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev,

@@ -89,16 +89,20 @@ class Agent:
 
         self.params.requires_grad_(True)
         self.params.grad = self.grads
-        # capturable: the step counter lives on the device so the whole learn step can be replayed as one hipGraph
+        # hipGraph replay of the whole step is opt-in (RAINBOW_AMD_GRAPH=1): measured within 2 % of eager on MI355X
+        # (the step is GPU-bound, profiles/round1_launch_ab.txt) while capturable Adam costs one extra kernel per step.
+        self._use_graph = os.environ.get("RAINBOW_AMD_GRAPH", "0") == "1"
+        kw = dict(lr=args.learning_rate, eps=args.adam_eps)
+        if self._use_graph:
+            kw["capturable"] = True    # the step counter must live on the device to be replayable
         try:
-            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps, fused=True,
-                                              capturable=True)
+            self.optimiser = torch.optim.Adam([self.params], fused=True, **kw)
         except (TypeError, RuntimeError):
-            self.optimiser = torch.optim.Adam([self.params], lr=args.learning_rate, eps=args.adam_eps, capturable=True)
+            self.optimiser = torch.optim.Adam([self.params], **kw)
         self._graph = None
         self._graph_mem = None
         self._eager_steps = 0
-        self._use_graph = os.environ.get("RAINBOW_AMD_GRAPH", "1") != "0"
+        self._noise_pending = False
         self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
         self._norm = torch.zeros(1, dtype=torch.float32, device=d)
         self._act_out = torch.zeros(1, dtype=torch.int32, device=d)
@@ -167,11 +171,19 @@ class Agent:
     def reset_noise(self, raw_normals=None):
         """agent.py:49-50 (online net only).  raw_normals: optional float32 device tensor of N(0,1) draws in the
         reference's order (parity hook)."""
-        ptr = None
-        if raw_normals is not None:
-            self._raw_on = raw_normals.to(device=self.device, dtype=torch.float32).contiguous()
-            ptr = self._raw_on.data_ptr()
-        L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 0, ptr, self._stream()))
+        if raw_normals is None:
+            # lazily: main.py calls reset_noise() right before learn() every 4th step (main.py:151,164); the draw is
+            # deferred so learn() can resample online + target noise in ONE launch.  act()/evaluate_q() flush it first.
+            self._noise_pending = True
+            return
+        self._noise_pending = False
+        self._raw_on = raw_normals.to(device=self.device, dtype=torch.float32).contiguous()
+        L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 0, self._raw_on.data_ptr(), self._stream()))
+
+    def _flush_noise(self):
+        if self._noise_pending:
+            self._noise_pending = False
+            L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 0, None, self._stream()))
 
     def _reset_target_noise(self, raw_normals=None):
         ptr = None
@@ -181,6 +193,7 @@ class Agent:
         L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 1, ptr, self._stream()))   # agent.py:74
 
     def _forward_single(self, state):
+        self._flush_noise()
         st = state.to(device=self.device, dtype=torch.float32).contiguous()
         L.check(self._lib, self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0,
                                                     self._act_out.data_ptr(), self._q_out.data_ptr(), self._stream()))
@@ -208,6 +221,7 @@ class Agent:
         injected = _target_raw_normals is not None or _unit_uniforms is not None
         if (self._use_graph and not injected and self._world == 1 and isinstance(mem, ReplayMemory)):
             if self._graph is not None and self._graph_mem is mem:
+                self._flush_noise()
                 mem._sync_beta()
                 self._graph.replay()
                 return
@@ -219,6 +233,7 @@ class Agent:
 
     def _capture(self, mem):
         dev = self.device
+        self._flush_noise()
         mem._sync_beta()
         torch.cuda.synchronize(dev)
         self._gstream = torch.cuda.Stream(device=dev)
@@ -246,7 +261,12 @@ class Agent:
             returns = returns.to(device=d, dtype=torch.float32).contiguous()
             nonterminals = nonterminals.to(device=d, dtype=torch.float32).reshape(B).contiguous()
             weights = weights.to(device=d, dtype=torch.float32).contiguous()
-        self._reset_target_noise(_target_raw_normals)                                      # agent.py:74
+        if self._noise_pending and _target_raw_normals is None:
+            self._noise_pending = False      # online (main.py:151) and target (agent.py:74) noise in one launch
+            L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 2, None, self._stream()))
+        else:
+            self._flush_noise()
+            self._reset_target_noise(_target_raw_normals)                                  # agent.py:74
         if zero_copy:   # conv1 reads the frames straight out of the HBM ring: no stack gather at all
             frames, windows, wlen = mem.frame_source()
             L.check(self._lib, self._lib.rb_learner_learn_windows(
@@ -280,6 +300,7 @@ class Agent:
 
     def update_target_net(self):
         """agent.py:102-103."""
+        self._flush_noise()
         L.check(self._lib, self._lib.rb_learner_sync_target(self._h, self._stream()))
 
     def train(self):
@@ -291,6 +312,7 @@ class Agent:
     # ------------------------------------------------------------------ checkpoints (agent.py:26-36,106-107)
     def state_dict(self):
         """Reference-compatible keys: convs.{0,2,4}.{weight,bias}, fc_*.{weight,bias}_{mu,sigma,epsilon}."""
+        self._flush_noise()
         sd = {}
         for name, _off, _shape in self._layout:
             sd[name] = self._view(self.params, name).clone()

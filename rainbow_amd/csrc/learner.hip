@@ -159,9 +159,12 @@ struct NoiseMap {
 };
 // The Philox epoch is DEVICE state (ctr[0]) so that a captured hipGraph draws fresh noise on every replay; the
 // last workgroup to finish (ticket in ctr[1]) advances it — every block has read the epoch before it takes a ticket.
-__global__ __launch_bounds__(256) void k_noise(float* noise, const float* raw, NoiseMap map, uint64_t seed,
+// blockIdx.y selects the net when both are resampled in one launch (noise2 != NULL): online = epoch, target = epoch+1,
+// i.e. exactly the draws two consecutive single-net launches would make.
+__global__ __launch_bounds__(256) void k_noise(float* noise, float* noise2, const float* raw, NoiseMap map, uint64_t seed,
                                                 unsigned long long* ctr) {
-  const uint64_t epoch = ctr[0];
+  const uint64_t epoch = ctr[0] + blockIdx.y;
+  if (blockIdx.y == 1) noise = noise2;
   const int64_t total = map.seg_begin[8];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float x;
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(256) void k_noise(float* noise, const float* raw, N
   if (threadIdx.x == 0) {
     __threadfence();
     const unsigned long long ticket = atomicAdd(&ctr[1], 1ull);
-    if (ticket == (unsigned long long)gridDim.x - 1ull) {
-      ctr[0] = epoch + 1;
+    if (ticket == (unsigned long long)gridDim.x * gridDim.y - 1ull) {
+      ctr[0] = ctr[0] + gridDim.y;
       ctr[1] = 0;
     }
   }
@@ -954,16 +957,18 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
 
 int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_reset_noise: NULL handle");
-  RB_REQUIRE(which == 0 || which == 1, "rb_learner_reset_noise: which must be 0 (online) or 1 (target)");
+  RB_REQUIRE(which >= 0 && which <= 2, "rb_learner_reset_noise: which must be 0 (online), 1 (target) or 2 (both)");
+  RB_REQUIRE(!(which == 2 && raw_normals_dev), "rb_learner_reset_noise: injected normals need one call per net");
   const Layout& L = l->L;
   NoiseMap map;
   const int64_t counts[8] = {L.F, L.H, L.F, L.H, L.H, L.Z, L.H, (int64_t)L.A * L.Z};
   const int64_t dst[8] = {L.h_ein, L.h_eout, L.h_ein + L.F, L.h_eout + L.H, L.z_ein, L.z_eout, L.z_ein + L.H, L.z_eout + L.Z};
   map.seg_begin[0] = 0;
   for (int i = 0; i < 8; ++i) { map.seg_begin[i + 1] = map.seg_begin[i] + counts[i]; map.dst[i] = dst[i]; }
-  float* noise = which == 0 ? l->n_online : l->n_target;
-  RB_LAUNCH(k_noise, dim3((unsigned)rb_div_up(map.seg_begin[8], 256)), dim3(256), stream, noise, raw_normals_dev, map,
-            l->seed, l->noise_ctr);
+  float* noise = which == 1 ? l->n_target : l->n_online;
+  float* noise2 = which == 2 ? l->n_target : nullptr;
+  RB_LAUNCH(k_noise, dim3((unsigned)rb_div_up(map.seg_begin[8], 256), which == 2 ? 2u : 1u), dim3(256), stream, noise, noise2,
+            raw_normals_dev, map, l->seed, l->noise_ctr);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }
@@ -1047,56 +1052,55 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   };
   const float* feat = l->act[L.nconv - 1];
   if (l->fast_fc) {
-    if ((rc = fork(s_fc)) != RB_OK) return rc;
-    {   // fc_z weight + bias grads
-      NlDwArgs a;
-      a.dy = l->dlogits; a.x = l->h; a.ldy = L.NZ; a.ldx = 2 * L.H; a.M = B; a.K = L.H; a.n_prob = 2;
-      const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
-      a.prob[0] = NlDwProblem{0, L.Z, 0, 0, 0};
-      a.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
-      a.g_mu = l->grads + L.z_mu; a.g_sigma = l->grads + L.z_sigma; a.g_bmu = l->grads + L.z_bmu;
-      a.g_bsigma = l->grads + L.z_bsigma; a.eout = on.z_eout; a.ein = on.z_ein;
-      RB_LAUNCH(k_nl_dw, dim3((unsigned)rb_div_up(L.H, 256), (unsigned)(vt + at)), dim3(256), s_fc, a);
-      RB_LAUNCH_CHECK();
+    // ---- output layer: weight/bias grads and (ReLU-masked) input grads in one launch
+    NlDwArgs zw;
+    zw.dy = l->dlogits; zw.x = l->h; zw.ldy = L.NZ; zw.ldx = 2 * L.H; zw.M = B; zw.K = L.H; zw.n_prob = 2;
+    const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
+    zw.prob[0] = NlDwProblem{0, L.Z, 0, 0, 0};
+    zw.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
+    zw.g_mu = l->grads + L.z_mu; zw.g_sigma = l->grads + L.z_sigma; zw.g_bmu = l->grads + L.z_bmu;
+    zw.g_bsigma = l->grads + L.z_bsigma; zw.eout = on.z_eout; zw.ein = on.z_ein;
+    NlDxArgs zx;
+    zx.dy = l->dlogits; zx.ldy = L.NZ; zx.M = B; zx.w = nl_z(on); zx.K = L.H; zx.n_prob = 2;
+    zx.prob[0] = NlDxProblem{0, L.Z, 1 << 30, 0, 0, 0};
+    zx.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
+    zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
+    zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
+    NlBwdGrid zg{(int)rb_div_up(L.H, 256), vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
+    // ---- hidden layer
+    NlDwArgs hw_;
+    hw_.dy = l->dh; hw_.x = feat; hw_.ldy = 2 * L.H; hw_.ldx = L.F; hw_.M = B; hw_.K = L.F; hw_.n_prob = 2;
+    const int ht = (int)rb_div_up(L.H, 16);
+    hw_.prob[0] = NlDwProblem{0, L.H, 0, 0, 0};
+    hw_.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
+    hw_.g_mu = l->grads + L.h_mu; hw_.g_sigma = l->grads + L.h_sigma; hw_.g_bmu = l->grads + L.h_bmu;
+    hw_.g_bsigma = l->grads + L.h_bsigma; hw_.eout = on.h_eout; hw_.ein = on.h_ein;
+    NlDxArgs hx;
+    hx.dy = l->dh; hx.ldy = 2 * L.H; hx.M = B; hx.w = nl_h(on); hx.K = L.F; hx.n_prob = 1;
+    hx.prob[0] = NlDxProblem{0, 2 * L.H, L.H, 0, L.F, 0};
+    hx.prob[1] = hx.prob[0];
+    hx.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
+    const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
+    hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
+    NlBwdGrid hg{(int)rb_div_up(L.F, 256), 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
+    if (side) {   // opt-in side streams: weight grads beside the input-gradient chain
+      if ((rc = fork(s_fc)) != RB_OK) return rc;
+      RB_LAUNCH(k_nl_dw, dim3((unsigned)zg.dw_x, (unsigned)zg.dw_y), dim3(256), s_fc, zw);
+      RB_LAUNCH(k_nl_dx, dim3((unsigned)zg.dx_x, (unsigned)zg.dx_y, (unsigned)zg.dx_z), dim3(256), stream, zx);
+      if ((rc = fork(s_fc)) != RB_OK) return rc;
+      RB_LAUNCH_T("fc_h_dw:k_nl_dw", k_nl_dw, dim3((unsigned)hg.dw_x, (unsigned)hg.dw_y), dim3(256), s_fc, hw_);
+      RB_LAUNCH_T("fc_h_dx:k_nl_dx", k_nl_dx, dim3((unsigned)hg.dx_x, (unsigned)hg.dx_y, (unsigned)hg.dx_z), dim3(256), stream, hx);
+    } else {
+      RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z)), dim3(256),
+                  stream, zw, zx, zg);
+      RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z)), dim3(256),
+                  stream, hw_, hx, hg);
     }
-    {   // fc_z input grads + hidden ReLU mask -> dh
-      NlDxArgs a;
-      a.dy = l->dlogits; a.ldy = L.NZ; a.M = B; a.w = nl_z(on); a.K = L.H; a.n_prob = 2;
-      a.prob[0] = NlDxProblem{0, L.Z, 1 << 30, 0, 0, 0};
-      a.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
-      a.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
-      a.out = l->dh; a.ld_out = 2 * L.H; a.mask_src = l->h;
-      RB_LAUNCH(k_nl_dx, dim3((unsigned)rb_div_up(L.H, 64), 1, 2 * (unsigned)rb_div_up(B, 64)), dim3(256), stream, a);
-      RB_LAUNCH_CHECK();
-    }
-    if ((rc = fork(s_fc)) != RB_OK) return rc;
-    {   // fc_h weight + bias grads
-      NlDwArgs a;
-      a.dy = l->dh; a.x = feat; a.ldy = 2 * L.H; a.ldx = L.F; a.M = B; a.K = L.F; a.n_prob = 2;
-      const int ht = (int)rb_div_up(L.H, 16);
-      a.prob[0] = NlDwProblem{0, L.H, 0, 0, 0};
-      a.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
-      a.g_mu = l->grads + L.h_mu; a.g_sigma = l->grads + L.h_sigma; a.g_bmu = l->grads + L.h_bmu;
-      a.g_bsigma = l->grads + L.h_bsigma; a.eout = on.h_eout; a.ein = on.h_ein;
-      RB_LAUNCH_T("fc_h_dw:k_nl_dw", k_nl_dw, dim3((unsigned)rb_div_up(L.F, 256), (unsigned)(2 * ht)), dim3(256), s_fc, a);
-      RB_LAUNCH_CHECK();
-    }
-    {   // fc_h input grads, split over the 2H reduction rows -> partials -> ReLU-masked dfeat
-      NlDxArgs a;
-      a.dy = l->dh; a.ldy = 2 * L.H; a.M = B; a.w = nl_h(on); a.K = L.F; a.n_prob = 1;
-      a.prob[0] = NlDxProblem{0, 2 * L.H, L.H, 0, L.F, 0};
-      a.prob[1] = a.prob[0];
-      a.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
-      const int splits = (int)rb_div_up(2 * L.H, a.rows_per_split);
-      a.out = l->dfeat_part; a.ld_out = L.F; a.mask_src = nullptr;
-      RB_LAUNCH_T("fc_h_dx:k_nl_dx", k_nl_dx, dim3((unsigned)rb_div_up(L.F, 64), (unsigned)splits, (unsigned)rb_div_up(B, 64)),
-                  dim3(256), stream, a);
-      RB_LAUNCH_CHECK();
-      const int64_t total = (int64_t)B * L.F;
-      RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
-                splits, total, feat, l->dact[L.nconv - 1]);
-      RB_LAUNCH_CHECK();
-    }
+    RB_LAUNCH_CHECK();
+    const int64_t total = (int64_t)B * L.F;
+    RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
+              hsplits, total, feat, l->dact[L.nconv - 1]);
+    RB_LAUNCH_CHECK();
   } else {
   FcGradOut gz;
   gz.g_mu = l->grads + L.z_mu; gz.g_sigma = l->grads + L.z_sigma; gz.g_bmu = l->grads + L.z_bmu;

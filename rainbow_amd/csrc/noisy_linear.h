@@ -61,7 +61,7 @@ struct NlFwdArgs {
 // grid = (32-row tiles, k splits, 2 * m-chunks of 64 rows), block = 512 (8 waves split the k range).
 // Each wave keeps the NEXT 16-wide k chunk's loads in flight while the MFMAs of the current one run.
 #define RB_NL_FWD_WAVES 8
-__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd(NlFwdArgs a) {
+__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES, 4) void k_nl_fwd(NlFwdArgs a) {   // <=128 VGPRs: two blocks per CU
   __shared__ float s_red[RB_NL_FWD_WAVES][32][64];
   const int lane = rb_lane(), wave = rb_wave();
   const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
@@ -195,18 +195,18 @@ struct NlDxArgs {
 };
 
 // grid = (64-column tiles, row splits, n_prob * m-chunks of 64), block = 256 (4 waves split the rows)
-__global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
+__device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by, int bz) {
   __shared__ float s_red[4][64][64];
   const int lane = rb_lane(), wave = rb_wave();
-  const int pi = (int)blockIdx.z % a.n_prob, mc = (int)blockIdx.z / a.n_prob;
+  const int pi = bz % a.n_prob, mc = bz / a.n_prob;
   const NlDxProblem pr = a.prob[pi];
   const int m0 = mc * 64;
   if (m0 >= a.M) return;
   const int mt_cnt = (a.M - m0 >= 64) ? 4 : (a.M - m0 + 15) / 16;
   const int K = a.K;
-  const int kt = (int)blockIdx.x * 64;
+  const int kt = bx * 64;
   const int row_end = pr.row_begin + pr.row_cnt;
-  int rb = pr.row_begin + (int)blockIdx.y * a.rows_per_split;
+  int rb = pr.row_begin + by * a.rows_per_split;
   int re = rb + a.rows_per_split;
   if (re > row_end) re = row_end;
   if (rb >= re) return;                                  // block-uniform
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
     const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
     const int k = kt + 4 * (l & 15);
     if (m < a.M && k < K) {
-      const int64_t o = ((int64_t)blockIdx.y * a.M + m) * a.ld_out + pr.out_off + k;
+      const int64_t o = ((int64_t)by * a.M + m) * a.ld_out + pr.out_off + k;
       if (a.mask_src) {
         const float4 ms = rb_ld4(a.mask_src + o);
         v.x = ms.x > 0.0f ? v.x : 0.0f;
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) { rb_nl_dx_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
 
 // ===================================================================== weight gradient ==
 // g_mu[n][k] = sum_m dy[m][n] * x[m][x_off + k] ; g_sigma = g_mu * (eps_out[n]*eps_in[k]) ;
@@ -312,13 +313,13 @@ struct NlDwArgs {
 };
 
 // grid = (256-column tiles, 16-row tiles), block = 256: wave w owns columns [256*bx + 64*w, +64)
-__global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
+__device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by) {
   const int lane = rb_lane(), wave = rb_wave();
-  const int kt = (int)blockIdx.x * 256 + wave * 64;
+  const int kt = bx * 256 + wave * 64;
   if (kt >= a.K) return;                                 // wave-uniform, no barriers below
-  const int g = (a.n_prob > 1 && (int)blockIdx.y >= a.prob[1].tile_begin) ? 1 : 0;
+  const int g = (a.n_prob > 1 && by >= a.prob[1].tile_begin) ? 1 : 0;
   const NlDwProblem pr = a.prob[g];
-  const int row0 = pr.row_begin + ((int)blockIdx.y - pr.tile_begin) * 16;
+  const int row0 = pr.row_begin + (by - pr.tile_begin) * 16;
   const int row_end = pr.row_begin + pr.row_cnt;
   const int c = lane & 15, q = lane >> 4;
   int col4 = kt + 4 * c;
@@ -373,5 +374,21 @@ __global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
         a.g_bsigma[n] = accb[e] * eo;
       }
     }
+  }
+}
+__global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) { rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y); }
+
+// Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in
+// ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
+// the dX tiles.
+struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; };
+__global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g) {
+  const int b = (int)blockIdx.x;
+  const int ndw = g.dw_x * g.dw_y;
+  if (b < ndw) {
+    rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x);
+  } else {
+    const int r = b - ndw;
+    rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y));
   }
 }

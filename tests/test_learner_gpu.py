@@ -165,7 +165,7 @@ def test_graph_replay_matches_eager(hip, monkeypatch):
     from rainbow_amd.memory import ReplayMemory
 
     def run(graph):
-        monkeypatch.setenv("RAINBOW_AMD_GRAPH", "1" if graph else "0")
+        monkeypatch.setenv("RAINBOW_AMD_GRAPH", "1" if graph else "0")   # graph replay is opt-in
         args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
         env = types.SimpleNamespace(action_space=lambda: 4)
         torch.manual_seed(5)
