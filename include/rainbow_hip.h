@@ -220,6 +220,11 @@ int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const i
  * max_norm/(norm+1e-6) when that is < 1.  norm_dev (f32[1], may be NULL) gets ||g||. */
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream);
 
+/* Tell the library the caller changed grads_dev after rb_learner_learn (e.g. the RCCL
+ * all-reduce of the replica path): the sum of squares the backward kernels accumulated on
+ * the fly is then stale and rb_learner_clip_grad re-reads the gradient.                    */
+int rb_learner_grads_modified(rb_learner_t* l);
+
 /* Agent.update_target_net (agent.py:102-103): params AND noise, device-to-device.   */
 int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream);
 

@@ -288,6 +288,7 @@ class Agent:
                 self._ev_upd.record(self._side)
         if self._world > 1:   # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
             rdist.average_gradients(self.grads)
+            L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
                                                           self._stream()))                # agent.py:97
         self.optimiser.step()                                                              # agent.py:98

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
 // ========================================================================= data gradient ==
 // dX[img][c][y][x] = relu'(x_act) * sum_{co,ky,kx} W[co][c][ky][kx] * dY[img][co][(y-ky)/S][(x-kx)/S]
 // decomposed by phase (y % S, x % S) so only real taps are visited.  The whole dY image sits in LDS.
-// grid = (phases S*S, cin / 32, images B); block = 256.
+// grid = (phases S*S * position groups of 32*NT, cin / 32, images B); block = 512.
 struct ConvLdsDxArgs {
   int cin, cout;
   const float* w;        // [cout][cin][KS][KS]
@@ -272,12 +272,15 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int img = (int)blockIdx.z;
   const int c0 = (int)blockIdx.y * 32;
-  const int py = (int)blockIdx.x / G::S, px = (int)blockIdx.x % G::S;
+  const int phase = (int)blockIdx.x % (G::S * G::S);
+  const int n0 = ((int)blockIdx.x / (G::S * G::S)) * (32 * NT);     // first position of this block inside the phase
+  const int py = phase / G::S, px = phase % G::S;
   const int nty = (G::KS - py + G::S - 1) / G::S, ntx = (G::KS - px + G::S - 1) / G::S;
   const int nyy = (G::IH - py + G::S - 1) / G::S, nxx = (G::IH - px + G::S - 1) / G::S;
   const int taps = nty * ntx;
   const int K = a.cout * taps;
   const int npos = nyy * nxx;
+  if (n0 >= npos) return;                                            // block-uniform
 
   // ---- stage dY image, the phase's weight slab transposed to [k'][c], tap tables
   {
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   int nyx[NT], noff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int n = nt * 32 + (lane & 31);
+    int n = n0 + nt * 32 + (lane & 31);
     if (n > npos - 1) n = npos - 1;
     const int yy = n / nxx, xx = n - yy * nxx;
     nyx[nt] = (yy << 8) | xx;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 #pragma unroll
     for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
     const int c = c0 + rb_mfma_row(r, l);
-    const int n = nt * 32 + (l & 31);
+    const int n = n0 + nt * 32 + (l & 31);
     if (c < a.cin && n < npos) {
       const int yy = n / nxx, xx = n - yy * nxx;
       const int64_t o = ((int64_t)img * a.cin + c) * G::IP + (yy * G::S + py) * G::IH + xx * G::S + px;

@@ -134,7 +134,9 @@ struct rb_learner {
   int32_t* a_star;      // [B]
   float* support;       // [Z]
   float* zero_noise;    // [n_noise] zeros (eval mode, model.py:46)
-  float* norm_part;     // [1024]
+  float* norm_part;     // sum-of-squares partials: [0,1024) k_sumsq; fused producers use [0, norm_slots)
+  int norm_conv_base;   // first slot of the conv reduction blocks
+  int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
@@ -246,10 +248,12 @@ struct ReduceAllArgs {
   ReduceLayer layer[3];
   int n_layers;
   int64_t total;
+  float* sq_part;         // optional: one slot per block = sum of squares of the gradients this block produced
 };
 __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.total) return;
+  float my = 0.0f;
+  if (i < a.total) {
   int li = 0;
   if (a.n_layers > 1 && i >= a.layer[1].begin) li = 1;
   if (a.n_layers > 2 && i >= a.layer[2].begin) li = 2;
@@ -262,6 +266,12 @@ __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const int co = (int)(j / (L.K + 1)), col = (int)(j % (L.K + 1));
   if (col < L.K) L.gw[(int64_t)co * L.K + col] = acc;
   else L.gb[co] = acc;
+  my = acc * acc;
+  }
+  if (a.sq_part) {
+    my = rb_wave_sum(my);
+    if (threadIdx.x == 0) a.sq_part[blockIdx.x] = my;
+  }
 }
 
 // ------------------------------------------------------------------------- head --
@@ -725,8 +735,11 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     a.cin = c.cin; a.cout = c.cout;
     a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
     constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
-    constexpr int NT = (NPOS + 31) / 32;
-    RB_LAUNCH((k_conv_dx_lds<G, NT, 64>), dim3((unsigned)(G::S * G::S), (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B),
+    constexpr int NT_ALL = (NPOS + 31) / 32;
+    // few images at batch 32: spread each phase's positions over several workgroups (weights are re-staged from L2)
+    constexpr int NT = NT_ALL >= 4 ? 2 : 1;
+    const unsigned groups = (unsigned)rb_div_up(NT_ALL, NT);
+    RB_LAUNCH((k_conv_dx_lds<G, NT, 64>), dim3((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B),
               dim3(RB_CONV_THREADS), stream, a);
     RB_LAUNCH_CHECK();
   } else if (layer > 0) {
@@ -889,7 +902,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   if (l->fast_fc) {
-    l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
+    const char* hs_env = getenv("RB_HS");   // tuning knob (experiments)
+    l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, hs_env ? atoi(hs_env) : 512);
     l->xs = pick_splits(rb_div_up(L.F, 64) * rb_div_up(B, 64), 2 * L.H / 16, 512);
   } else {
     l->hs = pick_splits(rb_div_up(2 * B, 64) * rb_div_up(2 * L.H, 64) * 2, (L.F + 15) / 16, 512);
@@ -932,7 +946,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->a_star, (int64_t)B);
   RB_ALLOC(l->support, (int64_t)L.Z);
   RB_ALLOC(l->zero_noise, L.n_noise);
-  RB_ALLOC(l->norm_part, 1024);
+  RB_ALLOC(l->norm_part, 16384);
   RB_ALLOC(l->noise_ctr, 4);
 #undef RB_ALLOC
   RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
@@ -1060,6 +1074,14 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     zw.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
     zw.g_mu = l->grads + L.z_mu; zw.g_sigma = l->grads + L.z_sigma; zw.g_bmu = l->grads + L.z_bmu;
     zw.g_bsigma = l->grads + L.z_bsigma; zw.eout = on.z_eout; zw.ein = on.z_ein;
+    // sum-of-squares slots (clip_grad_norm_ without re-reading the gradient): [fc_z dW waves | fc_h dW waves | conv reduce blocks]
+    const int z_slots = 4 * (int)rb_div_up(L.H, 256) * (vt + at);
+    const int h_slots = 4 * (int)rb_div_up(L.F, 256) * 2 * (int)rb_div_up(L.H, 16);
+    int64_t conv_out = 0;
+    for (int layer = 0; layer < L.nconv; ++layer) conv_out += (int64_t)L.conv[layer].cout * (L.conv[layer].K() + 1);
+    const int c_slots = (int)rb_div_up(conv_out, 64);
+    const bool fuse_norm = !side && z_slots + h_slots + c_slots <= 16384;
+    zw.sq_part = fuse_norm ? l->norm_part : nullptr;
     NlDxArgs zx;
     zx.dy = l->dlogits; zx.ldy = L.NZ; zx.M = B; zx.w = nl_z(on); zx.K = L.H; zx.n_prob = 2;
     zx.prob[0] = NlDxProblem{0, L.Z, 1 << 30, 0, 0, 0};
@@ -1075,6 +1097,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hw_.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
     hw_.g_mu = l->grads + L.h_mu; hw_.g_sigma = l->grads + L.h_sigma; hw_.g_bmu = l->grads + L.h_bmu;
     hw_.g_bsigma = l->grads + L.h_bsigma; hw_.eout = on.h_eout; hw_.ein = on.h_ein;
+    hw_.sq_part = fuse_norm ? l->norm_part + z_slots : nullptr;
+    l->norm_slots = fuse_norm ? z_slots + h_slots + c_slots : 0;
+    l->norm_conv_base = z_slots + h_slots;
     NlDxArgs hx;
     hx.dy = l->dh; hx.ldy = 2 * L.H; hx.M = B; hx.w = nl_h(on); hx.K = L.F; hx.n_prob = 1;
     hx.prob[0] = NlDxProblem{0, 2 * L.H, L.H, 0, L.F, 0};
@@ -1102,6 +1127,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
               hsplits, total, feat, l->dact[L.nconv - 1]);
     RB_LAUNCH_CHECK();
   } else {
+  l->norm_slots = 0;
   FcGradOut gz;
   gz.g_mu = l->grads + L.z_mu; gz.g_sigma = l->grads + L.z_sigma; gz.g_bmu = l->grads + L.z_bmu;
   gz.g_bsigma = l->grads + L.z_bsigma; gz.eout = on.z_eout; gz.ein = on.z_ein;
@@ -1155,6 +1181,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
       off += (int64_t)c.cout * (c.K() + 1);
     }
     ra.n_layers = L.nconv; ra.total = off;
+    ra.sq_part = l->norm_slots > 0 ? l->norm_part + l->norm_conv_base : nullptr;
     RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(off, 64)), dim3(64), s_cv, ra);
     RB_LAUNCH_CHECK();
   }
@@ -1170,13 +1197,24 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_clip_grad: NULL handle");
   const int64_t n = l->L.n_params;
-  int nparts = (int)rb_div_up(n, 256 * 16);
-  if (nparts > 1024) nparts = 1024;
-  RB_LAUNCH(k_sumsq, dim3((unsigned)nparts), dim3(256), stream, (const float*)l->grads, n, l->norm_part);
-  RB_LAUNCH_CHECK();
-  RB_LAUNCH(k_clip_scale, dim3((unsigned)nparts), dim3(256), stream, l->grads, n, (const float*)l->norm_part, nparts,
+  int nblocks = (int)rb_div_up(n, 256 * 16);
+  if (nblocks > 1024) nblocks = 1024;
+  int nparts = l->norm_slots;
+  if (nparts <= 0) {   // gradient was produced by the fallback path or modified since (all-reduce): one pass over it
+    nparts = nblocks;
+    RB_LAUNCH(k_sumsq, dim3((unsigned)nparts), dim3(256), stream, (const float*)l->grads, n, l->norm_part);
+    RB_LAUNCH_CHECK();
+  }
+  l->norm_slots = 0;   // consumed
+  RB_LAUNCH(k_clip_scale, dim3((unsigned)nblocks), dim3(256), stream, l->grads, n, (const float*)l->norm_part, nparts,
             max_norm, norm_dev);
   RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_grads_modified(rb_learner_t* l) {
+  RB_REQUIRE(l != nullptr, "rb_learner_grads_modified: NULL handle");
+  l->norm_slots = 0;
   return RB_OK;
 }
 

@@ -310,13 +310,18 @@ struct NlDwArgs {
   NlDwProblem prob[2];
   float *g_mu, *g_sigma, *g_bmu, *g_bsigma;
   const float *eout, *ein;
+  float* sq_part;            // optional: one slot per (block, wave) receiving the sum of squares of what that wave wrote
+                             // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
 };
 
 // grid = (256-column tiles, 16-row tiles), block = 256: wave w owns columns [256*bx + 64*w, +64)
-__device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by) {
+__device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by, int slot_base) {
   const int lane = rb_lane(), wave = rb_wave();
   const int kt = bx * 256 + wave * 64;
-  if (kt >= a.K) return;                                 // wave-uniform, no barriers below
+  if (kt >= a.K) {                                       // wave-uniform, no barriers below
+    if (a.sq_part && lane == 0) a.sq_part[slot_base + wave] = 0.0f;
+    return;
+  }
   const int g = (a.n_prob > 1 && by >= a.prob[1].tile_begin) ? 1 : 0;
   const NlDwProblem pr = a.prob[g];
   const int row0 = pr.row_begin + (by - pr.tile_begin) * 16;
@@ -357,6 +362,7 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by)
     }
   }
   const float4 e4 = rb_ld4(a.ein + pr.ein_off + col4);
+  float sq = 0.0f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int n = row0 + 4 * q + e;
@@ -368,15 +374,25 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by)
         gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
         rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
         rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+        sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
+        sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
       }
       if (do_bias && c == 0) {
-        a.g_bmu[n] = accb[e];
-        a.g_bsigma[n] = accb[e] * eo;
+        const float gb = accb[e], gbs = accb[e] * eo;
+        a.g_bmu[n] = gb;
+        a.g_bsigma[n] = gbs;
+        sq = fmaf(gb, gb, sq); sq = fmaf(gbs, gbs, sq);
       }
     }
   }
+  if (a.sq_part) {                                        // wave-uniform
+    sq = rb_wave_sum(sq);
+    if (lane == 0) a.sq_part[slot_base + wave] = sq;
+  }
 }
-__global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) { rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y); }
+__global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
+  rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y, 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x));
+}
 
 // Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in
 // ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
   const int b = (int)blockIdx.x;
   const int ndw = g.dw_x * g.dw_y;
   if (b < ndw) {
-    rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x);
+    rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
   } else {
     const int r = b - ndw;
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y));

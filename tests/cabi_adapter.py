@@ -278,6 +278,7 @@ class CAbiLearnAdapter:
         if self.grad_hook is not None:
             m.sync()
             self.grad_hook(self._as_torch(self.grads))
+            L.check(self.lib, self.lib.rb_learner_grads_modified(self.h))
         L.check(self.lib, self.lib.rb_learner_clip_grad(self.h, self.hy["norm_clip"], m.ptr(norm), m.stream))
         m.sync()
         grads = self._unflat(m.download(self.grads))
