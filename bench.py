@@ -90,7 +90,7 @@ def kernel_table(cfg):
     wh = 2 * H * F * 4                      # one of mu / sigma of the fused hidden layer, bytes
     return {
         # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident
-        "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4, unit="GB/s"),
+        "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4 + 3 * B * 2 * H * 4 * 2, unit="GB/s"),
         # hidden layer weight grads: writes d_mu + d_sigma once
         # hidden layer backward (one launch): streams mu+sigma of the online net once (dX), writes d_mu + d_sigma once (dW)
         "fc_h_bwd": dict(bound="hbm", work=2 * wh + 2 * wh + B * (F + 2 * H) * 4, unit="GB/s"),

@@ -23,6 +23,8 @@ struct ConvLdsFwdArgs {
   ImgSrc src;                // FIRST layer input
   const float* in_f;         // later layers: [img][cin][IP]
   float* out;                // [img][cout][P]
+  float* out_blocked;        // optional second copy of the flattened output in the k-blocked layout of noisy_linear.h
+  int rows_total;            //   ... with this many rows (images)
   int ablate;                // profiling experiments only (RB_ABLATE): 1 skip MFMA loop, 2 skip staging, 4 skip reduction
 };
 
@@ -238,8 +240,14 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
     }
     const int m = cout0 + rb_mfma_row(r, l);
     const int p = p0 + nt * 32 + (l & 31);
-    if (m < a.cout && p < G::P && p < p0 + 32 * NT)
-      a.out[((int64_t)img * a.cout + m) * G::P + p] = fmaxf(v + a.bias[net][m], 0.0f);
+    if (m < a.cout && p < G::P && p < p0 + 32 * NT) {
+      const float o = fmaxf(v + a.bias[net][m], 0.0f);
+      a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+      if (a.out_blocked) {
+        const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+        a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+      }
+    }
   }
 }
 

@@ -123,6 +123,7 @@ struct rb_learner {
   float* dact[3];       // [B][cout][P]
   float* hpart;         // [hs][NI][2H]
   float* h;             // [NI][2H]
+  float *feat_b, *h_b;  // k-blocked copies of feat [NI][F] and h [NI][2H] for the streamed forward kernels
   float* logits;        // [NI][NZ]
   float* dlogits;       // [B][NZ]
   float* dh;            // [B][2H]
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void k_noise(float* noise, float* noise2, cons
 // ----------------------------------------------------------- small fused passes --
 // h[img][n] = relu(sum_s part[s][img][n] + (bias_mu + bias_sigma*eps_out)[n])        model.py:44,72-73
 __global__ __launch_bounds__(256) void k_fc_h_finish(const float* part, int splits, int NI, int H2, int n_online,
-                                                      NetPtrs on, NetPtrs tg, float* h) {
+                                                      NetPtrs on, NetPtrs tg, float* h, float* h_blocked) {
   const int64_t total = (int64_t)NI * H2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int img = (int)(i / H2), n = (int)(i % H2);
@@ -209,7 +210,18 @@ __global__ __launch_bounds__(256) void k_fc_h_finish(const float* part, int spli
     float acc = 0.0f;
     for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];
     const float bias = p.h_bmu[n] + p.h_bsigma[n] * p.h_eout[n];
-    h[i] = fmaxf(acc + bias, 0.0f);
+    const float o = fmaxf(acc + bias, 0.0f);
+    h[i] = o;
+    if (h_blocked) h_blocked[((int64_t)(n >> 4) * NI + img) * 16 + (n & 15)] = o;
+  }
+}
+
+// row-major [rows][K] -> k-blocked copy (only when the generic conv path feeds the streamed FC kernels)
+__global__ __launch_bounds__(256) void k_block_copy(const float* x, int rows, int K, float* xb) {
+  const int64_t total = (int64_t)rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / K), k = (int)(i % K);
+    xb[((int64_t)(k >> 4) * rows + row) * 16 + (k & 15)] = x[i];
   }
 }
 
@@ -576,6 +588,8 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.cin = c.cin; a.cout = c.cout; a.n_on = n_on;
   a.w[0] = on.conv_w[layer]; a.w[1] = tg.conv_w[layer]; a.bias[0] = on.conv_b[layer]; a.bias[1] = tg.conv_b[layer];
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
+  a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
+  a.rows_total = n_on + n_tg;
   {
     static const char* ab = getenv("RB_ABLATE");
     a.ablate = ab ? atoi(ab) : 0;
@@ -628,38 +642,34 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
   const int m_max = n_on > n_tg ? n_on : n_tg;
   const unsigned mchunks = (unsigned)rb_div_up(m_max, 64);
   if (l->fast_fc) {
-    // hidden layer: both streams, both nets, weights streamed once (noisy_linear.h)
-    NlFwdArgs a;
-    a.x = feat; a.ldx = L.F;
+    if (!l->fast_conv) {
+      RB_LAUNCH(k_block_copy, dim3((unsigned)rb_div_up((int64_t)NI * L.F, 256)), dim3(256), stream, feat, NI, L.F, l->feat_b);
+      RB_LAUNCH_CHECK();
+    }
+    // hidden layer: both streams, both nets, weights streamed once, bias + ReLU fused, no partials (noisy_linear.h)
+    NlFwd2Args a;
+    a.x = l->feat_b;
     a.m_base[0] = 0; a.m_cnt[0] = n_on; a.m_base[1] = n_on; a.m_cnt[1] = n_tg;
     a.w[0] = nl_h(on); a.w[1] = nl_h(tg);
     a.K = L.F; a.n_groups = 2;
-    const int tiles_per_stream = (int)rb_div_up(L.H, 32);
+    const int ht16 = (int)rb_div_up(L.H, 16);
     a.grp[0] = NlRowGroup{0, L.H, 0, 0, 0};
-    a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, tiles_per_stream};
-    const int chunks = L.F / 16;
-    a.chunks_per_split = (int)rb_div_up(chunks, l->hs);
-    const int splits = (int)rb_div_up(chunks, a.chunks_per_split);
-    a.out = l->hpart; a.ld_out = 2 * L.H; a.rows_total = NI; a.add_bias = 0; a.relu = 0;
-    RB_LAUNCH_T("fc_h_fwd:k_nl_fwd", k_nl_fwd, dim3((unsigned)(2 * tiles_per_stream), (unsigned)splits, 2 * mchunks),
-                dim3(64 * RB_NL_FWD_WAVES), stream, a);
+    a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, ht16};
+    a.out = l->h; a.out_blocked = l->h_b; a.ld_out = 2 * L.H; a.rows_total = NI; a.relu = 1;
+    const unsigned mch32 = (unsigned)rb_div_up(m_max, RB_FWD2_MROWS);
+    RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2, dim3((unsigned)(2 * ht16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, a);
     RB_LAUNCH_CHECK();
-    const int64_t total = (int64_t)NI * 2 * L.H;
-    RB_LAUNCH(k_fc_h_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->hpart, splits, NI,
-              2 * L.H, n_on, on, tg, l->h);
-    RB_LAUNCH_CHECK();
-    // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused, no split
-    NlFwdArgs z;
-    z.x = l->h; z.ldx = 2 * L.H;
+    // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
+    NlFwd2Args z;
+    z.x = l->h_b;
     z.m_base[0] = 0; z.m_cnt[0] = n_on; z.m_base[1] = n_on; z.m_cnt[1] = n_tg;
     z.w[0] = nl_z(on); z.w[1] = nl_z(tg);
     z.K = L.H; z.n_groups = 2;
-    const int vt = (int)rb_div_up(L.Z, 32), at = (int)rb_div_up(L.NZ - L.Z, 32);
+    const int vt16 = (int)rb_div_up(L.Z, 16), at16 = (int)rb_div_up(L.NZ - L.Z, 16);
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
-    z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt};
-    z.chunks_per_split = L.H / 16;
-    z.out = l->logits; z.ld_out = L.NZ; z.rows_total = NI; z.add_bias = 1; z.relu = 0;
-    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd", k_nl_fwd, dim3((unsigned)(vt + at), 1, 2 * mchunks), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
+    z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
+    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2, dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
     RB_LAUNCH_CHECK();
     return RB_OK;
   }
@@ -674,7 +684,7 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     RB_LAUNCH_CHECK();
     const int64_t total = (int64_t)NI * 2 * L.H;
     RB_LAUNCH(k_fc_h_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->hpart, l->hs, NI,
-              2 * L.H, n_on, on, tg, l->h);
+              2 * L.H, n_on, on, tg, l->h, (float*)nullptr);
     RB_LAUNCH_CHECK();
   }
   {
@@ -864,7 +874,7 @@ int64_t rb_learner_noise_draws(const rb_learner_config_t* cfg) {
 
 int rb_learner_destroy(rb_learner_t* l) {
   if (!l) return RB_OK;
-  float** owned[] = {&l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
+  float** owned[] = {&l->feat_b, &l->h_b, &l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
                      &l->logits, &l->dlogits, &l->dh, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
                      &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
   for (float** p : owned)
@@ -936,6 +946,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   }
   RB_ALLOC(l->hpart, (int64_t)l->hs * NI * 2 * L.H);
   RB_ALLOC(l->h, (int64_t)NI * 2 * L.H);
+  RB_ALLOC(l->feat_b, (int64_t)NI * (L.F + 16));
+  RB_ALLOC(l->h_b, (int64_t)NI * (2 * L.H + 16));
   RB_ALLOC(l->logits, (int64_t)NI * L.NZ);
   RB_ALLOC(l->dlogits, (int64_t)B * L.NZ);
   RB_ALLOC(l->dh, (int64_t)B * 2 * L.H);

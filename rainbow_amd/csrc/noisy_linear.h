@@ -27,6 +27,11 @@ struct NlWeights {
   const float* bsigma;  // [N]
 };
 
+// k-blocked activation layout consumed by k_nl_fwd: element (row, k) of a [rows][K] matrix
+__host__ __device__ inline int64_t rb_blocked_index(int row, int k, int rows) {
+  return ((int64_t)(k >> 4) * rows + row) * 16 + (k & 15);
+}
+
 // W = mu + sigma * (eo * ein), component-wise, three separately rounded operations
 __device__ __forceinline__ float4 rb_noisy4(float4 mu, float4 sg, float eo, float4 e) {
   float4 w;
@@ -38,137 +43,156 @@ __device__ __forceinline__ float4 rb_noisy4(float4 mu, float4 sg, float eo, floa
 }
 
 // ============================================================================ forward ==
-// out[m][n] = sum_k x[m][x_off + k] * W[n][k]  (+ bias, ReLU optional when not split)
+// out[m][n] = b[n] + sum_k x[m][x_off + k] * W[n][k]   (ReLU optional)
 struct NlRowGroup {
   int row_begin, row_cnt;   // weight rows of this stream
   int x_off, ein_off;       // column offset into x, offset into ein
-  int tile_begin;           // first 32-row tile index of this group in grid.x
+  int tile_begin;           // first 16-row tile index of this group in grid.x
 };
-struct NlFwdArgs {
-  const float* x;
-  int ldx;
-  int m_base[2], m_cnt[2];  // activation rows of net 0 / net 1
+#define RB_NL_FWD_WAVES 8
+// k_nl_fwd2 — forward without split-K partials: one workgroup owns a 16-row weight tile for the whole K, its 8 waves
+// take contiguous K ranges and meet once in a 2 KB-per-wave LDS reduction; bias (+ReLU) is applied there and the
+// result is written directly (row-major and, optionally, k-blocked for the next layer) — no partial-sum round trip, no
+// separate finish kernel.  (Round-1 history: a split-K variant with a finish kernel measured the same 30 us for the
+// pair; ablation shows the activation re-reads through the 64 B/clk L1 cost as much as the weight stream itself.)
+struct NlFwd2Args {
+  const float* x;           // k-blocked activations (rb_blocked_index)
+  int m_base[2], m_cnt[2];
   NlWeights w[2];
   int K;
   int n_groups;
-  NlRowGroup grp[2];
-  int chunks_per_split;     // 16-wide k chunks per block (grid.y = splits)
-  float* out;               // split: part[s][rows_total][ld_out] ; else out[rows_total][ld_out]
+  NlRowGroup grp[2];        // tile_begin counts 16-row tiles here
+  float* out;               // [rows_total][ld_out]
+  float* out_blocked;       // optional k-blocked copy over ld_out columns
   int ld_out, rows_total;
-  int add_bias, relu;       // only with a single split
+  int relu;
 };
 
-// grid = (32-row tiles, k splits, 2 * m-chunks of 64 rows), block = 512 (8 waves split the k range).
-// Each wave keeps the NEXT 16-wide k chunk's loads in flight while the MFMAs of the current one run.
-#define RB_NL_FWD_WAVES 8
-__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES, 4) void k_nl_fwd(NlFwdArgs a) {   // <=128 VGPRs: two blocks per CU
-  __shared__ float s_red[RB_NL_FWD_WAVES][32][64];
+// grid = (16-row tiles, 1, 2 * m-chunks of 32 rows), block = 512
+#define RB_FWD2_MROWS 32
+__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) {
+  __shared__ float s_red[RB_NL_FWD_WAVES][8][64];
   const int lane = rb_lane(), wave = rb_wave();
   const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
   const int M = a.m_cnt[net];
-  const int m0 = mc * 64;
+  const int m0 = mc * RB_FWD2_MROWS;
   if (m0 >= M) return;                                   // block-uniform
-  const int mt_cnt = (M - m0 >= 64) ? 4 : (M - m0 + 15) / 16;
   const int g = (a.n_groups > 1 && (int)blockIdx.x >= a.grp[1].tile_begin) ? 1 : 0;
   const NlRowGroup grp = a.grp[g];
-  const int row0 = grp.row_begin + ((int)blockIdx.x - grp.tile_begin) * 32;
+  const int row0 = grp.row_begin + ((int)blockIdx.x - grp.tile_begin) * 16;
   const int row_end = grp.row_begin + grp.row_cnt;
   const NlWeights w = a.w[net];
   const int K = a.K;
-
-  const int total_chunks = K / 16;
-  const int c_begin = (int)blockIdx.y * a.chunks_per_split;
-  int c_end = c_begin + a.chunks_per_split;
-  if (c_end > total_chunks) c_end = total_chunks;
-  const int per_wave = (c_end - c_begin + RB_NL_FWD_WAVES - 1) / RB_NL_FWD_WAVES;
-  int wc0 = c_begin + wave * per_wave, wc1 = wc0 + per_wave;
-  if (wc1 > c_end) wc1 = c_end;
+  const int nchunks = K / 16;
+  const int per_wave = ((nchunks + RB_NL_FWD_WAVES - 1) / RB_NL_FWD_WAVES + 1) / 2 * 2;   // even: whole 32-wide blocks
+  int wc0 = wave * per_wave, wc1 = wc0 + per_wave;
+  if (wc0 > nchunks) wc0 = nchunks;
+  if (wc1 > nchunks) wc1 = nchunks;
+  const int nsc = (wc1 - wc0 + 1) / 2;                   // 32-wide k blocks of this wave
 
   const int r = lane & 15, q = lane >> 4;
-  const float* mu_p[2];
-  const float* sg_p[2];
-  float eo[2];
+  int row = row0 + r;
+  if (row > row_end - 1) row = row_end - 1;
+  const float* mu_p = w.mu + (int64_t)row * K + 4 * q;
+  const float* sg_p = w.sigma + (int64_t)row * K + 4 * q;
+  const float eo = w.eout[row];
+  const float* ein_p = w.ein + grp.ein_off + 4 * q;
+  const float* x_p[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int row = row0 + 16 * t + r;
-    if (row > row_end - 1) row = row_end - 1;
-    mu_p[t] = w.mu + (int64_t)row * K;
-    sg_p[t] = w.sigma + (int64_t)row * K;
-    eo[t] = w.eout[row];
-  }
-  const float* x_p[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < 2; ++mt) {
     int m = m0 + 16 * mt + r;
     if (m > M - 1) m = M - 1;
-    x_p[mt] = a.x + (int64_t)(a.m_base[net] + m) * a.ldx + grp.x_off;
+    x_p[mt] = a.x + ((int64_t)(grp.x_off >> 4) * a.rows_total + a.m_base[net] + m) * 16 + 4 * q;
   }
-  const float* ein_p = w.ein + grp.ein_off;
+  const int64_t xs = (int64_t)a.rows_total * 16;
 
-  rb_f32x4 acc[4][2];
+  rb_f32x4 acc[2];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[mt][t][e] = 0.0f;
+    for (int e = 0; e < 4; ++e) acc[mt][e] = 0.0f;
 
-  float4 n_e, n_mu[2], n_sg[2], n_x[4];
-  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  // Software pipeline.  Weights come from HBM (latency ~2 us under load), so FOUR 32-wide k blocks of mu/sigma
+  // (16 KB per wave) are kept in flight in a statically indexed register ring; activations / eps_in come from
+  // L2/L1 one block ahead.  Every load is UNCONDITIONAL (out-of-range blocks re-read the wave's last chunk and are
+  // multiplied by a zero mask): a branch around a load would make the outstanding-load count unknown to the
+  // compiler, which then drains the whole queue (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
+  constexpr int RING = 4;
+  float4 r_mu[RING][2], r_sg[RING][2];
+  float4 c_e[2], c_x[2][2], n_e[2], n_x[2][2];
+  const int c_last = wc1 > wc0 ? wc1 - 1 : (nchunks > 0 ? nchunks - 1 : 0);
+  auto chunk_of = [&](int sc, int h) { const int cc = wc0 + 2 * sc + h; return cc < wc1 ? cc : c_last; };
+  auto live = [&](int sc, int h) { return (wc0 + 2 * sc + h < wc1) ? 1.0f : 0.0f; };
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) n_x[mt] = zero4;
-  auto issue = [&](int c) {
-    const int k4 = c * 16 + 4 * q;
-    n_e = rb_ld4(ein_p + k4);
+  for (int d = 0; d < RING; ++d)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { n_mu[t] = rb_ld4(mu_p[t] + k4); n_sg[t] = rb_ld4(sg_p[t] + k4); }
+    for (int h = 0; h < 2; ++h) {
+      const int cc = chunk_of(d, h);
+      r_mu[d][h] = rb_ld4(mu_p + cc * 16);
+      r_sg[d][h] = rb_ld4(sg_p + cc * 16);
+    }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-      if (mt < mt_cnt) n_x[mt] = rb_ld4(x_p[mt] + k4);
-  };
-  if (wc0 < wc1) issue(wc0);
-  for (int c = wc0; c < wc1; ++c) {
-    float4 w4[2], x4[4];
+  for (int h = 0; h < 2; ++h) {
+    const int cc = chunk_of(0, h);
+    n_e[h] = rb_ld4(ein_p + cc * 16);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) w4[t] = rb_noisy4(n_mu[t], n_sg[t], eo[t], n_e);
+    for (int mt = 0; mt < 2; ++mt) n_x[h][mt] = rb_ld4(x_p[mt] + cc * xs);
+  }
+  const int nsc_pad = (nsc + RING - 1) / RING * RING;
+  for (int sc0 = 0; sc0 < nsc_pad; sc0 += RING) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) x4[mt] = n_x[mt];
-    if (c + 1 < wc1) issue(c + 1);                       // next chunk's loads fly under these MFMAs
+    for (int d = 0; d < RING; ++d) {
+      const int sc = sc0 + d;
+      float4 w4[2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      if (mt < mt_cnt) {                                 // wave-uniform
+      for (int h = 0; h < 2; ++h) {
+        c_e[h] = n_e[h];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          acc[mt][t] = rb_mfma16(x4[mt].x, w4[t].x, acc[mt][t]);
-          acc[mt][t] = rb_mfma16(x4[mt].y, w4[t].y, acc[mt][t]);
-          acc[mt][t] = rb_mfma16(x4[mt].z, w4[t].z, acc[mt][t]);
-          acc[mt][t] = rb_mfma16(x4[mt].w, w4[t].w, acc[mt][t]);
-        }
+        for (int mt = 0; mt < 2; ++mt) c_x[h][mt] = n_x[h][mt];
+        const float lv = live(sc, h);
+        w4[h] = rb_noisy4(r_mu[d][h], r_sg[d][h], eo, c_e[h]);
+        w4[h].x *= lv; w4[h].y *= lv; w4[h].z *= lv; w4[h].w *= lv;
       }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                      // refill this ring slot (block sc + RING), fetch x of block sc + 1
+        const int cw = chunk_of(sc + RING, h);
+        r_mu[d][h] = rb_ld4(mu_p + cw * 16);
+        r_sg[d][h] = rb_ld4(sg_p + cw * 16);
+        const int cx = chunk_of(sc + 1, h);
+        n_e[h] = rb_ld4(ein_p + cx * 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) n_x[h][mt] = rb_ld4(x_p[mt] + cx * xs);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[mt] = rb_mfma16(c_x[h][mt].x, w4[h].x, acc[mt]);
+          acc[mt] = rb_mfma16(c_x[h][mt].y, w4[h].y, acc[mt]);
+          acc[mt] = rb_mfma16(c_x[h][mt].z, w4[h].z, acc[mt]);
+          acc[mt] = rb_mfma16(c_x[h][mt].w, w4[h].w, acc[mt]);
+        }
     }
   }
-  // cross-wave reduction of the four k sub-ranges through LDS, fixed order
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s_red[wave][(mt * 2 + t) * 4 + e][lane] = acc[mt][t][e];
+    for (int e = 0; e < 4; ++e) s_red[wave][mt * 4 + e][lane] = acc[mt][e];
   __syncthreads();
-  const int slots = mt_cnt * 8;
-  for (int idx = (int)threadIdx.x; idx < slots * 64; idx += 64 * RB_NL_FWD_WAVES) {
+  for (int idx = (int)threadIdx.x; idx < 8 * 64; idx += 64 * RB_NL_FWD_WAVES) {
     const int slot = idx >> 6, l = idx & 63;
     float v = s_red[0][slot][l];
 #pragma unroll
     for (int wv = 1; wv < RB_NL_FWD_WAVES; ++wv) v += s_red[wv][slot][l];
-    const int mt = slot >> 3, t = (slot >> 2) & 1, e = slot & 3;
+    const int mt = slot >> 2, e = slot & 3;
     const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
-    const int n = row0 + 16 * t + (l & 15);
-    if (m < M && n < row_end) {
-      float o = v;
-      if (a.add_bias) o += w.bmu[n] + w.bsigma[n] * w.eout[n];      // model.py:44
+    const int n = row0 + (l & 15);
+    if (m < M && m < m0 + RB_FWD2_MROWS && n < row_end) {
+      float o = v + (w.bmu[n] + w.bsigma[n] * w.eout[n]);                 // model.py:44
       if (a.relu) o = fmaxf(o, 0.0f);
-      a.out[((int64_t)blockIdx.y * a.rows_total + a.m_base[net] + m) * a.ld_out + n] = o;
+      const int rowi = a.m_base[net] + m;
+      a.out[(int64_t)rowi * a.ld_out + n] = o;
+      if (a.out_blocked) a.out_blocked[((int64_t)(n >> 4) * a.rows_total + rowi) * 16 + (n & 15)] = o;
     }
   }
 }

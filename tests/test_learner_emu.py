@@ -82,3 +82,32 @@ def test_zero_copy_windows_equals_gathered_stacks(emu):
     assert np.array_equal(loss_a, loss_b)
     assert np.array_equal(grads_a, ad.grads)
     ad.close(); rp.close()
+
+
+def test_long_history_uses_generic_convs_with_streamed_fc(emu):
+    """history > 4 disables the LDS conv kernels but keeps the streamed FC kernels (row-major -> k-blocked copy in
+    between); checked against the oracle directly since no golden exists for this shape."""
+    import cabi_adapter
+    c = dict(architecture="data-efficient", hidden=32, actions=3, atoms=21, batch=4, multi_step=2, discount=0.95,
+             history=5, v_min=-5.0, v_max=5.0)
+    scenarios.LEARN_CONFIGS["_hist5"] = c
+    try:
+        cfg = O.Config(**c)
+        ad = CAbiLearnAdapter(emu, NumpyMem(), "_hist5")
+        online, target = O.init_params(cfg, 41), O.init_params(cfg, 42)
+        ad.load(online, target)
+        rs = np.random.RandomState(9)
+        draws = O.noise_draw_count(cfg)
+        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+        ad.reset_noise_online(raw_on)
+        batch = scenarios.make_batch(c, 77)
+        out = ad.learn_step(batch, raw_tg)
+        want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+        total, clipped = O.clip_grads(want["grads"], scenarios.LEARN_HYPER["norm_clip"])
+        np.testing.assert_allclose(out["loss"], want["loss"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(out["grad_norm"], total, rtol=2e-5)
+        for k, g in clipped.items():
+            np.testing.assert_allclose(out["grads"][k], g, rtol=2e-4, atol=5e-6 * float(np.abs(g).max()) + 1e-12, err_msg=k)
+        ad.close()
+    finally:
+        del scenarios.LEARN_CONFIGS["_hist5"]
