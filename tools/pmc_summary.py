@@ -24,7 +24,7 @@ def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     res = {}
-    tags = {"k_nl_fwd": "fc_h_fwd", "k_nl_dx": "fc_h_dx", "k_nl_dw": "fc_h_dw"}
+    tags = {"k_nl_fwd2": "fc_h_fwd", "k_nl_bwd": "fc_h_bwd"}
     for kern, tag in tags.items():
         keys = [k for k in fetch if k[0] == kern]
         if not keys:
