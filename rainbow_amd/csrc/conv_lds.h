@@ -404,19 +404,28 @@ struct ConvLdsDwArgs {
   float* part;             // [B * chunks][cout][K+1]
 };
 
+template <class G, int RC, int KMAX>
+struct ConvDwLdsSize {
+  static constexpr int PC = RC * G::OH;               // positions per chunk
+  static constexpr int PCP = (PC + 1) / 2 * 2;        // padded to the MFMA k granule
+  static constexpr int PR = (RC - 1) * G::S + G::KS;  // input rows per chunk
+  static constexpr int PLANE = PR * G::IH;
+  static constexpr int CMAX = KMAX / G::KK;
+  static constexpr int FLOATS = PCP * 33 + CMAX * PLANE + PCP;   // dY^T, patch, position offsets
+};
+
+// body with explicit block coordinates and caller-provided LDS, so several layers can share one launch
 template <class G, int RC, int KMAX, bool FIRST>
-__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a) {
-  constexpr int PC = RC * G::OH;                      // positions per chunk
-  constexpr int PCP = (PC + 1) / 2 * 2;               // padded to the MFMA k granule
-  constexpr int PR = (RC - 1) * G::S + G::KS;         // input rows per chunk
-  constexpr int PLANE = PR * G::IH;
-  constexpr int CMAX = KMAX / G::KK;
-  __shared__ float s_a[PCP * 33];                     // dY^T: [pos][co]
-  __shared__ float s_patch[CMAX * PLANE];
-  __shared__ int s_poff[PCP];
+__device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chunk, int cotile, int img, int nchunks,
+                                                float* smem) {
+  typedef ConvDwLdsSize<G, RC, KMAX> SZ;
+  constexpr int PC = SZ::PC, PCP = SZ::PCP, PR = SZ::PR, PLANE = SZ::PLANE;
+  float* s_a = smem;                                  // dY^T: [pos][co]
+  float* s_patch = smem + PCP * 33;
+  int* s_poff = reinterpret_cast<int*>(smem + PCP * 33 + SZ::CMAX * PLANE);
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int img = (int)blockIdx.z, co0 = (int)blockIdx.y * 32, chunk = (int)blockIdx.x;
+  const int co0 = cotile * 32;
   const int cin = a.cin, K = cin * G::KK;
   const int oy0 = chunk * RC;
   const int p0 = oy0 * G::OH;
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a
   }
   __syncthreads();
 
-  float* out = a.part + (((int64_t)img * gridDim.x + chunk) * a.cout) * (K + 1);
+  float* out = a.part + (((int64_t)img * nchunks + chunk) * a.cout) * (K + 1);
   // bias column: sum over the chunk's positions, fixed order
   if (t < 32 && co0 + t < a.cout) {
     float acc = 0.0f;
@@ -511,5 +520,47 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a
       const int m = co0 + rb_mfma_row(q, lane);
       if (cv && m < a.cout) out[(int64_t)m * (K + 1) + tile * 32 + nl] = acc[q];
     }
+  }
+}
+
+template <class G, int RC, int KMAX, bool FIRST>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a) {
+  __shared__ float smem[ConvDwLdsSize<G, RC, KMAX>::FLOATS];
+  rb_conv_dw_body<G, RC, KMAX, FIRST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+}
+
+// Every conv layer's weight gradient in ONE launch (they only feed the optimiser and are independent of each other
+// once all dact[] exist): block ranges [0,n0) layer 0, [n0,n0+n1) layer 1, ...  Saves two kernel boundaries and fills
+// the chip with 288 workgroups instead of 160 + 64 + 64 in sequence.
+struct ConvDwAllArgs {
+  ConvLdsDwArgs layer[3];
+  int nblocks[3];          // workgroups of each layer
+  int cotiles[3];
+  int batch;
+};
+template <class G0, int RC0, class G1, int RC1, int K1, class G2, int RC2, int K2, int NL>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a) {
+  typedef ConvDwLdsSize<G0, RC0, 4 * G0::KK> S0;
+  typedef ConvDwLdsSize<G1, RC1, K1> S1;
+  typedef ConvDwLdsSize<G2, RC2, K2> S2;
+  constexpr int M01 = S0::FLOATS > S1::FLOATS ? S0::FLOATS : S1::FLOATS;
+  constexpr int MAXF = (NL > 2 && S2::FLOATS > M01) ? S2::FLOATS : M01;
+  __shared__ float smem[MAXF];
+  int b = (int)blockIdx.x;
+  if (b < a.nblocks[0]) {                              // decode: chunk fastest, then cout tile, then image
+    constexpr int CH = (G0::OH + RC0 - 1) / RC0;
+    rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], b % CH, (b / CH) % a.cotiles[0], b / (CH * a.cotiles[0]), CH, smem);
+    return;
+  }
+  b -= a.nblocks[0];
+  if (b < a.nblocks[1]) {
+    constexpr int CH = (G1::OH + RC1 - 1) / RC1;
+    rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], b % CH, (b / CH) % a.cotiles[1], b / (CH * a.cotiles[1]), CH, smem);
+    return;
+  }
+  if (NL > 2) {
+    b -= a.nblocks[1];
+    constexpr int CH = (G2::OH + RC2 - 1) / RC2;
+    rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], b % CH, (b / CH) % a.cotiles[2], b / (CH * a.cotiles[2]), CH, smem);
   }
 }

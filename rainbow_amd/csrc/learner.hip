@@ -771,6 +771,34 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   return RB_OK;
 }
 
+// all conv layers' weight gradients in one launch (LDS kernels); fills dw_slices for the fused slice reduction
+static int conv_dw_all(rb_learner* l, hipStream_t stream) {
+  const Layout& L = l->L;
+  ConvDwAllArgs a;
+  a.batch = L.B;
+  unsigned total = 0;
+  for (int i = 0; i < L.nconv; ++i) {
+    const ConvLayer& c = L.conv[i];
+    ConvLdsDwArgs& d = a.layer[i];
+    d.cin = c.cin; d.cout = c.cout; d.dy = l->dact[i]; d.part = l->dw_part[i];
+    d.src = l->cur_src; d.x_f = i > 0 ? l->act[i - 1] : nullptr;
+    const int rc = i == 0 ? (c.ks == 8 ? 5 : 4) : c.oh;                 // later layers: the whole image is one chunk
+    const int chunks = (c.oh + rc - 1) / rc;
+    a.cotiles[i] = (int)rb_div_up(c.cout, 32);
+    a.nblocks[i] = chunks * a.cotiles[i] * L.B;
+    l->dw_slices[i] = chunks * L.B;
+    total += (unsigned)a.nblocks[i];
+  }
+  for (int i = L.nconv; i < 3; ++i) { a.nblocks[i] = 0; a.cotiles[i] = 1; a.layer[i] = a.layer[0]; }
+  if (L.nconv == 3) {
+    RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomC1, 5, GeomC2, 9, 512, GeomC3, 7, 576, 3>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
+  } else {
+    RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomD1, 4, GeomD2, 3, 800, GeomD2, 3, 800, 2>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
+  }
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
 static int conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream, int mode) {
   const ConvLayer& c = l->L.conv[layer];
   if (c.ks == 8) return launch_conv_bwd<GeomC1>(l, layer, states, stream, mode);
@@ -940,7 +968,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     RB_ALLOC(l->dact[i], (int64_t)B * c.cout * c.P());
     {
       int64_t slices = l->ws[i];
-      if (i == 0 && slices < (int64_t)B * 5) slices = (int64_t)B * 5;   // LDS first-layer kernel: B images x <=5 row chunks
+      if (slices < (int64_t)B * 5) slices = (int64_t)B * 5;   // LDS weight-grad kernels: B images x <=5 row chunks
       RB_ALLOC(l->dw_part[i], slices * c.cout * (c.K() + 1));
     }
   }
@@ -1178,10 +1206,16 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     RB_LAUNCH_CHECK();
   }
   }
-  for (int layer = L.nconv - 1; layer >= 0; --layer) {
-    if ((rc = fork(s_cv)) != RB_OK) return rc;                        // dact[layer] is final on the main stream
-    if ((rc = conv_bwd(l, layer, states_dev, s_cv, 1)) != RB_OK) return rc;       // weight grads: side stream
-    if (layer > 0 && (rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;   // data grads: main
+  if (l->fast_conv && !side) {
+    for (int layer = L.nconv - 1; layer > 0; --layer)                 // the input-gradient chain first ...
+      if ((rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;
+    if ((rc = conv_dw_all(l, stream)) != RB_OK) return rc;            // ... then every weight gradient in one launch
+  } else {
+    for (int layer = L.nconv - 1; layer >= 0; --layer) {
+      if ((rc = fork(s_cv)) != RB_OK) return rc;                      // dact[layer] is final on the main stream
+      if ((rc = conv_bwd(l, layer, states_dev, s_cv, 1)) != RB_OK) return rc;       // weight grads: side stream
+      if (layer > 0 && (rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;   // data grads: main
+    }
   }
   {   // one fixed-order reduction of every conv layer's split slices into the gradient buffer
     ReduceAllArgs ra;
@@ -1212,7 +1246,11 @@ int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_st
   int nblocks = (int)rb_div_up(n, 256 * 16);
   if (nblocks > 1024) nblocks = 1024;
   int nparts = l->norm_slots;
-  if (nparts <= 0) {   // gradient was produced by the fallback path or modified since (all-reduce): one pass over it
+  if (nparts > 0) {
+    // every block of the scale kernel re-sums the partial list (same order everywhere): keep that redundant work small.
+    // The scale loop itself only runs when the norm exceeds max_norm.
+    if (nblocks > 256) nblocks = 256;
+  } else {   // gradient was produced by the fallback path or modified since (all-reduce): one pass over it
     nparts = nblocks;
     RB_LAUNCH(k_sumsq, dim3((unsigned)nparts), dim3(256), stream, (const float*)l->grads, n, l->norm_part);
     RB_LAUNCH_CHECK();
