@@ -220,6 +220,16 @@ int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const i
  * max_norm/(norm+1e-6) when that is < 1.  norm_dev (f32[1], may be NULL) gets ||g||. */
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream);
 
+/* Fused priority write-back (agent.py:100 -> memory.py:157-159).  With a sink set, rb_learner_learn*
+ * itself applies  sum_tree[tree_idx] = loss^w  (+ ancestor sums, max) to `replay` as one extra
+ * workgroup of its backward launch, i.e. off the step's critical path.  tree_idx_dev must be the
+ * index buffer the sampler fills each step (i64[batch]).  rb_learner_priority_written() tells
+ * whether the LAST learn call did the write-back (it does not on the generic fallback path or
+ * for batch > 256; the caller then calls rb_replay_update_priorities as usual).  Pass NULLs to
+ * clear the sink.                                                                           */
+int rb_learner_set_priority_sink(rb_learner_t* l, rb_replay_t* replay, const int64_t* tree_idx_dev);
+int rb_learner_priority_written(rb_learner_t* l);
+
 /* Tell the library the caller changed grads_dev after rb_learner_learn (e.g. the RCCL
  * all-reduce of the replica path): the sum of squares the backward kernels accumulated on
  * the fly is then stale and rb_learner_clip_grad re-reads the gradient.                    */

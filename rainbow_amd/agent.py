@@ -103,6 +103,10 @@ class Agent:
         self._graph_mem = None
         self._eager_steps = 0
         self._noise_pending = False
+        # priority write-back beside clip + Adam on a second stream (one fork/join per step)
+        self._overlap_update = os.environ.get("RAINBOW_AMD_UPDATE_OVERLAP", "0") == "1"
+        # priority write-back as one extra workgroup of the learner's backward launch (see rb_learner_set_priority_sink)
+        self._fuse_update = os.environ.get("RAINBOW_AMD_FUSED_UPDATE", "1") == "1"
         self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
         self._norm = torch.zeros(1, dtype=torch.float32, device=d)
         self._act_out = torch.zeros(1, dtype=torch.int32, device=d)
@@ -267,6 +271,14 @@ class Agent:
         else:
             self._flush_noise()
             self._reset_target_noise(_target_raw_normals)                                  # agent.py:74
+        if (device_mem and self._fuse_update
+                and (getattr(self, "_sink_mem", None) is not mem or self._sink_idx is not idxs)):
+            # the learner writes the new priorities into mem's sum-tree itself (one extra workgroup of its backward)
+            L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, mem._h, idxs.data_ptr()))
+            self._sink_mem, self._sink_idx = mem, idxs
+        elif not device_mem and getattr(self, "_sink_mem", None) is not None:
+            L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, None, None))
+            self._sink_mem, self._sink_idx = None, None
         if zero_copy:   # conv1 reads the frames straight out of the HBM ring: no stack gather at all
             frames, windows, wlen = mem.frame_source()
             L.check(self._lib, self._lib.rb_learner_learn_windows(
@@ -276,7 +288,8 @@ class Agent:
             L.check(self._lib, self._lib.rb_learner_learn(
                 self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
                 nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), self._stream()))   # agent.py:66-96
-        overlap = device_mem and os.environ.get("RB_SIDE_STREAMS", "0") == "1"   # opt-in, see learner.hip
+        fused_update = device_mem and bool(self._lib.rb_learner_priority_written(self._h))
+        overlap = device_mem and self._overlap_update and not fused_update
         if overlap:
             # agent.py:100 without the D2H sync: the new priorities depend only on (idxs, loss), so the sum-tree
             # update runs on a side stream next to clip + Adam; the main stream re-joins before the next sample.
@@ -295,7 +308,8 @@ class Agent:
         if overlap:
             torch.cuda.current_stream(self.device).wait_event(self._ev_upd)
         elif device_mem:
-            mem.update_priorities(idxs, self._loss)                                        # agent.py:100, no D2H
+            if not fused_update:
+                mem.update_priorities(idxs, self._loss)                                    # agent.py:100, no D2H
         else:
             mem.update_priorities(idxs, self._loss.detach().cpu().numpy())                 # agent.py:100
 

@@ -25,7 +25,6 @@ struct ConvLdsFwdArgs {
   float* out;                // [img][cout][P]
   float* out_blocked;        // optional second copy of the flattened output in the k-blocked layout of noisy_linear.h
   int rows_total;            //   ... with this many rows (images)
-  int ablate;                // profiling experiments only (RB_ABLATE): 1 skip MFMA loop, 2 skip staging, 4 skip reduction
 };
 
 // ---- shared staging helpers ------------------------------------------------------------------
@@ -115,15 +114,13 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
   if (rows > PR) rows = PR;
 
   // ---- stage: weights (transposed), k -> patch offset table, input patch
-  if (!(a.ablate & 2))
   rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
     const int c = kc / G::KK, r = kc % G::KK;
     s_koff[k] = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
   }
-  if (a.ablate & 2) {
-  } else if (FIRST && !a.src.f32) {
+  if (FIRST && !a.src.f32) {
     const int per_c = rows * G::IH;                 // bytes per channel, 16-byte multiple for the frame geometries
     const int v16 = per_c >> 4;
     const int total16 = cin * v16;
@@ -216,9 +213,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
   const int kh = lane >> 5, ml = lane & 31;
-  const int KWE = (a.ablate & 1) ? 0 : KW;
 #pragma unroll 4
-  for (int kk = 0; kk < KWE; kk += 2) {               // LDS reads of the unrolled steps are issued ahead of the MFMAs
+  for (int kk = 0; kk < KW; kk += 2) {               // LDS reads of the unrolled steps are issued ahead of the MFMAs
     const int k = kb + kk + kh;                       // < KPAD
     const float av = s_w[k * 33 + ml];
     const int ko = s_koff[k];
@@ -234,10 +230,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
   for (int idx = t; idx < NT * 16 * 64; idx += RB_CONV_THREADS) {
     const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
     float v = s_all[((0 * NT + nt) * 16 + r) * 64 + l];
-    if (!(a.ablate & 4)) {
 #pragma unroll
     for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
-    }
     const int m = cout0 + rb_mfma_row(r, l);
     const int p = p0 + nt * 32 + (l & 31);
     if (m < a.cout && p < G::P && p < p0 + 32 * NT) {

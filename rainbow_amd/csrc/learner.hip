@@ -142,6 +142,9 @@ struct rb_learner {
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
   ImgSrc cur_src;       // input frames of the learn step in flight
+  int sink_done;        // the last learn() performed the priority write-back itself
+  rb_replay_t* sink;    // priority sink: when set, learn() writes loss^w back into this replay's sum-tree itself
+  const int64_t* sink_idx;
   int fast_fc;          // streamed 16x16x4 noisy-linear kernels usable (alignment preconditions hold)
   int fast_conv;        // LDS-resident conv kernels usable (history <= 4, standard channel counts)
   // backward fork/join: weight-gradient kernels run on side streams next to the input-gradient chain
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
                                                const float* returns, const float* nonterminals, const float* weights,
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
-                                               int32_t* a_star_out, float* loss_out, float* dlogits, int ablate) {
+                                               int32_t* a_star_out, float* loss_out, float* dlogits) {
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
   __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
@@ -364,7 +367,6 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
   const float R = returns[b], nt = nonterminals[b], wgt = weights[b];
   const int act = (int)actions[b];
   __syncthreads();
-  if (ablate & 32) { if (t == 0) loss_out[b] = s_lg[0][0] + R + nt + wgt + (float)act; return; }
   HeadWave hw;
   hw.lane = lane;
   float sup[RB_ZI];
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
 
   // ---------------- double-Q selection on online(next_states)   agent.py:71-73   (actions round-robin over waves)
   hw.mean_of(s_lg[1], Z, A, mean);
-  for (int a = wave; a < ((ablate & 8) ? 0 : A); a += 4) {
+  for (int a = wave; a < A; a += 4) {
     const float se = hw.softmax_of(s_lg[1], Z, mean, a, e, qm);
     float sv = 0.0f;
 #pragma unroll
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
   // the reference's first index_add_ (all l bins, j ascending) followed by the second (u bins) on the same m.
   for (int k = t; k < Z; k += 256) s_m[k] = 0.0f;
   __syncthreads();
-  if (!(ablate & 16)) {
+  {
     for (int j = t; j < Z; j += 256) {
       const int key = s_l[j];
       if (j == 0 || s_l[j - 1] != key) {
@@ -590,10 +592,6 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
-  {
-    static const char* ab = getenv("RB_ABLATE");
-    a.ablate = ab ? atoi(ab) : 0;
-  }
   RB_LAUNCH((k_conv_fwd_lds<G, NT, PR, KMAX, FIRST>),
             dim3((unsigned)rb_div_up(G::P, 32 * NT), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
             dim3(RB_CONV_THREADS), stream, a);
@@ -940,8 +938,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   if (l->fast_fc) {
-    const char* hs_env = getenv("RB_HS");   // tuning knob (experiments)
-    l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, hs_env ? atoi(hs_env) : 512);
+    l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
     l->xs = pick_splits(rb_div_up(L.F, 64) * rb_div_up(B, 64), 2 * L.H / 16, 512);
   } else {
     l->hs = pick_splits(rb_div_up(2 * B, 64) * rb_div_up(2 * L.H, 64) * 2, (L.F + 15) / 16, 512);
@@ -1087,7 +1084,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head, dim3((unsigned)B), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, getenv("RB_ABLATE") ? atoi(getenv("RB_ABLATE")) : 0);
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
@@ -1148,6 +1145,15 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
     hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
     NlBwdGrid hg{(int)rb_div_up(L.F, 256), 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
+    NlPriorityUpdate up;
+    memset(&up, 0, sizeof(up));
+    if (l->sink && B <= 256) {
+      up.enabled = 1; up.tree_idx = l->sink_idx; up.loss = loss_dev; up.n = B;
+      if (rb_replay_internal_view(l->sink, &up.view, &up.omega) != RB_OK) {
+        rb_set_error("rb_learner_learn: bad priority sink");
+        return RB_ERR_STATE;
+      }
+    }
     if (side) {   // opt-in side streams: weight grads beside the input-gradient chain
       if ((rc = fork(s_fc)) != RB_OK) return rc;
       RB_LAUNCH(k_nl_dw, dim3((unsigned)zg.dw_x, (unsigned)zg.dw_y), dim3(256), s_fc, zw);
@@ -1156,11 +1162,15 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
       RB_LAUNCH_T("fc_h_dw:k_nl_dw", k_nl_dw, dim3((unsigned)hg.dw_x, (unsigned)hg.dw_y), dim3(256), s_fc, hw_);
       RB_LAUNCH_T("fc_h_dx:k_nl_dx", k_nl_dx, dim3((unsigned)hg.dx_x, (unsigned)hg.dx_y, (unsigned)hg.dx_z), dim3(256), stream, hx);
     } else {
-      RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z)), dim3(256),
-                  stream, zw, zx, zg);
+      NlPriorityUpdate none;
+      memset(&none, 0, sizeof(none));
+      RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd,
+                  dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z + (up.enabled ? 1 : 0))), dim3(256), stream,
+                  zw, zx, zg, up);
       RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z)), dim3(256),
-                  stream, hw_, hx, hg);
+                  stream, hw_, hx, hg, none);
     }
+    l->sink_done = (up.enabled && !side) ? 1 : 0;
     RB_LAUNCH_CHECK();
     const int64_t total = (int64_t)B * L.F;
     RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
@@ -1168,6 +1178,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     RB_LAUNCH_CHECK();
   } else {
   l->norm_slots = 0;
+  l->sink_done = 0;
   FcGradOut gz;
   gz.g_mu = l->grads + L.z_mu; gz.g_sigma = l->grads + L.z_sigma; gz.g_bmu = l->grads + L.z_bmu;
   gz.g_bsigma = l->grads + L.z_bsigma; gz.eout = on.z_eout; gz.ein = on.z_ein;
@@ -1260,6 +1271,18 @@ int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_st
             max_norm, norm_dev);
   RB_LAUNCH_CHECK();
   return RB_OK;
+}
+
+int rb_learner_set_priority_sink(rb_learner_t* l, rb_replay_t* replay, const int64_t* tree_idx_dev) {
+  RB_REQUIRE(l != nullptr, "rb_learner_set_priority_sink: NULL handle");
+  RB_REQUIRE((replay == nullptr) == (tree_idx_dev == nullptr), "rb_learner_set_priority_sink: pass both or neither");
+  l->sink = replay;
+  l->sink_idx = tree_idx_dev;
+  return RB_OK;
+}
+
+int rb_learner_priority_written(rb_learner_t* l) {
+  return (l && l->sink_done) ? 1 : 0;
 }
 
 int rb_learner_grads_modified(rb_learner_t* l) {

@@ -17,6 +17,7 @@
 // K % 16 == 0, all leading dimensions and offsets multiples of 4 floats.
 #pragma once
 #include "rb_device.h"
+#include "replay_internal.h"
 
 struct NlWeights {
   const float* mu;      // [N][K]
@@ -422,13 +423,27 @@ __global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
 // ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
 // the dX tiles.
 struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; };
-__global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g) {
+// Optional third tenant of the output layer's backward launch: the sum-tree priority write-back (agent.py:100,
+// memory.py:157-159).  It depends only on (tree indices, per-sample loss), both final before this launch, and is a
+// single-workgroup latency chain — as one more block here it costs nothing on the step's critical path.
+struct NlPriorityUpdate {
+  int enabled;
+  ReplayView view;
+  const int64_t* tree_idx;
+  const float* loss;
+  int n;
+  double omega;
+};
+__global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g, NlPriorityUpdate up) {
   const int b = (int)blockIdx.x;
   const int ndw = g.dw_x * g.dw_y;
+  const int ndx = g.dx_x * g.dx_y * g.dx_z;
   if (b < ndw) {
     rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
-  } else {
+  } else if (b < ndw + ndx) {
     const int r = b - ndw;
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y));
+  } else {
+    rb_update_body(up.view, up.tree_idx, up.loss, up.n, 1, up.omega);     // the one extra block (n <= 256)
   }
 }

@@ -1,0 +1,148 @@
+// replay_internal.h — pieces of the replay implementation shared inside librainbow_hip.so (not part of the C ABI):
+// the kernel-side view of a replay handle and the sum-tree update body, so the learner can run the priority
+// write-back (agent.py:100) as one extra workgroup of its own backward launch instead of a separate dependent kernel.
+#pragma once
+#include "rb_common.h"
+
+struct ReplayView {
+  int64_t capacity;
+  int32_t history, n, levels;
+  int64_t tree_start, tree_len;
+  float* tree;
+  uint8_t* frames;
+  int32_t* timestep;
+  int32_t* action;
+  float* reward;
+  uint8_t* nonterminal;
+  rb_replay_header_t* hdr;
+};
+
+
+__device__ __forceinline__ int64_t rb_floor_mod(int64_t a, int64_t m) {
+  int64_t r = a % m;
+  return r < 0 ? r + m : r;
+}
+
+
+// ---------------------------------------------------------------------- update --
+// SegmentTree.update (memory.py:44-48) for n <= 1024 leaves in ONE workgroup.
+// Duplicate indices: numpy fancy assignment is last-write-wins (memory.py:45).
+// apply_pow: ReplayMemory.update_priorities' p = loss^w first (memory.py:158).
+//
+// Latency structure: the L ancestor sums are NOT walked through memory level by level (that is
+// L dependent round trips).  Each thread prefetches the sibling of its node on every level in one
+// batch of independent loads, then walks to the root in registers.  Where two paths of this batch
+// meet, the sibling's FRESH value must be used instead of the prefetched one: every level
+// publishes (node -> value) in an LDS hash table (open addressing, 2048 slots for <= 1024 keys,
+// three tables in rotation so one barrier per level suffices) and looks its sibling up there —
+// O(1) LDS probes per level instead of scanning the batch.  Every parent is still
+// fl32(left + right) of its current children (memory.py:25): same floats as the reference.
+#define RB_MAX_LEVELS 31
+#define RB_HASH_SLOTS 2048
+
+// the table size follows the batch (power of two >= 4n, <= 2048 slots): a batch of 32 clears and probes 128 slots
+__device__ __forceinline__ int rb_hash_slot(int node, int shift) {
+  return (int)(((unsigned)node * 2654435761u) >> shift);
+}
+__device__ __forceinline__ int rb_hash_insert(int* keys, int node, int shift, int mask) {
+  int h = rb_hash_slot(node, shift);
+  for (;;) {
+    const int prev = atomicCAS(&keys[h], -1, node);
+    if (prev == -1 || prev == node) return h;
+    h = (h + 1) & mask;
+  }
+}
+__device__ __forceinline__ int rb_hash_find(const int* keys, int node, int shift, int mask) {
+  int h = rb_hash_slot(node, shift);
+  for (;;) {
+    const int k = keys[h];
+    if (k == node) return h;
+    if (k == -1) return -1;
+    h = (h + 1) & mask;
+  }
+}
+
+// body (all threads of ONE workgroup of >= n threads, multiple of 64); shared by k_update and the learner's fused launch
+__device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
+                                               int32_t apply_pow, double omega) {
+  __shared__ int s_key[4][RB_HASH_SLOTS];     // [3] = leaf de-duplication table
+  __shared__ float s_tv[3][RB_HASH_SLOTS];
+  __shared__ int s_pos[RB_HASH_SLOTS];
+  __shared__ float s_vi[1024];
+  __shared__ float s_red[16];
+  const int i = (int)threadIdx.x;
+  const bool active = i < n;
+  int node = active ? (int)tree_idx[i] : -1;
+  // sibling prefetch for every level (stale where another updated path passes; fixed up from LDS)
+  float sib[RB_MAX_LEVELS];
+  {
+    int q = node;
+#pragma unroll
+    for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
+      if (active && lv < v.levels) {
+        const int sb = (q & 1) ? q + 1 : q - 1;
+        sib[lv] = v.tree[sb];
+        q = (q - 1) >> 1;
+      } else {
+        sib[lv] = 0.0f;
+      }
+    }
+  }
+  // (sizing the tables by the batch was measured SLOWER on MI355X — 15.3 vs 11.9 us at n=32, more probe collisions in
+  // the top hash bits — so all batches use the full 2048 slots)
+  const int hmask = RB_HASH_SLOTS - 1, hshift = 21;
+  for (int t = i; t <= hmask; t += (int)blockDim.x) {
+    s_key[0][t] = -1; s_key[1][t] = -1; s_key[2][t] = -1; s_key[3][t] = -1;
+    s_pos[t] = -1;
+  }
+  float val = 0.0f;
+  if (active) {
+    val = values[i];
+    if (apply_pow) val = (float)pow((double)val, omega);
+  }
+  s_vi[i] = val;
+  const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47 (+ barrier)
+  int slot = -1;
+  if (active) {
+    slot = rb_hash_insert(s_key[3], node, hshift, hmask);
+    atomicMax(&s_pos[slot], i);                // last occurrence wins (memory.py:45)
+  }
+  __syncthreads();
+  if (active) {
+    val = s_vi[s_pos[slot]];
+    v.tree[node] = val;
+  }
+  int prev_slot = -1;
+#pragma unroll
+  for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
+    if (lv < v.levels) {                        // block-uniform
+      const int c = lv % 3;
+      int my = -1;
+      if (active) {
+        my = rb_hash_insert(s_key[c], node, hshift, hmask);
+        s_tv[c][my] = val;                      // paths on the same node carry the same value
+      }
+      __syncthreads();
+      if (active) {
+        if (prev_slot >= 0) s_key[(lv + 2) % 3][prev_slot] = -1;   // retire level lv-1's entry (all its lookups are done)
+        const int sb = (node & 1) ? node + 1 : node - 1;
+        const int f = rb_hash_find(s_key[c], sb, hshift, hmask);
+        const float sv = f >= 0 ? s_tv[c][f] : sib[lv];
+        const float left = (node & 1) ? val : sv;     // odd index = left child (2p+1)
+        const float right = (node & 1) ? sv : val;
+        val = __fadd_rn(left, right);                 // memory.py:25
+        node = (node - 1) >> 1;
+        v.tree[node] = val;
+        prev_slot = my;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    v.hdr->max = fmaxf(vmax, v.hdr->max);  // memory.py:48
+    v.hdr->total = val;                    // thread 0 ended at the root
+  }
+}
+
+
+// host side (replay.hip): kernel view + priority exponent of a handle
+int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega);

@@ -81,6 +81,25 @@ def test_zero_copy_windows_equals_gathered_stacks(emu):
                                               mem.ptr(bufs["weights"]), mem.ptr(loss_b), None))
     assert np.array_equal(loss_a, loss_b)
     assert np.array_equal(grads_a, ad.grads)
+    # fused priority write-back: with a sink set, the same launch also updates the sum-tree — bit-identical to the
+    # separate rb_replay_update_priorities call on a twin tree
+    tree_before = rp.tree()
+    idx_dev = mem.upload(out["tree_idxs"])
+    L.check(emu, emu.rb_learner_set_priority_sink(ad.h, rp.h, mem.ptr(idx_dev)))
+    L.check(emu, emu.rb_learner_learn_windows(ad.h, rp.bufs.frames_dev, rp.bufs.window_dev, rp.bufs.window_len,
+                                              mem.ptr(bufs["actions"]), mem.ptr(bufs["returns"]), mem.ptr(bufs["nonterminals"]),
+                                              mem.ptr(bufs["weights"]), mem.ptr(loss_b), None))
+    assert emu.rb_learner_priority_written(ad.h) == 1
+    tree_fused, hdr_fused = rp.tree(), rp.raw_header()
+    assert not np.array_equal(tree_fused, tree_before)
+    # rewind the tree and apply the same update through the stand-alone entry point
+    leaves = np.arange(rp.bufs.tree_start, rp.bufs.tree_len)
+    rp.update_leaves(leaves[:1024][:512], tree_before[rp.bufs.tree_start:][:512])
+    assert np.array_equal(rp.tree(), tree_before)
+    rp.update_priorities(out["tree_idxs"], loss_b)
+    assert np.array_equal(rp.tree(), tree_fused)
+    assert rp.raw_header().total == hdr_fused.total
+    L.check(emu, emu.rb_learner_set_priority_sink(ad.h, None, None))
     ad.close(); rp.close()
 
 
