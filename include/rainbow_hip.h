@@ -39,6 +39,9 @@ extern "C" {
 #define RB_FRAME_BYTES (84 * 84) /* memory.py:7 'state' u8[84,84] */
 
 typedef void* rb_stream_t; /* hipStream_t */
+/* Opaque description of a pending noise resample (rb_learner_noise_job) that another launch of the
+ * library can host as extra workgroups (rb_replay_sample_fused_noise).                       */
+typedef struct { uint64_t opaque[32]; } rb_noise_job_t;
 typedef struct rb_replay rb_replay_t;
 typedef struct rb_learner rb_learner_t;
 
@@ -126,6 +129,16 @@ int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight,
                      int64_t* actions_dev, float* returns_dev, float* nonterminals_dev,
                      float* weights_dev, rb_stream_t stream);
 
+/* rb_replay_sample + the learner's per-step noise resample (model.py:36-40) in ONE launch: the
+ * sampler is a single-workgroup latency chain and the noise draw is independent of it, so the
+ * noise workgroups ride along and cost no kernel boundary of their own.  noise_job comes from
+ * rb_learner_noise_job (device RNG only).                                                    */
+int rb_replay_sample_fused_noise(rb_replay_t* r, int32_t batch, double priority_weight,
+                                 const double* unit_uniforms_dev, int32_t max_attempts,
+                                 int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                                 int64_t* actions_dev, float* returns_dev, float* nonterminals_dev,
+                                 float* weights_dev, const rb_noise_job_t* noise_job, rb_stream_t stream);
+
 /* Graph replay support: when set (non-NULL), rb_replay_sample reads -beta (float32, i.e.
  * float32(-priority_weight), memory.py:153) from this DEVICE location instead of its by-value
  * argument, so main.py:161's per-step annealing works under a captured hipGraph.           */
@@ -190,6 +203,9 @@ int rb_learner_destroy(rb_learner_t* l);
 int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev,
                            rb_stream_t stream);
 int64_t rb_learner_noise_draws(const rb_learner_config_t* cfg);
+/* The same resample as rb_learner_reset_noise(l, which, NULL, ...) described as a job another
+ * launch can host (rb_replay_sample_fused_noise); nothing is launched here.                  */
+int rb_learner_noise_job(rb_learner_t* l, int32_t which, rb_noise_job_t* out);
 
 /* Agent.act / evaluate_q (agent.py:53-55, 110-112): single state f32[history][7056]
  * in [0,1]; writes argmax action (i32) and its expected value (f32).

@@ -33,6 +33,10 @@ class LearnerConfig(C.Structure):
                 ("v_min", c_float), ("v_max", c_float), ("discount", c_double)]
 
 
+class NoiseJob(C.Structure):
+    _fields_ = [("opaque", c_uint64 * 32)]
+
+
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("offset", c_int64), ("ndim", c_int32), ("shape", c_int32 * 4)]
 
@@ -55,6 +59,8 @@ SIGNATURES = {
     "rb_replay_sample": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rb_replay_set_beta_source": (c_int, [c_void_p, c_void_p]),
+    "rb_replay_sample_fused_noise": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(NoiseJob), c_void_p]),
     "rb_replay_update_leaves": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_update_priorities": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_state_at": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
@@ -66,6 +72,7 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_uint64]),
     "rb_learner_destroy": (c_int, [c_void_p]),
     "rb_learner_reset_noise": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "rb_learner_noise_job": (c_int, [c_void_p, c_int32, C.POINTER(NoiseJob)]),
     "rb_learner_noise_draws": (c_int64, [C.POINTER(LearnerConfig)]),
     "rb_learner_act": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "rb_learner_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

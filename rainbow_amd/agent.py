@@ -103,6 +103,7 @@ class Agent:
         self._graph_mem = None
         self._eager_steps = 0
         self._noise_pending = False
+        self._noise_jobs = {}
         # priority write-back beside clip + Adam on a second stream (one fork/join per step)
         self._overlap_update = os.environ.get("RAINBOW_AMD_UPDATE_OVERLAP", "0") == "1"
         # priority write-back as one extra workgroup of the learner's backward launch (see rb_learner_set_priority_sink)
@@ -252,8 +253,20 @@ class Agent:
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
         zero_copy = device_mem and self._cfg.history <= 4 and mem.history == self._cfg.history and mem.n == self.n
+        noise_job = None
+        if device_mem and _target_raw_normals is None:
+            # the target-noise draw of this step (agent.py:74) — plus the deferred online draw (main.py:151) when one is
+            # pending — rides along in the sampler's launch: it does not depend on the batch, only has to precede the
+            # forwards, and the draws are the same Philox epochs as separate launches (online first, then target)
+            which = 2 if self._noise_pending else 1
+            self._noise_pending = False
+            noise_job = self._noise_jobs.get(which)
+            if noise_job is None:
+                noise_job = L.NoiseJob()
+                L.check(self._lib, self._lib.rb_learner_noise_job(self._h, which, C.byref(noise_job)))
+                self._noise_jobs[which] = noise_job
         if device_mem:
-            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy)                 # agent.py:63
+            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy, noise_job=noise_job)   # agent.py:63
             idxs, states, next_states = o["tree_idxs"], o["states"], o["next_states"]
             actions, returns, nonterminals, weights = o["actions"], o["returns"], o["nonterminals"], o["weights"]
         else:   # foreign replay with the reference's API: float32 /255 states come back; re-quantise (exact for k/255)
@@ -265,12 +278,13 @@ class Agent:
             returns = returns.to(device=d, dtype=torch.float32).contiguous()
             nonterminals = nonterminals.to(device=d, dtype=torch.float32).reshape(B).contiguous()
             weights = weights.to(device=d, dtype=torch.float32).contiguous()
-        if self._noise_pending and _target_raw_normals is None:
-            self._noise_pending = False      # online (main.py:151) and target (agent.py:74) noise in one launch
-            L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 2, None, self._stream()))
-        else:
-            self._flush_noise()
-            self._reset_target_noise(_target_raw_normals)                                  # agent.py:74
+        if noise_job is None:
+            if self._noise_pending and _target_raw_normals is None:
+                self._noise_pending = False      # online (main.py:151) and target (agent.py:74) noise in one launch
+                L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 2, None, self._stream()))
+            else:
+                self._flush_noise()
+                self._reset_target_noise(_target_raw_normals)                              # agent.py:74
         if (device_mem and self._fuse_update
                 and (getattr(self, "_sink_mem", None) is not mem or self._sink_idx is not idxs)):
             # the learner writes the new priorities into mem's sum-tree itself (one extra workgroup of its backward)

@@ -11,6 +11,7 @@
 // the float32 reference is the contract); everything else is fused into their operand
 // gathers / epilogues (learner_problems.h).
 #include "conv_lds.h"
+#include "noise_body.h"
 #include "learner_problems.h"
 #include "noisy_linear.h"
 #include "rb_common.h"
@@ -159,47 +160,9 @@ struct rb_learner {
 // f(x) = sign(x) * sqrt(|x|)  (model.py:32-34).  raw == NULL: N(0,1) from Philox + Box-Muller.
 // Draw order = the reference's: per layer randn(in) then randn(out); fc_h_v, fc_h_a, fc_z_v,
 // fc_z_a (model.py:36-38, 82-85).
-struct NoiseMap {
-  int64_t seg_begin[9];   // prefix of draw counts: hv_in, hv_out, ha_in, ha_out, zv_in, zv_out, za_in, za_out
-  int64_t dst[8];         // destination offsets in the noise buffer
-};
-// The Philox epoch is DEVICE state (ctr[0]) so that a captured hipGraph draws fresh noise on every replay; the
-// last workgroup to finish (ticket in ctr[1]) advances it — every block has read the epoch before it takes a ticket.
-// blockIdx.y selects the net when both are resampled in one launch (noise2 != NULL): online = epoch, target = epoch+1,
-// i.e. exactly the draws two consecutive single-net launches would make.
 __global__ __launch_bounds__(256) void k_noise(float* noise, float* noise2, const float* raw, NoiseMap map, uint64_t seed,
                                                 unsigned long long* ctr) {
-  const uint64_t epoch = ctr[0] + blockIdx.y;
-  if (blockIdx.y == 1) noise = noise2;
-  const int64_t total = map.seg_begin[8];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float x;
-    if (raw) {
-      x = raw[i];
-    } else {
-      const rb_philox_out r = rb_philox(seed, epoch, (uint64_t)(i >> 1));
-      const float u1 = ((float)(r.v[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const float u2 = ((float)(r.v[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const float rad = sqrtf(-2.0f * logf(u1));
-      const float ang = 6.283185307179586f * u2;
-      x = (i & 1) ? rad * sinf(ang) : rad * cosf(ang);
-    }
-    const float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
-    const float f = s * sqrtf(fabsf(x));
-    int seg = 0;
-#pragma unroll
-    for (int q = 1; q < 8; ++q) seg += (i >= map.seg_begin[q]) ? 1 : 0;
-    noise[map.dst[seg] + (i - map.seg_begin[seg])] = f;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned long long ticket = atomicAdd(&ctr[1], 1ull);
-    if (ticket == (unsigned long long)gridDim.x * gridDim.y - 1ull) {
-      ctr[0] = ctr[0] + gridDim.y;
-      ctr[1] = 0;
-    }
-  }
+  rb_noise_body(noise, noise2, raw, map, seed, ctr, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // ----------------------------------------------------------- small fused passes --
@@ -1006,16 +969,35 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   return RB_OK;
 }
 
-int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev, rb_stream_t stream) {
-  RB_REQUIRE(l != nullptr, "rb_learner_reset_noise: NULL handle");
-  RB_REQUIRE(which >= 0 && which <= 2, "rb_learner_reset_noise: which must be 0 (online), 1 (target) or 2 (both)");
-  RB_REQUIRE(!(which == 2 && raw_normals_dev), "rb_learner_reset_noise: injected normals need one call per net");
-  const Layout& L = l->L;
+static NoiseMap noise_map(const Layout& L) {
   NoiseMap map;
   const int64_t counts[8] = {L.F, L.H, L.F, L.H, L.H, L.Z, L.H, (int64_t)L.A * L.Z};
   const int64_t dst[8] = {L.h_ein, L.h_eout, L.h_ein + L.F, L.h_eout + L.H, L.z_ein, L.z_eout, L.z_ein + L.H, L.z_eout + L.Z};
   map.seg_begin[0] = 0;
   for (int i = 0; i < 8; ++i) { map.seg_begin[i + 1] = map.seg_begin[i] + counts[i]; map.dst[i] = dst[i]; }
+  return map;
+}
+
+int rb_learner_noise_job(rb_learner_t* l, int32_t which, rb_noise_job_t* out) {
+  RB_REQUIRE(l && out, "rb_learner_noise_job: NULL argument");
+  RB_REQUIRE(which >= 0 && which <= 2, "rb_learner_noise_job: which must be 0 (online), 1 (target) or 2 (both)");
+  static_assert(sizeof(NoiseJob) <= sizeof(rb_noise_job_t), "rb_noise_job_t too small");
+  NoiseJob j;
+  j.noise = which == 1 ? l->n_target : l->n_online;
+  j.noise2 = which == 2 ? l->n_target : nullptr;
+  j.map = noise_map(l->L);
+  j.seed = l->seed; j.ctr = l->noise_ctr;
+  j.nblk = (int)rb_div_up(j.map.seg_begin[8], 256); j.nets = which == 2 ? 2 : 1;
+  memset(out, 0, sizeof(*out));
+  memcpy(out, &j, sizeof(j));
+  return RB_OK;
+}
+
+int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_normals_dev, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_reset_noise: NULL handle");
+  RB_REQUIRE(which >= 0 && which <= 2, "rb_learner_reset_noise: which must be 0 (online), 1 (target) or 2 (both)");
+  RB_REQUIRE(!(which == 2 && raw_normals_dev), "rb_learner_reset_noise: injected normals need one call per net");
+  const NoiseMap map = noise_map(l->L);
   float* noise = which == 1 ? l->n_target : l->n_online;
   float* noise2 = which == 2 ? l->n_target : nullptr;
   RB_LAUNCH(k_noise, dim3((unsigned)rb_div_up(map.seg_begin[8], 256), which == 2 ? 2u : 1u), dim3(256), stream, noise, noise2,

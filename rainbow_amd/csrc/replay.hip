@@ -13,7 +13,10 @@
 // All of this is HBM-latency / HBM-bandwidth work (no GEMM shape anywhere): the frame
 // gather moves (h+n)·7056 B in and 2h·7056 B out per sample with 16-byte lanes, the tree
 // search is L dependent 4-byte loads per sample.
+#include "noise_body.h"
 #include "replay_internal.h"
+
+#include <string.h>
 
 #include <new>
 
@@ -274,7 +277,12 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                  float* weights_out) {
+                                                  float* weights_out, NoiseJob job) {
+  if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
+    const int nb = (int)blockIdx.x - 1;
+    rb_noise_body(job.noise, job.noise2, nullptr, job.map, job.seed, job.ctr, nb % job.nblk, job.nblk, nb / job.nblk, job.nets);
+    return;
+  }
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ float s_top[RB_TOP_NODES];
@@ -612,10 +620,10 @@ int rb_replay_find(rb_replay_t* r, const double* values_dev, int32_t n, float* p
   return RB_OK;
 }
 
-int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
-                     int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
-                     int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
-                     rb_stream_t stream) {
+static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
+                       int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                       int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
+                       const rb_noise_job_t* noise_job, rb_stream_t stream) {
   RB_REQUIRE(r && tree_idx_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev,
              "rb_replay_sample: NULL argument");
   RB_REQUIRE(batch >= 1 && batch <= r->max_batch, "rb_replay_sample: batch must be in [1,%d]", r->max_batch);
@@ -625,8 +633,16 @@ int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, cons
   if (threads < 256) threads = 256;   // enough lanes to stage the 16 KB tree top into LDS in one sweep
   // weights ** -beta: python float exponent is cast to float32 by numpy (NEP 50 weak scalar)
   const float neg_beta = (float)(-priority_weight);
-  RB_LAUNCH(k_sample, dim3(1), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-            r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev);
+  NoiseJob job;
+  memset(&job, 0, sizeof(job));
+  unsigned blocks = 1;
+  if (noise_job) {
+    memcpy(&job, noise_job, sizeof(job));
+    RB_REQUIRE(job.noise && job.ctr && job.nblk > 0 && job.nets >= 1, "rb_replay_sample_fused_noise: empty noise job");
+    blocks += (unsigned)(job.nblk * job.nets);
+  }
+  RB_LAUNCH(k_sample, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+            r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job);
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
     RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win,
@@ -634,6 +650,23 @@ int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, cons
     RB_LAUNCH_CHECK();
   }
   return RB_OK;
+}
+
+int rb_replay_sample(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
+                     int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                     int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
+                     rb_stream_t stream) {
+  return sample_impl(r, batch, priority_weight, unit_uniforms_dev, max_attempts, tree_idx_dev, states_dev, next_states_dev,
+                     actions_dev, returns_dev, nonterminals_dev, weights_dev, nullptr, stream);
+}
+
+int rb_replay_sample_fused_noise(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
+                                 int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                                 int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
+                                 const rb_noise_job_t* noise_job, rb_stream_t stream) {
+  RB_REQUIRE(noise_job != nullptr, "rb_replay_sample_fused_noise: noise_job is NULL");
+  return sample_impl(r, batch, priority_weight, unit_uniforms_dev, max_attempts, tree_idx_dev, states_dev, next_states_dev,
+                     actions_dev, returns_dev, nonterminals_dev, weights_dev, noise_job, stream);
 }
 
 static int rb_update_impl(rb_replay_t* r, const int64_t* tree_idx_dev, const float* values_dev, int32_t n,

@@ -147,11 +147,12 @@ class ReplayMemory:
             L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(self._bufs)))
         return self._bufs.frames_dev, self._bufs.window_dev, int(self._bufs.window_len)
 
-    def sample_device(self, batch_size, unit_uniforms=None, gather=True):
+    def sample_device(self, batch_size, unit_uniforms=None, gather=True, noise_job=None):
         """Device-resident batch: dict(tree_idxs i64[B], states u8[B,h,84,84], next_states u8, actions i64[B],
         returns f32[B], nonterminals f32[B], weights f32[B]).  Asynchronous.  unit_uniforms (float64 device
         tensor [attempts,B]) injects the sampler's random numbers for parity tests.  gather=False skips the
-        frame-stack copies (states/next_states are then stale): the consumer reads the ring via frame_source()."""
+        frame-stack copies (states/next_states are then stale): the consumer reads the ring via frame_source().
+        noise_job (rainbow_amd._lib.NoiseJob from the learner) lets the launch also carry the noise resample."""
         o = self._buffers(batch_size)
         if not torch.cuda.is_current_stream_capturing():
             self._sync_beta()
@@ -159,11 +160,13 @@ class ReplayMemory:
         if unit_uniforms is not None:
             self._uu = unit_uniforms.to(device=self.device, dtype=torch.float64).contiguous()
             uu_ptr, attempts = self._uu.data_ptr(), int(self._uu.shape[0])
-        L.check(self._lib, self._lib.rb_replay_sample(
-            self._h, int(batch_size), float(self.priority_weight), uu_ptr, attempts, o["tree_idxs"].data_ptr(),
-            o["states"].data_ptr() if gather else None, o["next_states"].data_ptr() if gather else None,
-            o["actions"].data_ptr(), o["returns"].data_ptr(),
-            o["nonterminals"].data_ptr(), o["weights"].data_ptr(), self._stream()))
+        args = (self._h, int(batch_size), float(self.priority_weight), uu_ptr, attempts, o["tree_idxs"].data_ptr(),
+                o["states"].data_ptr() if gather else None, o["next_states"].data_ptr() if gather else None,
+                o["actions"].data_ptr(), o["returns"].data_ptr(), o["nonterminals"].data_ptr(), o["weights"].data_ptr())
+        if noise_job is not None:
+            L.check(self._lib, self._lib.rb_replay_sample_fused_noise(*args, C.byref(noise_job), self._stream()))
+        else:
+            L.check(self._lib, self._lib.rb_replay_sample(*args, self._stream()))
         return o
 
     def sample(self, batch_size):
