@@ -236,6 +236,16 @@ int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const i
  * max_norm/(norm+1e-6) when that is < 1.  norm_dev (f32[1], may be NULL) gets ||g||. */
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream);
 
+/* clip_grad_norm_ + optimiser.step() (agent.py:97-98, optimiser built at agent.py:46) in one pass
+ * over the flat buffers: the clip coefficient is applied to the gradient in registers on its way
+ * into torch.optim.Adam's update (amsgrad off, weight_decay 0).  exp_avg_dev / exp_avg_sq_dev:
+ * caller-owned f32[n_params] moment buffers (zero before step 1); step: 1-based step number for
+ * the bias corrections.  grads_dev is rewritten (scaled) only when the norm exceeds max_norm,
+ * as clip_grad_norm_ would leave it.  norm_dev (f32[1], may be NULL) gets ||g||.            */
+int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg_dev, float* exp_avg_sq_dev,
+                         double lr, double beta1, double beta2, double eps, int64_t step,
+                         float* norm_dev, rb_stream_t stream);
+
 /* Fused priority write-back (agent.py:100 -> memory.py:157-159).  With a sink set, rb_learner_learn*
  * itself applies  sum_tree[tree_idx] = loss^w  (+ ancestor sums, max) to `replay` as one extra
  * workgroup of its backward launch, i.e. off the step's critical path.  tree_idx_dev must be the

@@ -18,6 +18,7 @@ clip.  Enabled automatically when torch.distributed is initialised
 import ctypes as C
 import math
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -35,6 +36,41 @@ def _query_layout(lib, cfg, fn):
     descs = (L.TensorDesc * n.value)()
     L.check(lib, fn(C.byref(cfg), descs, C.byref(n)))
     return [(d.name.decode(), int(d.offset), tuple(d.shape[i] for i in range(d.ndim))) for d in descs[:n.value]]
+
+
+class _FlatAdam(torch.optim.Adam):
+    """torch.optim.Adam over the single flat parameter tensor (agent.py:46).  The state is ordinary Adam state
+    (step / exp_avg / exp_avg_sq, so state_dict() and load_state_dict() work as usual), but step() runs the library's
+    one-pass kernel (rb_learner_clip_adam), optionally with clip_grad_norm_ folded in (max_norm)."""
+
+    def __init__(self, agent, **kw):
+        super().__init__([agent.params], **kw)
+        self._agent = weakref.ref(agent)
+        p = agent.params
+        self.state[p] = dict(step=torch.tensor(0.0, dtype=torch.float32),
+                             exp_avg=torch.zeros_like(p, memory_format=torch.preserve_format),
+                             exp_avg_sq=torch.zeros_like(p, memory_format=torch.preserve_format))
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=float("inf")):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        ag = self._agent()
+        if ag is None:
+            raise RuntimeError("the Agent that owns this optimiser is gone")
+        g = self.param_groups[0]
+        if g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"]:
+            raise NotImplementedError("rb_learner_clip_adam implements plain Adam (the reference's configuration)")
+        st = self.state[g["params"][0]]
+        st["step"] += 1
+        b1, b2 = g["betas"]
+        L.check(ag._lib, ag._lib.rb_learner_clip_adam(
+            ag._h, float(max_norm), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1),
+            float(b2), float(g["eps"]), int(st["step"].item()),
+            ag._norm.data_ptr() if math.isfinite(max_norm) else None, ag._stream()))
+        return loss
 
 
 class Agent:
@@ -95,10 +131,13 @@ class Agent:
         kw = dict(lr=args.learning_rate, eps=args.adam_eps)
         if self._use_graph:
             kw["capturable"] = True    # the step counter must live on the device to be replayable
-        try:
-            self.optimiser = torch.optim.Adam([self.params], fused=True, **kw)
-        except (TypeError, RuntimeError):
-            self.optimiser = torch.optim.Adam([self.params], **kw)
+        if self._use_graph or os.environ.get("RAINBOW_AMD_FUSED_ADAM", "1") != "1":
+            try:
+                self.optimiser = torch.optim.Adam([self.params], fused=True, **kw)
+            except (TypeError, RuntimeError):
+                self.optimiser = torch.optim.Adam([self.params], **kw)
+        else:
+            self.optimiser = _FlatAdam(self, **kw)                   # agent.py:46
         self._graph = None
         self._graph_mem = None
         self._eager_steps = 0
@@ -316,9 +355,12 @@ class Agent:
         if self._world > 1:   # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
             rdist.average_gradients(self.grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
-        L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
-                                                          self._stream()))                # agent.py:97
-        self.optimiser.step()                                                              # agent.py:98
+        if isinstance(self.optimiser, _FlatAdam):
+            self.optimiser.step(max_norm=float(self.norm_clip))                            # agent.py:97-98, one pass
+        else:
+            L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
+                                                              self._stream()))            # agent.py:97
+            self.optimiser.step()                                                          # agent.py:98
         if overlap:
             torch.cuda.current_stream(self.device).wait_event(self._ev_upd)
         elif device_mem:

@@ -510,6 +510,69 @@ __global__ __launch_bounds__(256) void k_clip_scale(float* g, int64_t n, const f
       g[i] *= coef;
 }
 
+// clip_grad_norm_ + Adam in ONE pass over the flat buffers (agent.py:97-98).  Every block re-sums the partial list in the
+// same fixed order (so all blocks agree on the clip coefficient) while its first parameter/gradient/moment loads are
+// already in flight, then applies torch.optim.Adam's single-tensor update:
+//   g' = g * clamp(max_norm / (norm + 1e-6), max=1)                       (clip_grad_norm_)
+//   m  = lerp(m, g', 1-b1);  v = v*b2 + (1-b2)*g'*g'
+//   p += -(lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// The scaled gradient is stored back only when the clip actually bites (the reference leaves .grad scaled).
+struct ClipAdamArgs {
+  float* p; float* g; float* m; float* v;
+  int64_t n;
+  const float* part; int nparts;
+  float max_norm; float* norm_out;
+  float w1, b2, w2, neg_step_size, bc2_sqrt, eps;
+};
+constexpr int RB_ADAM_UNROLL = 4;
+__device__ __forceinline__ void rb_adam_elem(float& p, float& g, float& m, float& v, float coef, const ClipAdamArgs& a) {
+  g = g * coef;
+  m = fmaf(a.w1, g - m, m);
+  v = v * a.b2 + a.w2 * g * g;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p = p + a.neg_step_size * (m / denom);
+}
+__global__ __launch_bounds__(256) void k_clip_adam(ClipAdamArgs a) {
+  __shared__ float s_red[16];
+  const int64_t n4 = a.n >> 2;
+  const int64_t base = (int64_t)blockIdx.x * (256 * RB_ADAM_UNROLL) + threadIdx.x;
+  float4 P[RB_ADAM_UNROLL], G[RB_ADAM_UNROLL], M[RB_ADAM_UNROLL], V[RB_ADAM_UNROLL];
+#pragma unroll
+  for (int u = 0; u < RB_ADAM_UNROLL; ++u) {
+    int64_t i = base + u * 256;
+    if (i >= n4) i = n4 > 0 ? n4 - 1 : 0;          // clamped load (always legal), masked store
+    P[u] = rb_ld4(a.p + 4 * i); G[u] = rb_ld4(a.g + 4 * i); M[u] = rb_ld4(a.m + 4 * i); V[u] = rb_ld4(a.v + 4 * i);
+  }
+  float acc = 0.0f;
+  for (int i = (int)threadIdx.x; i < a.nparts; i += 256) acc += a.part[i];
+  acc = rb_block_sum(acc, s_red);
+  const float total = sqrtf(acc);
+  float coef = a.max_norm / (total + 1e-6f);
+  if (coef > 1.0f) coef = 1.0f;                                    // clamp(max=1.0)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) *a.norm_out = total;
+#pragma unroll
+  for (int u = 0; u < RB_ADAM_UNROLL; ++u) {
+    const int64_t i = base + u * 256;
+    if (i >= n4) continue;
+    rb_adam_elem(P[u].x, G[u].x, M[u].x, V[u].x, coef, a);
+    rb_adam_elem(P[u].y, G[u].y, M[u].y, V[u].y, coef, a);
+    rb_adam_elem(P[u].z, G[u].z, M[u].z, V[u].z, coef, a);
+    rb_adam_elem(P[u].w, G[u].w, M[u].w, V[u].w, coef, a);
+    rb_st4(a.p + 4 * i, P[u]); rb_st4(a.m + 4 * i, M[u]); rb_st4(a.v + 4 * i, V[u]);
+    if (coef < 1.0f) rb_st4(a.g + 4 * i, G[u]);
+  }
+  // tail (n % 4 elements): last block's first threads
+  if (blockIdx.x == gridDim.x - 1) {
+    const int64_t t = (n4 << 2) + threadIdx.x;
+    if (t < a.n) {
+      float p = a.p[t], g = a.g[t], m = a.m[t], v = a.v[t];
+      rb_adam_elem(p, g, m, v, coef, a);
+      a.p[t] = p; a.m[t] = m; a.v[t] = v;
+      if (coef < 1.0f) a.g[t] = g;
+    }
+  }
+}
+
 // ========================================================================= host ==
 static int pick_splits(int64_t tiles, int ksteps, int64_t target_blocks) {
   int64_t s = target_blocks / (tiles > 0 ? tiles : 1);
@@ -1251,6 +1314,36 @@ int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_st
   l->norm_slots = 0;   // consumed
   RB_LAUNCH(k_clip_scale, dim3((unsigned)nblocks), dim3(256), stream, l->grads, n, (const float*)l->norm_part, nparts,
             max_norm, norm_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                         double beta2, double eps, int64_t step, float* norm_dev, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_clip_adam: NULL handle");
+  RB_REQUIRE(exp_avg != nullptr && exp_avg_sq != nullptr, "rb_learner_clip_adam: NULL moment buffer");
+  RB_REQUIRE(step >= 1, "rb_learner_clip_adam: step is 1-based");
+  const int64_t n = l->L.n_params;
+  int nparts = l->norm_slots;
+  if (!(max_norm < INFINITY) && norm_dev == nullptr) {
+    nparts = 0;        // plain optimiser.step(): no clip, nobody wants the norm
+  } else if (nparts <= 0) {   // gradient came from the fallback path or was modified since (all-reduce): one pass over it
+    nparts = (int)rb_div_up(n, 256 * 16);
+    if (nparts > 1024) nparts = 1024;
+    RB_LAUNCH(k_sumsq, dim3((unsigned)nparts), dim3(256), stream, (const float*)l->grads, n, l->norm_part);
+    RB_LAUNCH_CHECK();
+  }
+  l->norm_slots = 0;   // consumed
+  ClipAdamArgs a;
+  a.p = l->p_online; a.g = l->grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+  a.part = l->norm_part; a.nparts = nparts; a.max_norm = max_norm; a.norm_out = norm_dev;
+  // scalars exactly as torch.optim.adam._single_tensor_adam forms them (python doubles, rounded once to f32 by the op)
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
+  a.neg_step_size = (float)(-(lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)eps;
+  const int64_t n4 = n >> 2;
+  int64_t nblocks = rb_div_up(n4 > 0 ? n4 : 1, 256 * RB_ADAM_UNROLL);
+  RB_LAUNCH_T("clip_adam:k_clip_adam", k_clip_adam, dim3((unsigned)nblocks), dim3(256), stream, a);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }

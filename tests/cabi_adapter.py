@@ -196,7 +196,9 @@ def query_layout(lib, cfg, fn):
 
 
 class CAbiLearnAdapter:
-    """Drives rb_learner_* exactly like rainbow_amd.agent.Agent does (learn -> clip -> torch Adam)."""
+    """Drives rb_learner_* exactly like rainbow_amd.agent.Agent does: learn -> fused clip+Adam (default), or
+    learn -> clip -> torch Adam (fused_adam = False: the hipGraph path of the Agent and the pre-fusion behaviour)."""
+    fused_adam = True
 
     def __init__(self, lib, mem, name):
         import torch
@@ -250,6 +252,9 @@ class CAbiLearnAdapter:
         p.grad = self._as_torch(self.grads)
         self.param_t = p
         self.opt = self.torch.optim.Adam([p], lr=self.hy["lr"], eps=self.hy["adam_eps"])   # agent.py:46
+        self.adam_m = m.upload(np.zeros(self.n_params, dtype=np.float32))
+        self.adam_v = m.upload(np.zeros(self.n_params, dtype=np.float32))
+        self.adam_t = 0
         m.sync()
 
     def reset_noise_online(self, raw):
@@ -279,10 +284,18 @@ class CAbiLearnAdapter:
             m.sync()
             self.grad_hook(self._as_torch(self.grads))
             L.check(self.lib, self.lib.rb_learner_grads_modified(self.h))
-        L.check(self.lib, self.lib.rb_learner_clip_grad(self.h, self.hy["norm_clip"], m.ptr(norm), m.stream))
-        m.sync()
-        grads = self._unflat(m.download(self.grads))
-        self.opt.step()                                                                            # agent.py:98
+        if self.fused_adam:
+            self.adam_t += 1
+            L.check(self.lib, self.lib.rb_learner_clip_adam(self.h, self.hy["norm_clip"], m.ptr(self.adam_m),
+                                                            m.ptr(self.adam_v), self.hy["lr"], 0.9, 0.999,
+                                                            self.hy["adam_eps"], self.adam_t, m.ptr(norm), m.stream))
+            m.sync()
+            grads = self._unflat(m.download(self.grads))
+        else:
+            L.check(self.lib, self.lib.rb_learner_clip_grad(self.h, self.hy["norm_clip"], m.ptr(norm), m.stream))
+            m.sync()
+            grads = self._unflat(m.download(self.grads))
+            self.opt.step()                                                                        # agent.py:98
         m.sync()
         return dict(loss=m.download(loss), grad_norm=float(m.download(norm)[0]), grads=grads)
 

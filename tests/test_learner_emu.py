@@ -130,3 +130,27 @@ def test_long_history_uses_generic_convs_with_streamed_fc(emu):
         ad.close()
     finally:
         del scenarios.LEARN_CONFIGS["_hist5"]
+
+
+@pytest.mark.parametrize("norm_clip", [10.0, 0.02])
+def test_fused_clip_adam_equals_clip_then_torch_adam(emu, norm_clip):
+    """rb_learner_clip_adam (one pass) against rb_learner_clip_grad followed by torch.optim.Adam (agent.py:97-98),
+    with the clip idle (10.0) and biting (0.02: the gradient is rewritten in place, as clip_grad_norm_ leaves it)."""
+    name = "atoms21"
+    traces = []
+    for fused in (False, True):
+        ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+        ad.fused_adam = fused
+        ad.hy = dict(ad.hy, norm_clip=norm_clip)
+        traces.append(scenarios.learn_scenario(ad, name, O))
+        ad.close()
+    a, b = traces
+    bites = False
+    for k in a:
+        if "_param/" in k:        # summaries of the post-step parameters: same tolerance as against the reference
+            np.testing.assert_allclose(b[k], a[k], rtol=0, atol=2e-7, err_msg=k)
+        elif k.startswith("s0_"):  # before the first optimiser step both runs are the same computation
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+        if k.endswith("_grad_norm") and float(a[k]) > norm_clip:
+            bites = True
+    assert bites == (norm_clip < 1.0)
