@@ -15,7 +15,8 @@ non-uniform priorities.  Multi-GPU = independent replicas (own replay, own noise
 gradient all-reduce per step; weak scaling (per-GPU work fixed).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — dominant kernel, timed live with HIP events on its own stream (rb_profile_*)
+  roofline     — dominant kernel (clip+Adam pass), timed live with HIP events on its own stream (rb_profile_*);
+                 roofline_others: the hidden-layer forward / backward streams, timed the same way
   cpu_baseline — the CPU oracle (a port of the reference's algorithm: numpy replay + torch-CPU
                  learner) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
 """
@@ -82,13 +83,15 @@ def fill_replay(mem, capacity, actions, seed):
     torch.cuda.synchronize(dev)
 
 
-def kernel_table(cfg):
+def kernel_table(cfg, n_params):
     """Algorithmic work per launch of the candidate dominant kernels."""
     B, A = cfg["batch_size"], cfg["actions"]
     H = cfg["hidden_size"]
     F = 3136 if cfg["architecture"] == "canonical" else 576
     wh = 2 * H * F * 4                      # one of mu / sigma of the fused hidden layer, bytes
     return {
+        # clip + Adam over the flat buffers: reads p, g, m, v and writes p, m, v once (the step's largest kernel)
+        "clip_adam": dict(bound="hbm", work=7 * 4 * n_params, unit="GB/s"),
         # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident
         "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4 + 3 * B * 2 * H * 4 * 2, unit="GB/s"),
         # hidden layer weight grads: writes d_mu + d_sigma once
@@ -168,7 +171,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="pong-canonical-b32", choices=sorted(CONFIGS))
-    ap.add_argument("--roofline-kernel", default="fc_h_fwd")
+    ap.add_argument("--roofline-kernel", default="clip_adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
     ap.add_argument("--graph", action="store_true",
@@ -216,8 +219,8 @@ def main():
         step()
     torch.cuda.synchronize(dev)
 
-    ktab = kernel_table(cfg)
-    kname = opt.roofline_kernel if opt.roofline_kernel in ktab else "fc_h_fwd"
+    ktab = kernel_table(cfg, int(agent.params.numel()))
+    kname = opt.roofline_kernel if opt.roofline_kernel in ktab else "clip_adam"
     lib.rb_profile_select(kname.encode())
     if world > 1:
         torch.distributed.barrier()
@@ -236,6 +239,20 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # the other GB-scale kernels, each timed the same way in a short pass of its own AFTER the timed region
+    others = {}
+    for other in ktab:
+        if other == kname:
+            continue
+        lib.rb_profile_select(other.encode())
+        for _ in range(min(200, opt.steps)):
+            step()
+        torch.cuda.synchronize(dev)
+        o_ms, o_n = C.c_double(0), C.c_int64(0)
+        lib.rb_profile_read(C.byref(o_ms), C.byref(o_n))
+        lib.rb_profile_select(None)
+        if o_n.value > 0:
+            others[other] = (o_ms.value / o_n.value * 1e-3, o_n.value)
     hdr = mem._header()
     assert hdr.last_status == 0, "device sampler failed"
     assert bool(torch.isfinite(agent._loss).all()), "non-finite loss"
@@ -274,13 +291,17 @@ def main():
                 achieved, peak = k["work"] / avg_s / 1e9, HBM_PEAK_GBS
             else:
                 achieved, peak = k["work"] / avg_s / 1e12, F32_MFMA_PEAK_TF
-            traffic = None
             pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")   # rocprofv3 --pmc passes (tools/gpu_pmc.sh), per launch
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc)) if os.path.exists(pmc) else {}
             out["roofline"] = {"kernel": kname, "bound": k["bound"], "achieved": achieved, "peak": peak, "unit": k["unit"],
-                               "frac": achieved / peak, "traffic": traffic, "avg_us": avg_s * 1e6,
-                               "launches": launches.value, "algorithmic_work_per_launch": k["work"]}
+                               "frac": achieved / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
+                               "avg_us": avg_s * 1e6, "launches": launches.value,
+                               "algorithmic_work_per_launch": k["work"]}
+            out["roofline_others"] = [
+                {"kernel": o, "bound": "hbm", "achieved": ktab[o]["work"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": ktab[o]["work"] / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get(o, {}).get("hbm_bytes_per_launch"),
+                 "avg_us": t * 1e6, "launches": n, "algorithmic_work_per_launch": ktab[o]["work"]}
+                for o, (t, n) in others.items()]
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(cfg)
         print(json.dumps(out))

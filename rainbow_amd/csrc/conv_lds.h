@@ -255,6 +255,14 @@ struct ConvLdsDxArgs {
   const float* dy;       // [B][cout][P]
   const float* x_act;    // [NI][cin][IP] (rows [0,B))
   float* dx;             // [B][cin][IP]
+  // Last conv layer only: dY is not materialised yet — it is (dy_mask > 0) * sum_s dy_part[s][img][e] (the split
+  // partials of the hidden layer's input gradient, summed in slice order).  Every workgroup rebuilds its image while
+  // staging; the (x = 0, y = 0) workgroup of each image also writes it to dy_out for the weight-gradient launch.
+  const float* dy_part;  // NULL: plain dy
+  const float* dy_mask;  // [B][cout*P] the layer's own (ReLU) output
+  float* dy_out;         // [B][cout*P]
+  int dy_splits;
+  int64_t dy_stride;     // elements between partial slices (B * cout * P)
 };
 
 template <class G, int NT, int COUT>
@@ -285,7 +293,36 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   if (n0 >= npos) return;                                            // block-uniform
 
   // ---- stage dY image, the phase's weight slab transposed to [k'][c], tap tables
-  {
+  if (a.dy_part) {
+    const int n = a.cout * G::P;
+    const int64_t row = (int64_t)img * n;
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+    for (int e0 = 0; e0 < n; e0 += 4 * RB_CONV_THREADS) {              // 4 elements x splits loads in flight per thread
+      float acc[4], mk[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + i * RB_CONV_THREADS + t;
+        acc[i] = 0.0f;
+        mk[i] = e < n ? a.dy_mask[row + e] : 0.0f;
+      }
+#pragma unroll 5
+      for (int sl = 0; sl < a.dy_splits; ++sl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          if (e < n) acc[i] += a.dy_part[(int64_t)sl * a.dy_stride + row + e];
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + i * RB_CONV_THREADS + t;
+        if (e < n) {
+          const float v = mk[i] > 0.0f ? acc[i] : 0.0f;
+          s_dy[e] = v;
+          if (writer) a.dy_out[row + e] = v;
+        }
+      }
+    }
+  } else {
     const float* src = a.dy + (int64_t)img * a.cout * G::P;
     const int n = a.cout * G::P;
     for (int e0 = 0; e0 < n; e0 += 12 * RB_CONV_THREADS) {             // 12 loads in flight per thread

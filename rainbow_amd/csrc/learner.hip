@@ -138,6 +138,7 @@ struct rb_learner {
   float* zero_noise;    // [n_noise] zeros (eval mode, model.py:46)
   float* norm_part;     // sum-of-squares partials: [0,1024) k_sumsq; fused producers use [0, norm_slots)
   int norm_conv_base;   // first slot of the conv reduction blocks
+  int dfeat_pending;    // > 0: dact[last conv] is still `dfeat_pending` split partials in dfeat_part (see ConvLdsDxArgs)
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   int hs, xs, ws[3];    // split counts
@@ -681,7 +682,16 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, ht16};
     a.out = l->h; a.out_blocked = l->h_b; a.ld_out = 2 * L.H; a.rows_total = NI; a.relu = 1;
     const unsigned mch32 = (unsigned)rb_div_up(m_max, RB_FWD2_MROWS);
-    RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2, dim3((unsigned)(2 * ht16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, a);
+    static const int abl = getenv("RB_FWD2_ABLATE") ? atoi(getenv("RB_FWD2_ABLATE")) : 0;   // tools/gpu_ablate.sh only
+    const dim3 hg((unsigned)(2 * ht16), 1, 2 * mch32), hb(64 * RB_NL_FWD_WAVES);
+    switch (abl) {
+      case 1: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<1>, hg, hb, stream, a); break;
+      case 2: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<2>, hg, hb, stream, a); break;
+      case 3: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<3>, hg, hb, stream, a); break;
+      case 4: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<4>, hg, hb, stream, a); break;
+      case 7: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<7>, hg, hb, stream, a); break;
+      default: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<0>, hg, hb, stream, a); break;
+    }
     RB_LAUNCH_CHECK();
     // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
     NlFwd2Args z;
@@ -693,7 +703,7 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
     z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
-    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2, dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
     RB_LAUNCH_CHECK();
     return RB_OK;
   }
@@ -768,6 +778,12 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     ConvLdsDxArgs a;
     a.cin = c.cin; a.cout = c.cout;
     a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
+    a.dy_part = nullptr; a.dy_mask = nullptr; a.dy_out = nullptr; a.dy_splits = 0; a.dy_stride = 0;
+    if (layer == L.nconv - 1 && l->dfeat_pending > 0) {   // fold the hidden layer's split-partial finish into the staging
+      a.dy_part = l->dfeat_part; a.dy_mask = l->act[layer]; a.dy_out = l->dact[layer];
+      a.dy_splits = l->dfeat_pending; a.dy_stride = (int64_t)L.B * L.F;
+      l->dfeat_pending = 0;
+    }
     constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
     constexpr int NT_ALL = (NPOS + 31) / 32;
     // few images at batch 32: spread each phase's positions over several workgroups (weights are re-staged from L2)
@@ -961,7 +977,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   const int B = L.B, NI = 3 * B;
   // split-K factors: aim for >= ~2 workgroups per CU on the 256-CU part
   const char* generic_only = getenv("RB_GENERIC_GEMM_ONLY");   // A/B switch: force the gemm_core fallback
-  l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
+  l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
@@ -1217,10 +1233,17 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     }
     l->sink_done = (up.enabled && !side) ? 1 : 0;
     RB_LAUNCH_CHECK();
-    const int64_t total = (int64_t)B * L.F;
-    RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
-              hsplits, total, feat, l->dact[L.nconv - 1]);
-    RB_LAUNCH_CHECK();
+    // Folding this finish into the last conv layer's input-gradient staging (ConvLdsDxArgs::dy_part) is implemented but
+    // measured slower (every workgroup of an image re-sums the partials: 32 us vs 13.2 + 4.7), so it stays opt-in.
+    static const bool fold = getenv("RB_FOLD_DFEAT") && getenv("RB_FOLD_DFEAT")[0] == '1';
+    if (fold && l->fast_conv && !side && L.nconv > 1 && feat == l->act[L.nconv - 1]) {
+      l->dfeat_pending = hsplits;     // consumed by the last conv layer's input-gradient launch (conv_bwd)
+    } else {
+      const int64_t total = (int64_t)B * L.F;
+      RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
+                hsplits, total, feat, l->dact[L.nconv - 1]);
+      RB_LAUNCH_CHECK();
+    }
   } else {
   l->norm_slots = 0;
   l->sink_done = 0;
@@ -1265,6 +1288,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (l->fast_conv && !side) {
     for (int layer = L.nconv - 1; layer > 0; --layer)                 // the input-gradient chain first ...
       if ((rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;
+    RB_REQUIRE(l->dfeat_pending == 0, "learn: the hidden layer's input-gradient partials were never finished");
     if ((rc = conv_dw_all(l, stream)) != RB_OK) return rc;            // ... then every weight gradient in one launch
   } else {
     for (int layer = L.nconv - 1; layer >= 0; --layer) {

@@ -71,8 +71,11 @@ struct NlFwd2Args {
 
 // grid = (16-row tiles, 1, 2 * m-chunks of 32 rows), block = 512
 #define RB_FWD2_MROWS 32
+#define RB_FWD2_KMAX 4096          // eps_in slice staged in LDS (host checks K <= this)
+template <int ABL>   // ablation bits for tools/gpu_ablate.sh: 1 no weight refill, 2 no activation refill, 4 no MFMA (0 = product)
 __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) {
   __shared__ float s_red[RB_NL_FWD_WAVES][8][64];
+  __shared__ __attribute__((aligned(16))) float s_ein[RB_FWD2_KMAX];
   const int lane = rb_lane(), wave = rb_wave();
   const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
   const int M = a.m_cnt[net];
@@ -97,7 +100,6 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
   const float* mu_p = w.mu + (int64_t)row * K + 4 * q;
   const float* sg_p = w.sigma + (int64_t)row * K + 4 * q;
   const float eo = w.eout[row];
-  const float* ein_p = w.ein + grp.ein_off + 4 * q;
   const float* x_p[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -114,16 +116,23 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
     for (int e = 0; e < 4; ++e) acc[mt][e] = 0.0f;
 
   // Software pipeline.  Weights come from HBM (latency ~2 us under load), so FOUR 32-wide k blocks of mu/sigma
-  // (16 KB per wave) are kept in flight in a statically indexed register ring; activations / eps_in come from
-  // L2/L1 one block ahead.  Every load is UNCONDITIONAL (out-of-range blocks re-read the wave's last chunk and are
-  // multiplied by a zero mask): a branch around a load would make the outstanding-load count unknown to the
-  // compiler, which then drains the whole queue (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
+  // (16 KB per wave) are kept in flight in a statically indexed register ring.  The activations ride in the SAME ring
+  // at the SAME depth: vector-memory loads retire in issue order (one vmcnt counter), so an activation load issued
+  // one block ahead would sit behind the weight loads issued four blocks ahead and every wait for it would drain
+  // the whole weight prefetch (that was the first version: 30 us, effective depth 1).  eps_in is staged in LDS once
+  // (its reads count on lgkmcnt, not vmcnt).  Every load is UNCONDITIONAL (out-of-range blocks re-read the wave's last
+  // chunk and are multiplied by a zero mask): a branch around a load would make the outstanding-load count unknown
+  // to the compiler, which then drains the whole queue (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
   constexpr int RING = 4;
-  float4 r_mu[RING][2], r_sg[RING][2];
-  float4 c_e[2], c_x[2][2], n_e[2], n_x[2][2];
+  float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][2];
   const int c_last = wc1 > wc0 ? wc1 - 1 : (nchunks > 0 ? nchunks - 1 : 0);
   auto chunk_of = [&](int sc, int h) { const int cc = wc0 + 2 * sc + h; return cc < wc1 ? cc : c_last; };
   auto live = [&](int sc, int h) { return (wc0 + 2 * sc + h < wc1) ? 1.0f : 0.0f; };
+  {
+    const float* ein_g = w.ein + grp.ein_off;
+    for (int k4 = (int)threadIdx.x; k4 < (K >> 2); k4 += 64 * RB_NL_FWD_WAVES)
+      *reinterpret_cast<float4*>(&s_ein[4 * k4]) = rb_ld4(ein_g + 4 * k4);
+  }
 #pragma unroll
   for (int d = 0; d < RING; ++d)
 #pragma unroll
@@ -131,14 +140,10 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
       const int cc = chunk_of(d, h);
       r_mu[d][h] = rb_ld4(mu_p + cc * 16);
       r_sg[d][h] = rb_ld4(sg_p + cc * 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cc * xs);
     }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int cc = chunk_of(0, h);
-    n_e[h] = rb_ld4(ein_p + cc * 16);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) n_x[h][mt] = rb_ld4(x_p[mt] + cc * xs);
-  }
+  __syncthreads();                                       // eps_in visible
   const int nsc_pad = (nsc + RING - 1) / RING * RING;
   for (int sc0 = 0; sc0 < nsc_pad; sc0 += RING) {
 #pragma unroll
@@ -147,32 +152,42 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
       float4 w4[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        c_e[h] = n_e[h];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) c_x[h][mt] = n_x[h][mt];
+        const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[chunk_of(sc, h) * 16 + 4 * q]);
         const float lv = live(sc, h);
-        w4[h] = rb_noisy4(r_mu[d][h], r_sg[d][h], eo, c_e[h]);
+        w4[h] = rb_noisy4(r_mu[d][h], r_sg[d][h], eo, e4);
         w4[h].x *= lv; w4[h].y *= lv; w4[h].z *= lv; w4[h].w *= lv;
       }
+      if constexpr (!(ABL & 1)) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                      // refill this ring slot (block sc + RING), fetch x of block sc + 1
-        const int cw = chunk_of(sc + RING, h);
-        r_mu[d][h] = rb_ld4(mu_p + cw * 16);
-        r_sg[d][h] = rb_ld4(sg_p + cw * 16);
-        const int cx = chunk_of(sc + 1, h);
-        n_e[h] = rb_ld4(ein_p + cx * 16);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) n_x[h][mt] = rb_ld4(x_p[mt] + cx * xs);
+        for (int h = 0; h < 2; ++h) {                    // refill the weight half of this ring slot (block sc + RING)
+          const int cw = chunk_of(sc + RING, h);
+          r_mu[d][h] = rb_ld4(mu_p + cw * 16);
+          r_sg[d][h] = rb_ld4(sg_p + cw * 16);
+        }
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          acc[mt] = rb_mfma16(c_x[h][mt].x, w4[h].x, acc[mt]);
-          acc[mt] = rb_mfma16(c_x[h][mt].y, w4[h].y, acc[mt]);
-          acc[mt] = rb_mfma16(c_x[h][mt].z, w4[h].z, acc[mt]);
-          acc[mt] = rb_mfma16(c_x[h][mt].w, w4[h].w, acc[mt]);
+          if constexpr (ABL & 4) {
+            acc[mt][0] += r_x[d][h][mt].x * w4[h].x; acc[mt][1] += r_x[d][h][mt].y * w4[h].y;
+            acc[mt][2] += r_x[d][h][mt].z * w4[h].z; acc[mt][3] += r_x[d][h][mt].w * w4[h].w;
+          } else {
+            acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4[h].x, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4[h].y, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4[h].z, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4[h].w, acc[mt]);
+          }
         }
+      if constexpr (!(ABL & 2)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                    // ... and its activation half, once the MFMAs have read it
+          const int cw = chunk_of(sc + RING, h);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cw * xs);
+        }
+      }
+      RB_SCHED_FENCE();                                  // keep this slot's refill here, not at the end of the loop
     }
   }
 #pragma unroll

@@ -57,6 +57,15 @@ __device__ __forceinline__ rb_f32x4 rb_mfma16(float a, float b, rb_f32x4 c) {
 
 __device__ __forceinline__ int rb_mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Instruction-scheduler fence: the compiler may not move anything across it.  Used to pin the ISSUE ORDER of the
+// prefetch loads in software-pipelined loops (left alone, the machine scheduler sinks all refill loads of an unrolled
+// ring to the end of the loop body, which turns the ring into "burst, stall, compute").
+#if defined(RB_HOST_INTERP)
+#define RB_SCHED_FENCE() ((void)0)
+#else
+#define RB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // 16-byte global/LDS accesses (pointers must be 16-byte aligned)
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -24,9 +24,9 @@ def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     res = {}
-    tags = {"k_nl_fwd2": "fc_h_fwd", "k_nl_bwd": "fc_h_bwd"}
+    tags = {"k_clip_adam": "clip_adam", "k_nl_fwd2": "fc_h_fwd", "k_nl_bwd": "fc_h_bwd"}
     for kern, tag in tags.items():
-        keys = [k for k in fetch if k[0] == kern]
+        keys = [k for k in fetch if kern in k[0]]
         if not keys:
             continue
         big = max(keys, key=lambda k: k[1])          # the hidden-layer launch is the larger grid of the two
