@@ -212,6 +212,13 @@ int rb_learner_noise_job(rb_learner_t* l, int32_t which, rb_noise_job_t* out);
  * noisy=0 is online_net.eval() (mu only, model.py:46).                              */
 int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_dev,
                    float* q_dev, rb_stream_t stream);
+/* The same for n states at once (vectorised actors; the reference acts on one state per call,
+ * main.py:153 — this is that call batched): states f32[n][history][7056],
+ * 1 <= n <= 2*batch; actions_dev i32[n], q_dev f32[n] (either may be NULL).  action_dev /
+ * q_dev of both calls may point to pinned host memory mapped on the device, which saves the
+ * caller a device-to-host copy: the values are final once the stream has drained.         */
+int rb_learner_act_batch(rb_learner_t* l, const float* states_dev, int32_t n, int32_t noisy,
+                         int32_t* actions_dev, float* q_dev, rb_stream_t stream);
 
 /* Agent.learn minus sampling/optimiser (agent.py:66-96): three forwards, double-Q
  * select, C51 projection, weighted cross-entropy, full backward into grads_dev.

@@ -149,8 +149,9 @@ class Agent:
         self._fuse_update = os.environ.get("RAINBOW_AMD_FUSED_UPDATE", "1") == "1"
         self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
         self._norm = torch.zeros(1, dtype=torch.float32, device=d)
-        self._act_out = torch.zeros(1, dtype=torch.int32, device=d)
-        self._q_out = torch.zeros(1, dtype=torch.float32, device=d)
+        self._act_pin = torch.zeros(2 * self.batch_size, dtype=torch.int32).pin_memory()     # written by the device
+        self._q_pin = torch.zeros(2 * self.batch_size, dtype=torch.float32).pin_memory()
+        self._act_np, self._q_np = self._act_pin.numpy(), self._q_pin.numpy()
         self._side = torch.cuda.Stream(device=d)          # priority write-back overlaps clip + Adam
         self._ev_loss = torch.cuda.Event()
         self._ev_upd = torch.cuda.Event()
@@ -237,15 +238,35 @@ class Agent:
         L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 1, ptr, self._stream()))   # agent.py:74
 
     def _forward_single(self, state):
+        """One state through the act path; the action / value land in PINNED host memory the kernel writes directly
+        (no device-to-host copy): they are final after the stream synchronize below."""
         self._flush_noise()
         st = state.to(device=self.device, dtype=torch.float32).contiguous()
         L.check(self._lib, self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0,
-                                                    self._act_out.data_ptr(), self._q_out.data_ptr(), self._stream()))
+                                                    self._act_pin.data_ptr(), self._q_pin.data_ptr(), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
 
     def act(self, state):
         """agent.py:53-55: greedy action on the expected value of the (noisy) online distribution."""
         self._forward_single(state)
-        return int(self._act_out.item())
+        return int(self._act_np[0])
+
+    def act_batch(self, states):
+        """Vectorised actors: `states` f32 [n, h, 84, 84] on the device (processed 2*batch_size at a time).
+        Returns the n greedy actions (numpy int64), i.e. [self.act(s) for s in states] in one forward."""
+        self._flush_noise()
+        st = states.to(device=self.device, dtype=torch.float32).contiguous()
+        n = int(st.shape[0])
+        cap = int(self._act_np.shape[0])          # 2 * batch_size images fit the learner's activation buffers
+        out = np.empty(n, dtype=np.int64)
+        for lo in range(0, n, cap):
+            m = min(cap, n - lo)
+            L.check(self._lib, self._lib.rb_learner_act_batch(self._h, st[lo:lo + m].data_ptr(), m,
+                                                              1 if self.training else 0, self._act_pin.data_ptr(),
+                                                              self._q_pin.data_ptr(), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+            out[lo:lo + m] = self._act_np[:m]
+        return out
 
     def act_e_greedy(self, state, epsilon=0.001):
         """agent.py:58-59."""
@@ -254,7 +275,7 @@ class Agent:
     def evaluate_q(self, state):
         """agent.py:110-112."""
         self._forward_single(state)
-        return float(self._q_out.item())
+        return float(self._q_np[0])
 
     GRAPH_WARMUP = 3   # eager steps before the learn step is captured into a hipGraph
 

@@ -14,6 +14,7 @@
 #include "noise_body.h"
 #include "learner_problems.h"
 #include "noisy_linear.h"
+#include "act_path.h"
 #include "rb_common.h"
 
 #include <stdlib.h>
@@ -453,6 +454,9 @@ __global__ __launch_bounds__(256) void k_head_act(int Z, int A, const float* log
   const int t = (int)threadIdx.x;
   const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
   const int NZ = Z + A * Z;
+  row += (int)blockIdx.x;                       // batched acting: one workgroup per state, outputs indexed alike
+  if (action_out) action_out += blockIdx.x;
+  if (q_out) q_out += blockIdx.x;
   const float* lg = logits + (int64_t)row * NZ;
   for (int z = t; z < Z; z += (int)blockDim.x) {
     float acc = 0.0f;
@@ -1085,6 +1089,44 @@ int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_norm
   return RB_OK;
 }
 
+// One state through the act path (act_path.h).  RB_ERR_STATE (without touching the error string) = geometry not
+// covered, the caller falls back to the training kernels.
+static int act_forward_single(rb_learner* l, const float* state_dev, const NetPtrs& on, int noisy, hipStream_t stream) {
+  const Layout& L = l->L;
+  static const bool off = getenv("RB_ACT_PATH") && getenv("RB_ACT_PATH")[0] == '0';
+  if (off || !l->fast_fc || (L.F & 3) || (L.H & 3)) return RB_ERR_STATE;   // RB_GENERIC_GEMM_ONLY=1 also lands here
+  int rg[3];
+  for (int layer = 0; layer < L.nconv; ++layer) {   // output rows per workgroup: <= 128 positions, patch fits the LDS
+    const ConvLayer& c = L.conv[layer];
+    int r = RB_ACT_MAXPOS / c.oh;
+    if (r > c.oh) r = c.oh;
+    while (r >= 1 && (int64_t)c.cin * ((r - 1) * c.s + c.ks) * c.ih > RB_ACT_LDS) --r;
+    if (r < 1 || c.K() > RB_ACT_KMAX) return RB_ERR_STATE;
+    rg[layer] = r;
+  }
+  const float* x = state_dev;
+  for (int layer = 0; layer < L.nconv; ++layer) {
+    const ConvLayer& c = L.conv[layer];
+    ActConvArgs a;
+    a.x = x; a.w = on.conv_w[layer]; a.bias = on.conv_b[layer]; a.y = l->act[layer];
+    a.cin = c.cin; a.cout = c.cout; a.KS = c.ks; a.S = c.s; a.IH = c.ih; a.OH = c.oh; a.RG = rg[layer];
+    RB_LAUNCH(k_act_conv, dim3((unsigned)c.cout, (unsigned)rb_div_up(c.oh, rg[layer])), dim3(256), stream, a);
+    RB_LAUNCH_CHECK();
+    x = l->act[layer];
+  }
+  ActFcArgs h;
+  h.x = x; h.w = nl_h(on); h.K = L.F; h.n_rows = 2 * L.H; h.split_row = L.H; h.x_off1 = 0; h.ein_off1 = L.F;
+  h.out = l->h; h.relu = 1; h.mu_only = noisy ? 0 : 1;
+  RB_LAUNCH(k_act_fc, dim3((unsigned)rb_div_up(h.n_rows, 4)), dim3(256), stream, h);
+  RB_LAUNCH_CHECK();
+  ActFcArgs z;
+  z.x = l->h; z.w = nl_z(on); z.K = L.H; z.n_rows = L.NZ; z.split_row = L.Z; z.x_off1 = L.H; z.ein_off1 = L.H;
+  z.out = l->logits; z.relu = 0; z.mu_only = noisy ? 0 : 1;
+  RB_LAUNCH(k_act_fc, dim3((unsigned)rb_div_up(z.n_rows, 4)), dim3(256), stream, z);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
 int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_dev, float* q_dev,
                    rb_stream_t stream) {
   RB_REQUIRE(l && state_dev, "rb_learner_act: NULL argument");
@@ -1093,10 +1135,29 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
   memset(&src, 0, sizeof(src));
   src.f32 = state_dev; src.B = 1;
   const NetPtrs on = net_ptrs(L, l->p_online, noisy ? l->n_online : l->zero_noise);
-  int rc = forward(l, 1, 0, src, on, on, (hipStream_t)stream);
+  int rc = act_forward_single(l, state_dev, on, noisy, (hipStream_t)stream);
+  if (rc == RB_ERR_STATE) rc = forward(l, 1, 0, src, on, on, (hipStream_t)stream);   // geometry outside the act path
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head_act, dim3(1), dim3(256), stream, L.Z, L.A, (const float*)l->logits, 0, (const float*)l->support,
             action_dev, q_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_act_batch(rb_learner_t* l, const float* states_dev, int32_t n, int32_t noisy, int32_t* actions_dev,
+                         float* q_dev, rb_stream_t stream) {
+  RB_REQUIRE(l && states_dev, "rb_learner_act_batch: NULL argument");
+  const Layout& L = l->L;
+  RB_REQUIRE(n >= 1 && n <= 2 * L.B, "rb_learner_act_batch: n must be in [1, 2*batch] (activation buffers are sized for the learn step)");
+  if (n == 1) return rb_learner_act(l, states_dev, noisy, actions_dev, q_dev, stream);
+  ImgSrc src;
+  memset(&src, 0, sizeof(src));
+  src.f32 = states_dev; src.B = n;
+  const NetPtrs on = net_ptrs(L, l->p_online, noisy ? l->n_online : l->zero_noise);
+  int rc = forward(l, n, 0, src, on, on, (hipStream_t)stream);     // the training kernels: n images share every weight read
+  if (rc != RB_OK) return rc;
+  RB_LAUNCH(k_head_act, dim3((unsigned)n), dim3(256), stream, L.Z, L.A, (const float*)l->logits, 0, (const float*)l->support,
+            actions_dev, q_dev);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }

@@ -54,7 +54,8 @@ struct NlRowGroup {
 // k_nl_fwd2 — forward without split-K partials: one workgroup owns a 16-row weight tile for the whole K, its 8 waves
 // take contiguous K ranges and meet once in a 2 KB-per-wave LDS reduction; bias (+ReLU) is applied there and the
 // result is written directly (row-major and, optionally, k-blocked for the next layer) — no partial-sum round trip, no
-// separate finish kernel.  (Round-1 history: a split-K variant with a finish kernel measured the same 30 us for the
+// separate finish kernel.  (Round-1 history: non-temporal weight loads measured +13 us on the step, prefetching the
+// bias terms before the loop measured nothing; a split-K variant with a finish kernel measured the same 30 us for the
 // pair; ablation shows the activation re-reads through the 64 B/clk L1 cost as much as the weight stream itself.)
 struct NlFwd2Args {
   const float* x;           // k-blocked activations (rb_blocked_index)

@@ -73,6 +73,16 @@ __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<f
 __device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int rb_wave() { return (int)(threadIdx.x >> 6); }
 
+// a value the caller knows to be identical in all lanes of the wave: lets the compiler keep it (and everything derived
+// from it: loop bounds, weight addresses) in scalar registers
+__device__ __forceinline__ int rb_wave_uniform(int v) {
+#if defined(RB_HOST_INTERP)
+  return v;
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // wave64 butterfly reductions (all 64 lanes must call)
 __device__ __forceinline__ float rb_wave_sum(float v) {
 #pragma unroll

@@ -317,3 +317,14 @@ class CAbiLearnAdapter:
         L.check(self.lib, self.lib.rb_learner_act(self.h, m.ptr(st), 1 if noisy else 0, m.ptr(a), m.ptr(q), m.stream))
         m.sync()
         return int(m.download(a)[0]), float(m.download(q)[0])
+
+    def act_batch(self, states, noisy):
+        m = self.mem
+        n = len(states)
+        st = m.upload(np.asarray(states, dtype=np.float32))
+        a = m.empty((n,), np.int32)
+        q = m.empty((n,), np.float32)
+        L.check(self.lib, self.lib.rb_learner_act_batch(self.h, m.ptr(st), n, 1 if noisy else 0, m.ptr(a), m.ptr(q),
+                                                        m.stream))
+        m.sync()
+        return m.download(a).astype(np.int64), m.download(q)

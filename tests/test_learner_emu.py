@@ -154,3 +154,22 @@ def test_fused_clip_adam_equals_clip_then_torch_adam(emu, norm_clip):
         if k.endswith("_grad_norm") and float(a[k]) > norm_clip:
             bites = True
     assert bites == (norm_clip < 1.0)
+
+
+@pytest.mark.parametrize("name", ["atoms21", "dataeff"])
+def test_act_path_single_equals_batched(emu, name):
+    """rb_learner_act (act_path.h: one channel / one weight row per wave) against rb_learner_act_batch (the training
+    kernels on n images), noisy and eval mode; the golden act_* entries pin the single path to the reference."""
+    c = scenarios.LEARN_CONFIGS[name]
+    cfg = O.Config(**c)
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    ad.load(O.init_params(cfg, 77), O.init_params(cfg, 78))
+    ad.reset_noise_online(np.random.RandomState(5).randn(O.noise_draw_count(cfg)).astype(np.float32))
+    states = [scenarios.synth_state(np.random.RandomState(100 + i), c["history"], 0) for i in range(3)]
+    for noisy in (True, False):
+        single = [ad.act(s, noisy) for s in states]
+        acts, qs = ad.act_batch(states, noisy)
+        for i, (a, q) in enumerate(single):
+            assert a == acts[i]
+            np.testing.assert_allclose(q, qs[i], rtol=2e-5, atol=1e-6)
+    ad.close()
