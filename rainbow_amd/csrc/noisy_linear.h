@@ -236,8 +236,9 @@ struct NlDxArgs {
 };
 
 // grid = (64-column tiles, row splits, n_prob * m-chunks of 64), block = 256 (4 waves split the rows)
-__device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by, int bz) {
-  __shared__ float s_red[4][64][64];
+#define RB_NL_DX_LDS (2 * 64 * 64)   // floats: two wave tiles (the four waves meet pairwise, see the reduction below)
+__device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by, int bz, float* lds) {
+  float (*s_red)[64][64] = reinterpret_cast<float (*)[64][64]>(lds);   // [2][64][64]
   const int lane = rb_lane(), wave = rb_wave();
   const int pi = bz % a.n_prob, mc = bz / a.n_prob;
   const NlDxProblem pr = a.prob[pi];
@@ -300,12 +301,34 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
       }
     }
   }
+  // cross-wave sum in a fixed order, (w0 + w2) + (w1 + w3), through two 16 KB tiles instead of four (the LDS footprint
+  // sets how many workgroups of the fused backward launch a CU holds)
+  if (wave >= 2) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
+        for (int j = 0; j < 4; ++j) s_red[wave - 2][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mt][j][e] += s_red[wave][(mt * 4 + e) * 4 + j][lane];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
+  }
   __syncthreads();
   const int slots = mt_cnt * 4;                          // (mt, e) pairs; j is the float4 lane
   for (int idx = (int)threadIdx.x; idx < slots * 64; idx += 256) {
@@ -315,7 +338,7 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int s = slot * 4 + j;
-      vv[j] = ((s_red[0][s][l] + s_red[1][s][l]) + s_red[2][s][l]) + s_red[3][s][l];
+      vv[j] = s_red[0][s][l] + s_red[1][s][l];
     }
     const int mt = slot >> 2, e = slot & 3;
     const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
@@ -333,7 +356,10 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
     }
   }
 }
-__global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) { rb_nl_dx_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+__global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
+  __shared__ float lds[RB_NL_DX_LDS];
+  rb_nl_dx_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
+}
 
 // ===================================================================== weight gradient ==
 // g_mu[n][k] = sum_m dy[m][n] * x[m][x_off + k] ; g_sigma = g_mu * (eps_out[n]*eps_in[k]) ;
@@ -451,6 +477,10 @@ struct NlPriorityUpdate {
   double omega;
 };
 __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g, NlPriorityUpdate up) {
+  // ONE LDS buffer for whichever body this workgroup runs (separate static arrays would add up: 132 KB, one workgroup
+  // per CU for the whole launch; 32 KB lets five share a CU)
+  constexpr int LDSW = RB_NL_DX_LDS > UpdateLds<512, 256>::WORDS ? RB_NL_DX_LDS : UpdateLds<512, 256>::WORDS;
+  __shared__ float lds[LDSW];
   const int b = (int)blockIdx.x;
   const int ndw = g.dw_x * g.dw_y;
   const int ndx = g.dx_x * g.dx_y * g.dx_z;
@@ -458,8 +488,8 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
     rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
   } else if (b < ndw + ndx) {
     const int r = b - ndw;
-    rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y));
+    rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
   } else {
-    rb_update_body(up.view, up.tree_idx, up.loss, up.n, 1, up.omega);     // the one extra block (n <= 256)
+    rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // the one extra block (n <= 256)
   }
 }

@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 // (body: replay_internal.h)
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
                                                   int32_t apply_pow, double omega) {
-  rb_update_body(v, tree_idx, values, n, apply_pow, omega);
+  __shared__ float lds[UpdateLds<2048, 1024>::WORDS];
+  rb_update_body<2048, 1024>(v, tree_idx, values, n, apply_pow, omega, lds);
 }
 
 // -------------------------------------------------------------- validation view --

@@ -38,7 +38,6 @@ __device__ __forceinline__ int64_t rb_floor_mod(int64_t a, int64_t m) {
 // O(1) LDS probes per level instead of scanning the batch.  Every parent is still
 // fl32(left + right) of its current children (memory.py:25): same floats as the reference.
 #define RB_MAX_LEVELS 31
-#define RB_HASH_SLOTS 2048
 
 // the table size follows the batch (power of two >= 4n, <= 2048 slots): a batch of 32 clears and probes 128 slots
 __device__ __forceinline__ int rb_hash_slot(int node, int shift) {
@@ -63,13 +62,20 @@ __device__ __forceinline__ int rb_hash_find(const int* keys, int node, int shift
 }
 
 // body (all threads of ONE workgroup of >= n threads, multiple of 64); shared by k_update and the learner's fused launch
+// LDS comes from the caller (HS hash slots per table, a power of two >= 2 * NMAX; NMAX >= n): the stand-alone kernel
+// uses <2048, 1024>, the learner's fused launch <512, 256> so that its other workgroups keep their occupancy.
+template <int HS, int NMAX>
+struct UpdateLds {
+  static constexpr int WORDS = 8 * HS + NMAX + 16;
+};
+template <int HS, int NMAX>
 __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
-                                               int32_t apply_pow, double omega) {
-  __shared__ int s_key[4][RB_HASH_SLOTS];     // [3] = leaf de-duplication table
-  __shared__ float s_tv[3][RB_HASH_SLOTS];
-  __shared__ int s_pos[RB_HASH_SLOTS];
-  __shared__ float s_vi[1024];
-  __shared__ float s_red[16];
+                                               int32_t apply_pow, double omega, float* lds) {
+  int (*s_key)[HS] = reinterpret_cast<int (*)[HS]>(lds);                 // [4][HS]; [3] = leaf de-duplication table
+  float (*s_tv)[HS] = reinterpret_cast<float (*)[HS]>(lds + 4 * HS);     // [3][HS]
+  int* s_pos = reinterpret_cast<int*>(lds + 7 * HS);
+  float* s_vi = lds + 8 * HS;
+  float* s_red = lds + 8 * HS + NMAX;
   const int i = (int)threadIdx.x;
   const bool active = i < n;
   int node = active ? (int)tree_idx[i] : -1;
@@ -90,7 +96,9 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
   }
   // (sizing the tables by the batch was measured SLOWER on MI355X — 15.3 vs 11.9 us at n=32, more probe collisions in
   // the top hash bits — so all batches use the full 2048 slots)
-  const int hmask = RB_HASH_SLOTS - 1, hshift = 21;
+  constexpr int HBITS = HS == 2048 ? 11 : HS == 1024 ? 10 : HS == 512 ? 9 : HS == 256 ? 8 : -1;
+  static_assert(HBITS > 0, "HS must be 256, 512, 1024 or 2048");
+  const int hmask = HS - 1, hshift = 32 - HBITS;
   for (int t = i; t <= hmask; t += (int)blockDim.x) {
     s_key[0][t] = -1; s_key[1][t] = -1; s_key[2][t] = -1; s_key[3][t] = -1;
     s_pos[t] = -1;
