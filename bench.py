@@ -186,7 +186,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         __graft_entry__.build()
-    if world > 1:
+    force_dist = os.environ.get("RAINBOW_AMD_FORCE_DIST") == "1" and "RANK" in os.environ   # one-rank RCCL plumbing test
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -222,7 +223,7 @@ def main():
     ktab = kernel_table(cfg, int(agent.params.numel()))
     kname = opt.roofline_kernel if opt.roofline_kernel in ktab else "clip_adam"
     lib.rb_profile_select(kname.encode())
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -253,6 +254,10 @@ def main():
         lib.rb_profile_select(None)
         if o_n.value > 0:
             others[other] = (o_ms.value / o_n.value * 1e-3, o_n.value)
+    ev_ms = C.c_double(0)
+    lib.rb_profile_overhead(torch.cuda.current_stream(dev).cuda_stream, 256, C.byref(ev_ms))
+    ev_us = ev_ms.value * 1e3          # what an EMPTY event pair reads: reported, not subtracted (rocprof's duration of
+                                       # the same kernel sits between avg_us and avg_us - event_pair_overhead_us)
     hdr = mem._header()
     assert hdr.last_status == 0, "device sampler failed"
     assert bool(torch.isfinite(agent._loss).all()), "non-finite loss"
@@ -286,7 +291,7 @@ def main():
         }
         k = ktab[kname]
         if launches.value > 0:
-            avg_s = tot_ms.value / launches.value * 1e-3
+            avg_s = tot_ms.value / launches.value * 1e-3     # raw event-pair time (includes the bracketing, see below)
             if k["bound"] == "hbm":
                 achieved, peak = k["work"] / avg_s / 1e9, HBM_PEAK_GBS
             else:
@@ -296,7 +301,7 @@ def main():
             out["roofline"] = {"kernel": kname, "bound": k["bound"], "achieved": achieved, "peak": peak, "unit": k["unit"],
                                "frac": achieved / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
                                "avg_us": avg_s * 1e6, "launches": launches.value,
-                               "algorithmic_work_per_launch": k["work"]}
+                               "algorithmic_work_per_launch": k["work"], "event_pair_overhead_us": ev_us}
             out["roofline_others"] = [
                 {"kernel": o, "bound": "hbm", "achieved": ktab[o]["work"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": ktab[o]["work"] / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get(o, {}).get("hbm_bytes_per_launch"),
@@ -305,7 +310,7 @@ def main():
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

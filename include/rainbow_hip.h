@@ -60,6 +60,9 @@ int rb_copy_to_device(void* dst_dev, const void* src_host, size_t nbytes, rb_str
  * the number of launches, and resets the counters.                                        */
 int rb_profile_select(const char* kernel_substr);
 int rb_profile_read(double* total_ms, int64_t* launches);
+/* Cost of an event pair with NOTHING between them on `stream` (mean of n pairs, ms): what the
+ * bracketing itself adds to every rb_profile_read sample.  Blocks until the stream drains.     */
+int rb_profile_overhead(rb_stream_t stream, int32_t n, double* mean_ms);
 
 /* ===================================================================== replay ==
  * HBM-resident prioritised replay: SoA ring (frames u8[C][7056], timestep i32[C],
@@ -238,6 +241,9 @@ int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const i
                              int32_t window_len, const int64_t* actions_dev, const float* returns_dev,
                              const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
                              rb_stream_t stream);
+/* 1 when rb_learner_learn_windows is available for this handle (the ring-reading first conv
+ * layer needs history <= 4 and the LDS conv kernels), else 0: gather and call rb_learner_learn. */
+int rb_learner_zero_copy_ok(rb_learner_t* l);
 
 /* clip_grad_norm_ (agent.py:97): global L2 norm of grads_dev, scale in place by
  * max_norm/(norm+1e-6) when that is < 1.  norm_dev (f32[1], may be NULL) gets ||g||. */

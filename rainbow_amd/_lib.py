@@ -49,6 +49,7 @@ SIGNATURES = {
     "rb_copy_to_device": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "rb_profile_select": (c_int, [c_char_p]),
     "rb_profile_read": (c_int, [C.POINTER(c_double), C.POINTER(c_int64)]),
+    "rb_profile_overhead": (c_int, [c_void_p, c_int32, C.POINTER(c_double)]),
     "rb_replay_create": (c_int, [C.POINTER(c_void_p), c_int64, c_int32, c_int32, c_double, c_double, c_uint64]),
     "rb_replay_destroy": (c_int, [c_void_p]),
     "rb_replay_buffers": (c_int, [c_void_p, C.POINTER(ReplayBuffers)]),
@@ -80,6 +81,7 @@ SIGNATURES = {
                                  c_void_p]),
     "rb_learner_learn_windows": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
+    "rb_learner_zero_copy_ok": (c_int, [c_void_p]),
     "rb_learner_clip_grad": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rb_learner_clip_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                      c_int64, c_void_p, c_void_p]),

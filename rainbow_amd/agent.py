@@ -156,7 +156,8 @@ class Agent:
         self._ev_loss = torch.cuda.Event()
         self._ev_upd = torch.cuda.Event()
         self._world = rdist.world_size()
-        if self._world > 1:   # identical replicas: rank 0's initial parameters everywhere
+        self._dist = rdist.active()
+        if self._dist:        # identical replicas: rank 0's initial parameters everywhere
             rdist.broadcast_parameters(self.params.detach(), 0)
             self.update_target_net()
 
@@ -284,7 +285,7 @@ class Agent:
         device-resident; after GRAPH_WARMUP eager calls it is captured once into a hipGraph and replayed
         (set RAINBOW_AMD_GRAPH=0 to stay eager).  The injected-randomness arguments are parity-test hooks."""
         injected = _target_raw_normals is not None or _unit_uniforms is not None
-        if (self._use_graph and not injected and self._world == 1 and isinstance(mem, ReplayMemory)):
+        if (self._use_graph and not injected and not self._dist and isinstance(mem, ReplayMemory)):
             if self._graph is not None and self._graph_mem is mem:
                 self._flush_noise()
                 mem._sync_beta()
@@ -312,7 +313,8 @@ class Agent:
     def _learn_eager(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
-        zero_copy = device_mem and self._cfg.history <= 4 and mem.history == self._cfg.history and mem.n == self.n
+        zero_copy = (device_mem and bool(self._lib.rb_learner_zero_copy_ok(self._h)) and mem.history == self._cfg.history
+                     and mem.n == self.n)
         noise_job = None
         if device_mem and _target_raw_normals is None:
             # the target-noise draw of this step (agent.py:74) — plus the deferred online draw (main.py:151) when one is
@@ -373,7 +375,7 @@ class Agent:
                 self._side.wait_event(self._ev_loss)
                 mem.update_priorities(idxs, self._loss)
                 self._ev_upd.record(self._side)
-        if self._world > 1:   # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
+        if self._dist:        # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
             rdist.average_gradients(self.grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         if isinstance(self.optimiser, _FlatAdam):

@@ -66,6 +66,31 @@ int rb_profile_read(double* total_ms, int64_t* launches) {
   return RB_OK;
 }
 
+int rb_profile_overhead(rb_stream_t stream, int32_t n, double* mean_ms) {
+  RB_REQUIRE(mean_ms != nullptr && n >= 1 && n <= 4096, "rb_profile_overhead: bad argument");
+  *mean_ms = 0.0;
+#if !defined(RB_HOST_INTERP)
+  std::vector<hipEvent_t> ev((size_t)2 * n);
+  for (auto& e : ev) RB_HIP_TRY(hipEventCreate(&e));
+  for (int i = 0; i < n; ++i) {
+    RB_HIP_TRY(hipEventRecord(ev[2 * i], (hipStream_t)stream));
+    RB_HIP_TRY(hipEventRecord(ev[2 * i + 1], (hipStream_t)stream));
+  }
+  RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  double total = 0.0;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.0f;
+    RB_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    total += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *mean_ms = total / n;
+#else
+  (void)stream;
+#endif
+  return RB_OK;
+}
+
 const char* rb_last_error(void) { return g_rb_error; }
 int rb_abi_version(void) { return 1; }
 

@@ -983,6 +983,10 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   const char* generic_only = getenv("RB_GENERIC_GEMM_ONLY");   // A/B switch: force the gemm_core fallback
   l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
+  {
+    const char* generic_fc = getenv("RB_GENERIC_FC");             // A/B switch: only the noisy-linear layers fall back
+    if (generic_fc && generic_fc[0] == '1') l->fast_fc = 0;
+  }
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
     l->xs = pick_splits(rb_div_up(L.F, 64) * rb_div_up(B, 64), 2 * L.H / 16, 512);
@@ -1439,6 +1443,10 @@ int rb_learner_set_priority_sink(rb_learner_t* l, rb_replay_t* replay, const int
   l->sink = replay;
   l->sink_idx = tree_idx_dev;
   return RB_OK;
+}
+
+int rb_learner_zero_copy_ok(rb_learner_t* l) {
+  return (l && l->fast_conv) ? 1 : 0;
 }
 
 int rb_learner_priority_written(rb_learner_t* l) {
