@@ -209,12 +209,15 @@ __global__ __launch_bounds__(256) void k_find(ReplayView v, const double* values
 //      instead of 20 dependent HBM/L2 loads.
 // Every load index is clamped to tree_len-1, which IS memory.py:70-71 on the leaf level and a
 // no-op above it.
-#define RB_TOP_NODES 4095
+#define RB_TOP_NODES 4095    // levels 0..11 = 16 KB of LDS (16383 nodes = one round trip fewer measured SLOWER: 17.3 vs 15.7 us)
 
 __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const float* s_top, int n_cached,
-                                                        int32_t levels, int64_t tree_len, double value) {
+                                                        int32_t levels, int64_t tree_len, double value,
+                                                        float* node_value) {
   int64_t node = 0;
   int32_t lv = 0;
+  float nv = 0.0f;                                  // tree[node] of the node reached (saves the caller a round trip)
+  bool have_nv = false;
   const int64_t last = tree_len - 1;
   for (; lv < levels; ++lv) {                       // LDS phase
     int64_t left = 2 * node + 1, right = left + 1;
@@ -225,6 +228,8 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
     const bool go_right = value > lv_d;
     node = go_right ? right : left;
     if (go_right) value = __dsub_rn(value, lv_d);
+    nv = s_top[node];
+    have_nv = true;
   }
   while (lv < levels) {                             // global phase, up to 3 levels per round trip
     const int32_t d = levels - lv < 3 ? levels - lv : 3;
@@ -248,6 +253,8 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
       int64_t nx = b1 + (r ? 1 : 0);
       node = nx > last ? last : nx;
       int sel = r ? 1 : 0;
+      nv = c1[sel];
+      have_nv = true;
       if (d >= 2) {
         const double l2 = (double)(sel ? c2[2] : c2[0]);
         const bool r2 = value > l2;
@@ -255,6 +262,7 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
         nx = 2 * node + 1 + (r2 ? 1 : 0);
         node = nx > last ? last : nx;
         sel = sel * 2 + (r2 ? 1 : 0);
+        nv = sel == 0 ? c2[0] : (sel == 1 ? c2[1] : (sel == 2 ? c2[2] : c2[3]));
         if (d >= 3) {
           const float l3f = sel == 0 ? c3[0] : (sel == 1 ? c3[2] : (sel == 2 ? c3[4] : c3[6]));
           const double l3 = (double)l3f;
@@ -262,11 +270,18 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
           if (r3) value = __dsub_rn(value, l3);
           nx = 2 * node + 1 + (r3 ? 1 : 0);
           node = nx > last ? last : nx;
+          const int s3 = sel * 2 + (r3 ? 1 : 0);
+          nv = c3[0];
+#pragma unroll
+          for (int t = 1; t < 8; ++t) nv = s3 == t ? c3[t] : nv;
         }
       }
     }
     lv += d;
   }
+  // a child index clamped to the last node may not be the entry that was loaded for the unclamped slot: re-read then
+  if (!have_nv || node == last) nv = tree[node];   // rare: explicit branch so the common path carries no load
+  *node_value = nv;
   return node;
 }
 
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
   }
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
-  __shared__ float s_top[RB_TOP_NODES];
+  __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
   const int i = (int)threadIdx.x;
   const bool active = i < batch;
   const int64_t C = v.capacity;
@@ -293,7 +308,13 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
   const float neg_beta_f32 = neg_beta_ptr ? *neg_beta_ptr : neg_beta_arg;
 
   const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
-  for (int t = i; t < n_cached; t += (int)blockDim.x) s_top[t] = v.tree[t];
+  for (int t = 4 * i; t < n_cached; t += 4 * (int)blockDim.x) {        // 16-byte loads (the tree buffer is 16-byte aligned)
+    if (t + 3 < n_cached) {
+      *reinterpret_cast<float4*>(&s_top[t]) = *reinterpret_cast<const float4*>(&v.tree[t]);
+    } else {
+      for (int u = t; u < n_cached; ++u) s_top[u] = v.tree[u];
+    }
+  }
   const int64_t w_index = v.hdr->index;
   const int32_t full = v.hdr->full;
   const uint64_t rng_base = v.hdr->rng_counter;
@@ -320,11 +341,10 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     const double sample = __dadd_rn(__dadd_rn(0.0, __dmul_rn(seg, u)), start);
     int valid = 1;
     if (active) {
-      leaf = rb_tree_descend_fast(v.tree, s_top, n_cached, v.levels, v.tree_len, sample);   // memory.py:130
-      prob = v.tree[leaf];
+      leaf = rb_tree_descend_fast(v.tree, s_top, n_cached, v.levels, v.tree_len, sample, &prob);   // memory.py:130
       const int64_t idx = leaf - v.tree_start;
       // memory.py:131
-      valid = (rb_floor_mod(w_index - idx, C) > (int64_t)n) && (rb_floor_mod(idx - w_index, C) >= (int64_t)h) &&
+      valid = (rb_wrap(w_index, -idx, C) > (int64_t)n) && (rb_wrap(idx, -w_index, C) >= (int64_t)h) &&
               (prob != 0.0f);
     }
     ok = rb_block_all(valid, s_flag);
@@ -338,11 +358,46 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     const int64_t idx = leaf - v.tree_start;
     const int win_len = h + n;
     int32_t* my_win = win + (int64_t)i * win_len;
+    // Everything below depends only on idx: the window's timesteps, the action, the n rewards and the last
+    // nonterminal are fetched in ONE round trip (8 at a time, fully unrolled — a runtime-length loop of
+    // load-then-test made each of the h+n timesteps and n rewards its own dependent trip: 15 -> ~9 us).
+    constexpr int CH = 8;
+    int ts0[CH];
+    float rw0[CH];
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int tc = t < win_len ? t : win_len - 1;
+      ts0[t] = v.timestep[rb_wrap(idx, (int64_t)(tc - (h - 1)), C)];
+      const int kc = t < n ? t : n - 1;
+      rw0[t] = v.reward[rb_wrap(idx, (int64_t)kc, C)];
+    }
+    const int64_t ring_now = idx;
+    const int act_now = v.action[ring_now];                             // slot h-1 is never blanked
+    const int64_t ring_last = rb_wrap(idx, (int64_t)n, C);
+    const uint8_t nt_last = v.nonterminal[ring_last];
+    // IS weight while those loads are in flight: probs / p_total ; capacity * probs ; ** -beta (memory.py:151-153),
+    // all float32 (the double pow is the longest ALU chain of the kernel)
+    {
+      const float pn = __fdiv_rn(prob, p_total);
+      const float cap = (float)(full ? C : w_index);
+      const float base = __fmul_rn(cap, pn);
+      w = (float)pow((double)base, (double)neg_beta_f32);
+    }
     // firsts: timestep == 0
     unsigned long long first_bits = 0ull;  // h+n <= 64
-    for (int t = 0; t < win_len; ++t) {
-      const int64_t ring = rb_floor_mod(idx + (int64_t)(t - (h - 1)), C);
-      if (v.timestep[ring] == 0) first_bits |= 1ull << t;
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+      if (t < win_len && ts0[t] == 0) first_bits |= 1ull << t;
+    for (int t0 = CH; t0 < win_len; t0 += CH) {                         // long windows (n = 20): 8 more per trip
+      int tsx[CH];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int tc = t0 + t < win_len ? t0 + t : win_len - 1;
+        tsx[t] = v.timestep[rb_wrap(idx, (int64_t)(tc - (h - 1)), C)];
+      }
+#pragma unroll
+      for (int t = 0; t < CH; ++t)
+        if (t0 + t < win_len && tsx[t] == 0) first_bits |= 1ull << (t0 + t);
     }
     unsigned long long blank = 0ull;
     for (int t = h - 2; t >= 0; --t) {  // memory.py:116-117
@@ -354,29 +409,37 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
       if (b) blank |= 1ull << t;
     }
     for (int t = 0; t < win_len; ++t) {
-      const int64_t ring = rb_floor_mod(idx + (int64_t)(t - (h - 1)), C);
+      const int64_t ring = rb_wrap(idx, (int64_t)(t - (h - 1)), C);
       my_win[t] = ((blank >> t) & 1ull) ? -1 : (int32_t)ring;
     }
-    // slot h-1 is never blanked
-    const int64_t ring_now = rb_floor_mod(idx, C);
-    actions_out[i] = (int64_t)v.action[ring_now];                       // memory.py:140
-    float R = 0.0f;                                                     // memory.py:142-143
-    for (int k = 0; k < n; ++k) {
-      const int t = h - 1 + k;
-      const int64_t ring = rb_floor_mod(idx + (int64_t)k, C);
-      const float rew = ((blank >> t) & 1ull) ? 0.0f : v.reward[ring];
-      R = __fadd_rn(R, __fmul_rn(rew, scaling[k]));
+    actions_out[i] = (int64_t)act_now;                                  // memory.py:140
+    float R = 0.0f;                                                     // memory.py:142-143, k ascending
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (k < n) {
+        const float rew = ((blank >> (h - 1 + k)) & 1ull) ? 0.0f : rw0[k];
+        R = __fadd_rn(R, __fmul_rn(rew, scaling[k]));
+      }
+    }
+    for (int k0 = CH; k0 < n; k0 += CH) {
+      float rwx[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int kc = k0 + k < n ? k0 + k : n - 1;
+        rwx[k] = v.reward[rb_wrap(idx, (int64_t)kc, C)];
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (k0 + k < n) {
+          const float rew = ((blank >> (h - 1 + k0 + k)) & 1ull) ? 0.0f : rwx[k];
+          R = __fadd_rn(R, __fmul_rn(rew, scaling[k0 + k]));
+        }
+      }
     }
     returns_out[i] = R;
     const int t_last = h + n - 1;                                       // memory.py:145
-    const int64_t ring_last = rb_floor_mod(idx + (int64_t)n, C);
-    nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (v.nonterminal[ring_last] ? 1.0f : 0.0f);
+    nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (nt_last ? 1.0f : 0.0f);
     tree_idx_out[i] = leaf;
-    // probs / p_total ; capacity * probs ; ** -beta   (memory.py:151-153), all float32
-    const float pn = __fdiv_rn(prob, p_total);
-    const float cap = (float)(full ? C : w_index);
-    const float base = __fmul_rn(cap, pn);
-    w = (float)pow((double)base, (double)neg_beta_f32);
   }
   const float w_max = rb_block_max(active ? w : -INFINITY, s_red);
   if (active) weights_out[i] = __fdiv_rn(w, w_max);                     // memory.py:154

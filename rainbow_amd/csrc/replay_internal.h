@@ -18,6 +18,15 @@ struct ReplayView {
 };
 
 
+// floor_mod(a + d, m) for a in [0, m) and a SMALL offset d (window slots, write-head distance): conditional add /
+// subtract instead of a 64-bit division (~100 instructions each; the sampler needs ~25 per sample).  The loops run
+// at most once unless the ring is shorter than the window (degenerate capacities stay correct).
+__device__ __forceinline__ int64_t rb_wrap(int64_t a, int64_t d, int64_t m) {
+  int64_t x = a + d;
+  while (x < 0) x += m;
+  while (x >= m) x -= m;
+  return x;
+}
 __device__ __forceinline__ int64_t rb_floor_mod(int64_t a, int64_t m) {
   int64_t r = a % m;
   return r < 0 ? r + m : r;
