@@ -86,7 +86,10 @@ def check_fake_uniform_is_faithful():
 
 def main():
     check_fake_uniform_is_faithful()
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]     # optional: names of the fixtures to (re)generate
     for name, cfg in scenarios.REPLAY_CONFIGS.items():
+        if only and name not in only:
+            continue
         capacity, history, n, discount, omega, _ = cfg
         trace = scenarios.replay_scenario(ReferenceReplayAdapter(capacity, history, n, discount, omega), name)
         path = os.path.join(HERE, "replay_%s.npz" % name)

@@ -120,7 +120,10 @@ class ReferenceLearnAdapter:
 
 
 def main():
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]     # optional: names of the fixtures to (re)generate
     for name in scenarios.LEARN_CONFIGS:
+        if only and name not in only:
+            continue
         trace = scenarios.learn_scenario(ReferenceLearnAdapter(name), name, O)
         path = os.path.join(HERE, "learn_%s.npz" % name)
         np.savez_compressed(path, **trace)

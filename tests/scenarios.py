@@ -42,16 +42,17 @@ REPLAY_CONFIGS = {
     "small": (256, 4, 3, 0.99, 0.5, 0.05),
     "ragged": (100, 2, 5, 0.9, 0.7, 0.08),       # non power-of-two capacity, other h/n/omega
     "nstep20": (1000, 4, 20, 0.99, 0.5, 0.01),   # data-efficient window (n=20)
+    "c4096": (4096, 4, 3, 0.99, 0.5, 0.02),      # C = 4096 with the benchmark batch sizes 32 and 256
 }
 # batch sizes of the three sampling phases (small rings cannot host 32 strata next to the write head)
-REPLAY_BATCHES = {"small": (8, 16, 32), "ragged": (4, 6, 5), "nstep20": (8, 16, 32)}
+REPLAY_BATCHES = {"small": (8, 16, 32), "ragged": (4, 6, 5), "nstep20": (8, 16, 32), "c4096": (32, 256, 256)}
 
 
 def replay_scenario(backend, name):
     """Drives `backend` through appends / samples / priority updates with wrap-around,
     episode boundaries inside windows, a not-yet-full buffer and duplicate leaf updates."""
     capacity, history, n, discount, omega, p_term = REPLAY_CONFIGS[name]
-    rs = np.random.RandomState({"small": 11, "ragged": 22, "nstep20": 33}[name])
+    rs = np.random.RandomState({"small": 11, "ragged": 22, "nstep20": 33, "c4096": 44}[name])
     b1, b2, b3 = REPLAY_BATCHES[name]
     trace = {}
     step = [0]
@@ -151,8 +152,12 @@ LEARN_CONFIGS = {
     "atoms21": dict(architecture="data-efficient", hidden=48, actions=3, atoms=21, batch=5, multi_step=1,
                     discount=0.9, history=2, v_min=-5.0, v_max=5.0),
 }
+LEARN_CONFIGS["k10"] = dict(architecture="data-efficient", hidden=32, actions=3, atoms=51, batch=4, multi_step=3,
+                            discount=0.99, history=4, v_min=-10.0, v_max=10.0)   # K = 1 and K = 10
 LEARN_HYPER = dict(lr=6.25e-5, adam_eps=1.5e-4, norm_clip=10.0)   # main.py:43-46 defaults
 LEARN_STEPS = 3
+LEARN_STEPS_BY = {"k10": 10}                 # other configs: LEARN_STEPS
+LEARN_FULL_RECORD = {"k10": (0, 9)}          # steps whose gradient / parameter summaries are kept (default: all)
 
 
 def make_batch(cfg, seed):
@@ -196,19 +201,22 @@ def learn_scenario(backend, name, oracle_mod):
     oracle_mod supplies Config/init_params/noise_draw_count only (pure bookkeeping)."""
     c = LEARN_CONFIGS[name]
     cfg = oracle_mod.Config(**c)
-    seed0 = {"canon": 1000, "dataeff": 2000, "atoms21": 3000}[name]
+    seed0 = {"canon": 1000, "dataeff": 2000, "atoms21": 3000, "k10": 4000}[name]
     online = oracle_mod.init_params(cfg, seed0)
     target = oracle_mod.init_params(cfg, seed0 + 1)
     backend.load(online, target)
     draws = oracle_mod.noise_draw_count(cfg)
     trace = {}
-    for k in range(LEARN_STEPS):
+    full = LEARN_FULL_RECORD.get(name)
+    for k in range(LEARN_STEPS_BY.get(name, LEARN_STEPS)):
         rs = np.random.RandomState(seed0 + 10 + k)
         backend.reset_noise_online(rs.randn(draws).astype(np.float32))
         batch = make_batch(c, seed0 + 20 + k)
         out = backend.learn_step(batch, rs.randn(draws).astype(np.float32))
         trace["s%d_loss" % k] = np.asarray(out["loss"], dtype=np.float32)
         trace["s%d_grad_norm" % k] = np.float32(out["grad_norm"])
+        if full is not None and k not in full:
+            continue
         for pname, g in out["grads"].items():
             trace["s%d_grad/%s" % (k, pname)] = summarize(g)
             trace["s%d_gradnorm/%s" % (k, pname)] = np.float32(np.sqrt(np.sum(np.asarray(g, dtype=np.float64) ** 2)))

@@ -15,7 +15,7 @@ def emu():
     return loader.load()
 
 
-@pytest.mark.parametrize("name", ["atoms21", "dataeff", "canon"])
+@pytest.mark.parametrize("name", ["atoms21", "k10", "dataeff", "canon"])
 def test_learn_step_matches_reference_golden(emu, name):
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O)
