@@ -173,3 +173,38 @@ def test_act_path_single_equals_batched(emu, name):
             assert a == acts[i]
             np.testing.assert_allclose(q, qs[i], rtol=2e-5, atol=1e-6)
     ad.close()
+
+
+def test_projection_known_answers(emu, monkeypatch):
+    """Analytic checks of the C51 projection that need no reference run: rows of m sum to 1; a terminal
+    transition puts all mass on the two atoms around (R - Vmin)/dz with weights (u - b), (b - l); R = 0 with
+    gamma^n = 1 on a non-terminal row returns the target distribution itself (agent.py:79-92)."""
+    cfgd = dict(scenarios.LEARN_CONFIGS["atoms21"], discount=1.0)
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, "ka", cfgd)
+    cfg = O.Config(**cfgd)
+    ad = CAbiLearnAdapter(emu, NumpyMem(), "ka")
+    ad.load(O.init_params(cfg, 31), O.init_params(cfg, 32))
+    draws = O.noise_draw_count(cfg)
+    rs = np.random.RandomState(9)
+    ad.reset_noise_online(rs.randn(draws).astype(np.float32))
+    batch = scenarios.make_batch(cfgd, 555)
+    B, Z = cfgd["batch"], cfgd["atoms"]
+    vmin, vmax = cfgd["v_min"], cfgd["v_max"]
+    dz = (vmax - vmin) / (Z - 1)
+    batch["returns"][:] = np.array([0.0, 0.0, 1.3, -2.75, 0.4][:B], dtype=np.float32)
+    batch["nonterminals"][:] = np.array([1, 1, 0, 0, 1][:B], dtype=batch["nonterminals"].dtype).reshape(batch["nonterminals"].shape)
+    ad.learn_step(batch, rs.randn(draws).astype(np.float32))
+    m = ad.debug(1, (B, Z), np.float32)
+    pns = ad.debug(3, (B, Z), np.float32)
+    np.testing.assert_allclose(m.sum(1), 1.0, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(pns.sum(1), 1.0, rtol=0, atol=2e-6)
+    for i in (0, 1):                                   # identity rows
+        np.testing.assert_allclose(m[i], pns[i], rtol=0, atol=2e-6)
+    for i in (2, 3):                                   # terminal rows
+        b = (float(batch["returns"][i]) - vmin) / dz
+        lo, hi = int(np.floor(b)), int(np.ceil(b))
+        want = np.zeros(Z, dtype=np.float64)
+        want[lo] += hi - b
+        want[hi] += b - lo
+        np.testing.assert_allclose(m[i], want, rtol=0, atol=2e-6)
+    ad.close()

@@ -73,3 +73,17 @@ def test_sampler_deep_tree_matches_oracle(emu, capacity):
     wp, wdi, wti = ora.transitions.find(vals)
     assert np.array_equal(ti, wti) and np.array_equal(p, wp)
     ad.close()
+
+
+def test_create_rejects_what_the_reference_cannot_run(emu):
+    """Odd capacities crash the reference's sum-tree walk (IndexError in _propagate_index) and a window
+    longer than 64 slots does not fit the sampler's masks: both are refused with an error code and a message."""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    for cap, h, n in ((501, 4, 3), (0, 4, 3), (512, 0, 3), (512, 4, 0), (512, 16, 49)):
+        handle = C.c_void_p()
+        rc = emu.rb_replay_create(C.byref(handle), cap, h, n, 0.99, 0.5, 1)
+        assert rc != 0 and not handle.value, (cap, h, n)
+        assert emu.rb_last_error()
+    with pytest.raises(L.RainbowError):
+        L.check(emu, emu.rb_replay_create(C.byref(C.c_void_p()), 501, 4, 3, 0.99, 0.5, 1))
