@@ -439,7 +439,7 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
         float4 gm, gs;
         gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
         gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
-        rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
+        rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);      // (write-through stores measured no gain here)
         rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
         sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
         sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);

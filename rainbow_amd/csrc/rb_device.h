@@ -69,6 +69,21 @@ __device__ __forceinline__ int rb_mfma_row(int reg, int lane) { return (reg & 3)
 // 16-byte global/LDS accesses (pointers must be 16-byte aligned)
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// write-through 16-byte store (sc1): the line leaves the XCD's L2 as it is written instead of staying dirty until the
+// end-of-kernel release, which otherwise flushes up to 8 x 4 MB behind a streaming kernel (MI355X_MICROARCH: stores).
+// Issued as a raw buffer store (wave-uniform base, per-lane byte offset < 2 GB) so that it is a compiler-known
+// instruction: a hand-written `global_store ... sc1` in inline asm escaped the hazard recogniser and corrupted data.
+__device__ __forceinline__ void rb_st4_wt(float* base, unsigned byte_off, float4 v) {
+#if defined(RB_HOST_INTERP)
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+#else
+  typedef unsigned int rb_v4u __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00027000);
+  rb_v4u t;
+  t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)byte_off, 0, 16);   // aux bit 4 = sc1
+#endif
+}
 
 __device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int rb_wave() { return (int)(threadIdx.x >> 6); }
