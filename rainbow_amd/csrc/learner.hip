@@ -712,7 +712,8 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
     z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
-    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, dim3((unsigned)(vt16 + at16), 1, 2 * (unsigned)rb_div_up(m_max, RB_FWD2_MROWS)),
+                dim3(64 * RB_NL_FWD_WAVES), stream, z);
     RB_LAUNCH_CHECK();
     return RB_OK;
   }
@@ -986,7 +987,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   const int B = L.B, NI = 3 * B;
   // split-K factors: aim for >= ~2 workgroups per CU on the 256-CU part
   const char* generic_only = getenv("RB_GENERIC_GEMM_ONLY");   // A/B switch: force the gemm_core fallback
-  l->fast_fc = (L.F % 16 == 0 && L.H % 16 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
+  l->fast_fc = (L.F % 32 == 0 && L.H % 32 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
   {
     const char* generic_fc = getenv("RB_GENERIC_FC");             // A/B switch: only the noisy-linear layers fall back

@@ -54,8 +54,9 @@ struct NlRowGroup {
 // k_nl_fwd2 — forward without split-K partials: one workgroup owns a 16-row weight tile for the whole K, its 8 waves
 // take contiguous K ranges and meet once in a 2 KB-per-wave LDS reduction; bias (+ReLU) is applied there and the
 // result is written directly (row-major and, optionally, k-blocked for the next layer) — no partial-sum round trip, no
-// separate finish kernel.  (Round-1 history: non-temporal weight loads measured +13 us on the step, prefetching the
-// bias terms before the loop measured nothing; a split-K variant with a finish kernel measured the same 30 us for the
+// separate finish kernel.  (Round-1 history: a K-split-across-workgroups variant with the activations shared through
+// LDS and a finish pass lost to this kernel, 251 vs 238.5 us per step; non-temporal weight loads measured +13 us on
+// the step, prefetching the bias terms before the loop measured nothing; a split-K variant with a finish kernel measured the same 30 us for the
 // pair; ablation shows the activation re-reads through the 64 B/clk L1 cost as much as the weight stream itself.)
 struct NlFwd2Args {
   const float* x;           // k-blocked activations (rb_blocked_index)
@@ -73,10 +74,13 @@ struct NlFwd2Args {
 // grid = (16-row tiles, 1, 2 * m-chunks of 32 rows), block = 512
 #define RB_FWD2_MROWS 32
 #define RB_FWD2_KMAX 4096          // eps_in slice staged in LDS (host checks K <= this)
+#define RB_FWD2_WT_LD 36           // row stride (floats) of a wave's 16 x 32 weight tile: 16-byte reads of 16 rows hit 64 distinct banks
 template <int ABL>   // ablation bits for tools/gpu_ablate.sh: 1 no weight refill, 2 no activation refill, 4 no MFMA (0 = product)
+                     // requires K % 32 == 0 (whole 32-wide k blocks)
 __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) {
   __shared__ float s_red[RB_NL_FWD_WAVES][8][64];
   __shared__ __attribute__((aligned(16))) float s_ein[RB_FWD2_KMAX];
+  __shared__ __attribute__((aligned(16))) float s_wt[RB_NL_FWD_WAVES][16 * RB_FWD2_WT_LD];
   const int lane = rb_lane(), wave = rb_wave();
   const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
   const int M = a.m_cnt[net];
@@ -96,11 +100,24 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
   const int nsc = (wc1 - wc0 + 1) / 2;                   // 32-wide k blocks of this wave
 
   const int r = lane & 15, q = lane >> 4;
-  int row = row0 + r;
-  if (row > row_end - 1) row = row_end - 1;
-  const float* mu_p = w.mu + (int64_t)row * K + 4 * q;
-  const float* sg_p = w.sigma + (int64_t)row * K + 4 * q;
-  const float eo = w.eout[row];
+  // WEIGHT LOADS are line-wide: an instruction covers 8 rows x 128 B (lane -> row 8 i + (lane >> 3), 16 B at
+  // 4 (lane & 7)), i.e. 8 full cache lines, not the MFMA operand layout (16 rows x 64 B = 16 half lines per
+  // instruction, which measured 31.4 us against 22.5 us for the same bytes read as flat 1 KB runs: the request count,
+  // not the byte count, was the limiter).  The noisy weight is formed in that load layout and transposed to the
+  // MFMA layout through a private 16 x 32 LDS tile per wave.
+  const int lr = lane >> 3, lk = lane & 7;
+  const float* mu_p[2];
+  const float* sg_p[2];
+  float eo2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = row0 + 8 * i + lr;
+    if (row > row_end - 1) row = row_end - 1;
+    mu_p[i] = w.mu + (int64_t)row * K + 4 * lk;
+    sg_p[i] = w.sigma + (int64_t)row * K + 4 * lk;
+    eo2[i] = w.eout[row];
+  }
+  float* wt = &s_wt[wave][0];                             // [16 rows][RB_FWD2_WT_LD]
   const float* x_p[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -120,66 +137,77 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
   // (16 KB per wave) are kept in flight in a statically indexed register ring.  The activations ride in the SAME ring
   // at the SAME depth: vector-memory loads retire in issue order (one vmcnt counter), so an activation load issued
   // one block ahead would sit behind the weight loads issued four blocks ahead and every wait for it would drain
-  // the whole weight prefetch (that was the first version: 30 us, effective depth 1).  eps_in is staged in LDS once
-  // (its reads count on lgkmcnt, not vmcnt).  Every load is UNCONDITIONAL (out-of-range blocks re-read the wave's last
-  // chunk and are multiplied by a zero mask): a branch around a load would make the outstanding-load count unknown
-  // to the compiler, which then drains the whole queue (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
+  // the whole weight prefetch.  eps_in is staged in LDS once (its reads count on lgkmcnt, not vmcnt).  Every load is
+  // UNCONDITIONAL (out-of-range blocks re-read the wave's last block and are multiplied by a zero mask): a branch
+  // around a load would make the outstanding-load count unknown to the compiler, which then drains the whole queue
+  // (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
   constexpr int RING = 4;
   float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][2];
   const int c_last = wc1 > wc0 ? wc1 - 1 : (nchunks > 0 ? nchunks - 1 : 0);
   auto chunk_of = [&](int sc, int h) { const int cc = wc0 + 2 * sc + h; return cc < wc1 ? cc : c_last; };
-  auto live = [&](int sc, int h) { return (wc0 + 2 * sc + h < wc1) ? 1.0f : 0.0f; };
+  auto block_of = [&](int sc) { const int cc = wc0 + 2 * sc; return cc + 1 < wc1 ? cc : (c_last > 0 ? c_last - 1 : 0); };   // first chunk of a 32-wide block
+  auto live = [&](int sc) { return (wc0 + 2 * sc < wc1) ? 1.0f : 0.0f; };
   {
     const float* ein_g = w.ein + grp.ein_off;
     for (int k4 = (int)threadIdx.x; k4 < (K >> 2); k4 += 64 * RB_NL_FWD_WAVES)
       *reinterpret_cast<float4*>(&s_ein[4 * k4]) = rb_ld4(ein_g + 4 * k4);
   }
 #pragma unroll
-  for (int d = 0; d < RING; ++d)
+  for (int d = 0; d < RING; ++d) {
+    const int cb = block_of(d);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      r_mu[d][i] = rb_ld4(mu_p[i] + cb * 16);
+      r_sg[d][i] = rb_ld4(sg_p[i] + cb * 16);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int cc = chunk_of(d, h);
-      r_mu[d][h] = rb_ld4(mu_p + cc * 16);
-      r_sg[d][h] = rb_ld4(sg_p + cc * 16);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cc * xs);
     }
+  }
   __syncthreads();                                       // eps_in visible
   const int nsc_pad = (nsc + RING - 1) / RING * RING;
   for (int sc0 = 0; sc0 < nsc_pad; sc0 += RING) {
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
       const int sc = sc0 + d;
-      float4 w4[2];
+      {
+        const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[block_of(sc) * 16 + 4 * lk]);
+        const float lv = live(sc);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[chunk_of(sc, h) * 16 + 4 * q]);
-        const float lv = live(sc, h);
-        w4[h] = rb_noisy4(r_mu[d][h], r_sg[d][h], eo, e4);
-        w4[h].x *= lv; w4[h].y *= lv; w4[h].z *= lv; w4[h].w *= lv;
-      }
-      if constexpr (!(ABL & 1)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                    // refill the weight half of this ring slot (block sc + RING)
-          const int cw = chunk_of(sc + RING, h);
-          r_mu[d][h] = rb_ld4(mu_p + cw * 16);
-          r_sg[d][h] = rb_ld4(sg_p + cw * 16);
+        for (int i = 0; i < 2; ++i) {
+          float4 wv = rb_noisy4(r_mu[d][i], r_sg[d][i], eo2[i], e4);
+          wv.x *= lv; wv.y *= lv; wv.z *= lv; wv.w *= lv;
+          *reinterpret_cast<float4*>(&wt[(8 * i + lr) * RB_FWD2_WT_LD + 4 * lk]) = wv;
         }
       }
+      if constexpr (!(ABL & 1)) {
+        const int cb = block_of(sc + RING);              // refill the weight half of this ring slot (block sc + RING)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 2; ++i) {
+          r_mu[d][i] = rb_ld4(mu_p[i] + cb * 16);
+          r_sg[d][i] = rb_ld4(sg_p[i] + cb * 16);
+        }
+      }
+      rb_wave_sync();                                    // the tile is private to the wave: LDS executes its ops in order
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 w4 = *reinterpret_cast<const float4*>(&wt[r * RB_FWD2_WT_LD + 16 * h + 4 * q]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           if constexpr (ABL & 4) {
-            acc[mt][0] += r_x[d][h][mt].x * w4[h].x; acc[mt][1] += r_x[d][h][mt].y * w4[h].y;
-            acc[mt][2] += r_x[d][h][mt].z * w4[h].z; acc[mt][3] += r_x[d][h][mt].w * w4[h].w;
+            acc[mt][0] += r_x[d][h][mt].x * w4.x; acc[mt][1] += r_x[d][h][mt].y * w4.y;
+            acc[mt][2] += r_x[d][h][mt].z * w4.z; acc[mt][3] += r_x[d][h][mt].w * w4.w;
           } else {
-            acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4[h].x, acc[mt]);
-            acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4[h].y, acc[mt]);
-            acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4[h].z, acc[mt]);
-            acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4[h].w, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4.x, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4.y, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4.z, acc[mt]);
+            acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4.w, acc[mt]);
           }
         }
+      }
       if constexpr (!(ABL & 2)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                    // ... and its activation half, once the MFMAs have read it
@@ -188,6 +216,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
           for (int mt = 0; mt < 2; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cw * xs);
         }
       }
+      rb_wave_sync();                                    // tile reads done before the next block overwrites it
       RB_SCHED_FENCE();                                  // keep this slot's refill here, not at the end of the loop
     }
   }

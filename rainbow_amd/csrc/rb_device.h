@@ -98,6 +98,19 @@ __device__ __forceinline__ int rb_wave_uniform(int v) {
 #endif
 }
 
+// Ordering point for LDS traffic that stays inside one wave (a lane reads what another lane of the SAME wave wrote):
+// the hardware executes a wave's LDS operations in order, so no s_barrier is needed — this only pins the compiler's
+// (and the host interpreter's) ordering.
+__device__ __forceinline__ void rb_wave_sync() {
+#if defined(RB_HOST_INTERP)
+  hipemu::wave_barrier();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // wave64 butterfly reductions (all 64 lanes must call)
 __device__ __forceinline__ float rb_wave_sum(float v) {
 #pragma unroll
