@@ -436,6 +436,14 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
 #pragma unroll
   for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
   const bool do_bias = kt == 0;
+  // epilogue operands, requested with the first operand loads (asked for after the loop they cost a second round trip)
+  const float4 e4 = rb_ld4(a.ein + pr.ein_off + col4);
+  float eo4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    eo4[e] = a.eout[n < row_end ? n : row_end - 1];
+  }
   for (int mb = 0; mb < a.M; mb += 32) {                  // 8 reduction steps of loads in flight per iteration
     float avs[8];
     float4 xs[8];
@@ -459,13 +467,12 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
       }
     }
   }
-  const float4 e4 = rb_ld4(a.ein + pr.ein_off + col4);
   float sq = 0.0f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int n = row0 + 4 * q + e;
     if (n < row_end) {
-      const float eo = a.eout[n];
+      const float eo = eo4[e];
       if (cv) {
         float4 gm, gs;
         gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
