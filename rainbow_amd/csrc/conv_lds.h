@@ -371,7 +371,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   }
   __syncthreads();
 
-  const int KW = ((K + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES)) * 2;
+  constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time (rows >= K of s_w are zero): full unroll
   const int kb = wave * KW;
   int nyx[NT], noff[NT];
 #pragma unroll
@@ -388,11 +388,14 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
   const int kh = lane >> 5, ml = lane & 31;
-#pragma unroll 4
-  for (int kk = 0; kk < KW; kk += 2) {
-    const int k = kb + kk + kh;
+  int kos[KW / 2], ktp[KW / 2];                       // tap tables of this wave's k range, off the per-step critical path
+#pragma unroll
+  for (int j = 0; j < KW / 2; ++j) { kos[j] = s_koff[kb + 2 * j + kh]; ktp[j] = s_ktap[kb + 2 * j + kh]; }
+#pragma unroll
+  for (int j = 0; j < KW / 2; ++j) {
+    const int k = kb + 2 * j + kh;
     const float av = s_w[k * 33 + ml];
-    const int ko = s_koff[k], tap = s_ktap[k];
+    const int ko = kos[j], tap = ktp[j];
     const int ty = tap >> 8, tx = tap & 255;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -535,6 +538,9 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
   }
   const int ntiles = (K + 31) / 32;
   const int kh = lane >> 5, nl = lane & 31;
+  int pofs[PCP / 2];                                  // position offsets of the whole chunk, read once (not per step)
+#pragma unroll
+  for (int j = 0; j < PCP / 2; ++j) pofs[j] = s_poff[2 * j + kh];
   for (int tile = wave; tile < ntiles; tile += RB_CONV_WAVES) {   // wave-uniform
     int col = tile * 32 + nl;
     const bool cv = col < K;
@@ -544,11 +550,8 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
     rb_f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-#pragma unroll 4
-    for (int p = 0; p < PCP; p += 2) {
-      const int pp = p + kh;
-      acc = rb_mfma32(s_a[pp * 33 + nl], s_patch[koff + s_poff[pp]], acc);
-    }
+#pragma unroll
+    for (int j = 0; j < PCP / 2; ++j) acc = rb_mfma32(s_a[(2 * j + kh) * 33 + nl], s_patch[koff + pofs[j]], acc);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = co0 + rb_mfma_row(q, lane);
