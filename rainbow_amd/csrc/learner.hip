@@ -331,12 +331,14 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
   }
   const float R = returns[b], nt = nonterminals[b], wgt = weights[b];
   const int act = (int)actions[b];
+  float sup[RB_ZI];                                  // requested with the logits: one memory round trip, not two
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = support[z < Z ? z : Z - 1]; }
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RB_ZI; ++i) sup[i] = lane + 64 * i < Z ? sup[i] : 0.0f;
   HeadWave hw;
   hw.lane = lane;
-  float sup[RB_ZI];
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = z < Z ? support[z] : 0.0f; }
   float mean[RB_ZI], e[RB_ZI], qm[RB_ZI];
 
   // ---------------- double-Q selection on online(next_states)   agent.py:71-73   (actions round-robin over waves)
