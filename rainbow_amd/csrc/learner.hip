@@ -692,7 +692,8 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     a.grp[0] = NlRowGroup{0, L.H, 0, 0, 0};
     a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, ht16};
     a.out = l->h; a.out_blocked = l->h_b; a.ld_out = 2 * L.H; a.rows_total = NI; a.relu = 1;
-    const unsigned mch32 = (unsigned)rb_div_up(m_max, RB_FWD2_MROWS);
+    const bool wide = m_max >= 128;                      // batch 256: 64-row m-chunks halve the passes over the weights
+    const unsigned mch32 = (unsigned)rb_div_up(m_max, wide ? 64 : RB_FWD2_MROWS);
     static const int abl = getenv("RB_FWD2_ABLATE") ? atoi(getenv("RB_FWD2_ABLATE")) : 0;   // tools/gpu_ablate.sh only
     const dim3 hg((unsigned)(2 * ht16), 1, 2 * mch32), hb(64 * RB_NL_FWD_WAVES);
     switch (abl) {
@@ -701,7 +702,10 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
       case 3: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<3>, hg, hb, stream, a); break;
       case 4: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<4>, hg, hb, stream, a); break;
       case 7: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<7>, hg, hb, stream, a); break;
-      default: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<0>, hg, hb, stream, a); break;
+      default:
+        if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), hg, hb, stream, a); }
+        else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<0>, hg, hb, stream, a); }
+        break;
     }
     RB_LAUNCH_CHECK();
     // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
@@ -714,8 +718,11 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
     z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
-    RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, dim3((unsigned)(vt16 + at16), 1, 2 * (unsigned)rb_div_up(m_max, RB_FWD2_MROWS)),
-                dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    if (wide) {
+      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    } else {
+      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    }
     RB_LAUNCH_CHECK();
     return RB_OK;
   }

@@ -71,20 +71,22 @@ struct NlFwd2Args {
   int relu;
 };
 
-// grid = (16-row tiles, 1, 2 * m-chunks of 32 rows), block = 512
+// grid = (16-row tiles, 1, 2 * m-chunks of 16 MT rows), block = 512
 #define RB_FWD2_MROWS 32
 #define RB_FWD2_KMAX 4096          // eps_in slice staged in LDS (host checks K <= this)
 #define RB_FWD2_WT_LD 36           // row stride (floats) of a wave's 16 x 32 weight tile: 16-byte reads of 16 rows hit 64 distinct banks
-template <int ABL>   // ablation bits for tools/gpu_ablate.sh: 1 no weight refill, 2 no activation refill, 4 no MFMA (0 = product)
-                     // requires K % 32 == 0 (whole 32-wide k blocks)
+// ABL: ablation bits for tools/gpu_ablate.sh: 1 no weight refill, 2 no activation refill, 4 no MFMA (0 = product).
+// MT: 16-row m-tiles per workgroup (2 = 32 rows, the batch-32 shape; 4 = 64 rows, which halves the number of passes over
+// the weights when a net has >= 128 rows, i.e. batch 256).  Requires K % 32 == 0 (whole 32-wide k blocks).
+template <int ABL, int MT = 2>
 __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) {
-  __shared__ float s_red[RB_NL_FWD_WAVES][8][64];
+  __shared__ float s_red[RB_NL_FWD_WAVES][4 * MT][64];
   __shared__ __attribute__((aligned(16))) float s_ein[RB_FWD2_KMAX];
   __shared__ __attribute__((aligned(16))) float s_wt[RB_NL_FWD_WAVES][16 * RB_FWD2_WT_LD];
   const int lane = rb_lane(), wave = rb_wave();
   const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
   const int M = a.m_cnt[net];
-  const int m0 = mc * RB_FWD2_MROWS;
+  const int m0 = mc * (16 * MT);
   if (m0 >= M) return;                                   // block-uniform
   const int g = (a.n_groups > 1 && (int)blockIdx.x >= a.grp[1].tile_begin) ? 1 : 0;
   const NlRowGroup grp = a.grp[g];
@@ -118,18 +120,18 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
     eo2[i] = w.eout[row];
   }
   float* wt = &s_wt[wave][0];                             // [16 rows][RB_FWD2_WT_LD]
-  const float* x_p[2];
+  const float* x_p[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     int m = m0 + 16 * mt + r;
     if (m > M - 1) m = M - 1;
     x_p[mt] = a.x + ((int64_t)(grp.x_off >> 4) * a.rows_total + a.m_base[net] + m) * 16 + 4 * q;
   }
   const int64_t xs = (int64_t)a.rows_total * 16;
 
-  rb_f32x4 acc[2];
+  rb_f32x4 acc[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[mt][e] = 0.0f;
 
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
   // around a load would make the outstanding-load count unknown to the compiler, which then drains the whole queue
   // (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
   constexpr int RING = 4;
-  float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][2];
+  float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][MT];
   const int c_last = wc1 > wc0 ? wc1 - 1 : (nchunks > 0 ? nchunks - 1 : 0);
   auto chunk_of = [&](int sc, int h) { const int cc = wc0 + 2 * sc + h; return cc < wc1 ? cc : c_last; };
   auto block_of = [&](int sc) { const int cc = wc0 + 2 * sc; return cc + 1 < wc1 ? cc : (c_last > 0 ? c_last - 1 : 0); };   // first chunk of a 32-wide block
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
     for (int h = 0; h < 2; ++h) {
       const int cc = chunk_of(d, h);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cc * xs);
+      for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cc * xs);
     }
   }
   __syncthreads();                                       // eps_in visible
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
       for (int h = 0; h < 2; ++h) {
         const float4 w4 = *reinterpret_cast<const float4*>(&wt[r * RB_FWD2_WT_LD + 16 * h + 4 * q]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           if constexpr (ABL & 4) {
             acc[mt][0] += r_x[d][h][mt].x * w4.x; acc[mt][1] += r_x[d][h][mt].y * w4.y;
             acc[mt][2] += r_x[d][h][mt].z * w4.z; acc[mt][3] += r_x[d][h][mt].w * w4.w;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
         for (int h = 0; h < 2; ++h) {                    // ... and its activation half, once the MFMAs have read it
           const int cw = chunk_of(sc + RING, h);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cw * xs);
+          for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cw * xs);
         }
       }
       rb_wave_sync();                                    // tile reads done before the next block overwrites it
@@ -221,11 +223,11 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
     }
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) s_red[wave][mt * 4 + e][lane] = acc[mt][e];
   __syncthreads();
-  for (int idx = (int)threadIdx.x; idx < 8 * 64; idx += 64 * RB_NL_FWD_WAVES) {
+  for (int idx = (int)threadIdx.x; idx < 4 * MT * 64; idx += 64 * RB_NL_FWD_WAVES) {
     const int slot = idx >> 6, l = idx & 63;
     float v = s_red[0][slot][l];
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
     const int mt = slot >> 2, e = slot & 3;
     const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
     const int n = row0 + (l & 15);
-    if (m < M && m < m0 + RB_FWD2_MROWS && n < row_end) {
+    if (m < M && m < m0 + 16 * MT && n < row_end) {
       float o = v + (w.bmu[n] + w.bsigma[n] * w.eout[n]);                 // model.py:44
       if (a.relu) o = fmaxf(o, 0.0f);
       const int rowi = a.m_base[net] + m;

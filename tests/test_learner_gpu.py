@@ -197,3 +197,27 @@ def test_graph_replay_matches_eager(hip, monkeypatch):
     np.testing.assert_allclose(lg, le, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pg, pe, rtol=0, atol=2e-6)
     np.testing.assert_allclose(tg, te, rtol=1e-4)
+
+
+def test_wide_batch_matches_oracle(hip, monkeypatch):
+    """Batch 64 (128 online rows): the noisy-linear forward switches to 64-row m-chunks (k_nl_fwd2<0, 4>); loss,
+    gradient norm and every gradient against the oracle on the same inputs."""
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=64, multi_step=3)
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, "wide", cfgd)
+    cfg = O.Config(**cfgd)
+    ad = CAbiLearnAdapter(hip, TorchMem(), "wide")
+    online, target = O.init_params(cfg, 177), O.init_params(cfg, 178)
+    ad.load(online, target)
+    rs = np.random.RandomState(15)
+    draws = O.noise_draw_count(cfg)
+    raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+    ad.reset_noise_online(raw_on)
+    batch = scenarios.make_batch(cfgd, 321)
+    got = ad.learn_step(batch, raw_tg)
+    want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+    np.testing.assert_allclose(got["loss"], want["loss"], rtol=2e-5, atol=1e-6)
+    for k, g in want["grads"].items():
+        scale = float(np.max(np.abs(g))) if g.size else 0.0
+        np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
+    ad.close()
