@@ -451,12 +451,16 @@ struct ConvDwLdsSize {
   static constexpr int FLOATS = PCP * 33 + CMAX * PLANE + PCP;   // dY^T, patch, position offsets
 };
 
-// body with explicit block coordinates and caller-provided LDS, so several layers can share one launch
+// body with explicit block coordinates and caller-provided LDS, so several layers can share one launch.
+// `grp` = slice index along the image axis: the workgroup sums images [grp * ipb, (grp + 1) * ipb) in registers before
+// it writes its slice (ipb = 1 at batch 32; batch 256 uses 8, which keeps the slice count — and the reduction pass
+// over the slices — at the batch-32 size).
 template <class G, int RC, int KMAX, bool FIRST>
-__device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chunk, int cotile, int img, int nchunks,
-                                                float* smem) {
+__device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chunk, int cotile, int grp, int nchunks,
+                                                int ipb, int batch, float* smem) {
   typedef ConvDwLdsSize<G, RC, KMAX> SZ;
   constexpr int PC = SZ::PC, PCP = SZ::PCP, PR = SZ::PR, PLANE = SZ::PLANE;
+  constexpr int TPW = ((KMAX + 31) / 32 + RB_CONV_WAVES - 1) / RB_CONV_WAVES;   // 32-wide column tiles per wave
   float* s_a = smem;                                  // dY^T: [pos][co]
   float* s_patch = smem + PCP * 33;
   int* s_poff = reinterpret_cast<int*>(smem + PCP * 33 + SZ::CMAX * PLANE);
@@ -471,91 +475,113 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
   const int iy0 = oy0 * G::S;
   int rows = G::IH - iy0;
   if (rows > PR) rows = PR;
+  const int ntiles = (K + 31) / 32;
+  const int kh = lane >> 5, nl = lane & 31;
 
-  // ---- stage dY^T (zero beyond the chunk), position offsets, input patch
-  for (int e = t; e < 32 * PCP; e += RB_CONV_THREADS) {
-    const int m = e / PCP, p = e - m * PCP;          // p fastest: coalesced along positions
-    float v = 0.0f;
-    if (p < npos && co0 + m < a.cout) v = a.dy[((int64_t)img * a.cout + co0 + m) * G::P + p0 + p];
-    s_a[p * 33 + m] = v;
-  }
   for (int p = t; p < PCP; p += RB_CONV_THREADS) {
     const int pc = p < npos ? p : npos - 1;
     s_poff[p] = (pc / G::OH) * G::S * G::IH + (pc % G::OH) * G::S;
   }
-  if (FIRST) {
-    const int per_c = rows * G::IH;
-    const int v16 = per_c >> 4;
-    const int total16 = cin * v16;
-    for (int e0 = 0; e0 < total16; e0 += 2 * RB_CONV_THREADS) {        // both 16-byte loads of a thread are in flight together
-      uint4 raw[2];
+  rb_f32x16 acc[TPW];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = e0 + i * RB_CONV_THREADS + t;
-        raw[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (e < total16) {
-          const int c = e / v16, q = e - c * v16;
-          const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
-          if (fp) raw[i] = *reinterpret_cast<const uint4*>(fp + iy0 * G::IH + q * 16);
-        }
-      }
+  for (int j = 0; j < TPW; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = e0 + i * RB_CONV_THREADS + t;
-        if (e < total16) {
-          const int c = e / v16, q = e - c * v16;
-          float* d = s_patch + c * PLANE + q * 16;
-          const unsigned wds[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
-#pragma unroll
-          for (int wd = 0; wd < 4; ++wd)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
-        }
-      }
-    }
-    const int tail = per_c & 15;
-    for (int e = t; e < cin * tail; e += RB_CONV_THREADS) {
-      const int c = e / tail, q = (v16 << 4) + e % tail;
-      const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
-      s_patch[c * PLANE + q] = fp ? rb_unit(fp[iy0 * G::IH + q]) : 0.0f;
-    }
-  } else {
-    const float* base = a.x_f + (int64_t)img * cin * G::IP;
-    const int per_c = rows * G::IH;
-    for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
-      const int c = e / per_c, q = e - c * per_c;
-      s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
-    }
-  }
-  __syncthreads();
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+  float bias_acc = 0.0f;
 
-  float* out = a.part + (((int64_t)img * nchunks + chunk) * a.cout) * (K + 1);
-  // bias column: sum over the chunk's positions, fixed order
-  if (t < 32 && co0 + t < a.cout) {
-    float acc = 0.0f;
-    for (int p = 0; p < npos; ++p) acc += s_a[p * 33 + t];
-    out[(int64_t)(co0 + t) * (K + 1) + K] = acc;
+  for (int ii = 0; ii < ipb; ++ii) {
+    const int img = grp * ipb + ii;
+    if (img >= batch) break;                          // block-uniform
+    if (ii > 0) __syncthreads();                      // the previous image's operands are no longer being read
+    // ---- stage dY^T (zero beyond the chunk) and the input patch of this image
+    for (int e = t; e < 32 * PCP; e += RB_CONV_THREADS) {
+      const int m = e / PCP, p = e - m * PCP;          // p fastest: coalesced along positions
+      float v = 0.0f;
+      if (p < npos && co0 + m < a.cout) v = a.dy[((int64_t)img * a.cout + co0 + m) * G::P + p0 + p];
+      s_a[p * 33 + m] = v;
+    }
+    if (FIRST) {
+      const int per_c = rows * G::IH;
+      const int v16 = per_c >> 4;
+      const int total16 = cin * v16;
+      for (int e0 = 0; e0 < total16; e0 += 2 * RB_CONV_THREADS) {        // both 16-byte loads of a thread are in flight together
+        uint4 raw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          raw[i] = make_uint4(0u, 0u, 0u, 0u);
+          if (e < total16) {
+            const int c = e / v16, q = e - c * v16;
+            const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+            if (fp) raw[i] = *reinterpret_cast<const uint4*>(fp + iy0 * G::IH + q * 16);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int e = e0 + i * RB_CONV_THREADS + t;
+          if (e < total16) {
+            const int c = e / v16, q = e - c * v16;
+            float* d = s_patch + c * PLANE + q * 16;
+            const unsigned wds[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+              for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+          }
+        }
+      }
+      const int tail = per_c & 15;
+      for (int e = t; e < cin * tail; e += RB_CONV_THREADS) {
+        const int c = e / tail, q = (v16 << 4) + e % tail;
+        const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+        s_patch[c * PLANE + q] = fp ? rb_unit(fp[iy0 * G::IH + q]) : 0.0f;
+      }
+    } else {
+      const float* base = a.x_f + (int64_t)img * cin * G::IP;
+      const int per_c = rows * G::IH;
+      for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
+        const int c = e / per_c, q = e - c * per_c;
+        s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+      }
+    }
+    __syncthreads();
+
+    // bias column: sum over the chunk's positions, fixed order (then over the images, ascending)
+    if (t < 32 && co0 + t < a.cout) {
+      float sum = 0.0f;
+      for (int p = 0; p < npos; ++p) sum += s_a[p * 33 + t];
+      bias_acc += sum;
+    }
+    int pofs[PCP / 2];                                  // position offsets of the whole chunk, read once (not per step)
+#pragma unroll
+    for (int j = 0; j < PCP / 2; ++j) pofs[j] = s_poff[2 * j + kh];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int tile = wave + j * RB_CONV_WAVES;        // wave-uniform
+      if (tile < ntiles) {
+        int col = tile * 32 + nl;
+        if (col > K - 1) col = K - 1;
+        const int c = col / G::KK, r = col % G::KK;
+        const int koff = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
+#pragma unroll
+        for (int jj = 0; jj < PCP / 2; ++jj)
+          acc[j] = rb_mfma32(s_a[(2 * jj + kh) * 33 + nl], s_patch[koff + pofs[jj]], acc[j]);
+      }
+    }
   }
-  const int ntiles = (K + 31) / 32;
-  const int kh = lane >> 5, nl = lane & 31;
-  int pofs[PCP / 2];                                  // position offsets of the whole chunk, read once (not per step)
+
+  float* out = a.part + (((int64_t)grp * nchunks + chunk) * a.cout) * (K + 1);
+  if (t < 32 && co0 + t < a.cout) out[(int64_t)(co0 + t) * (K + 1) + K] = bias_acc;
 #pragma unroll
-  for (int j = 0; j < PCP / 2; ++j) pofs[j] = s_poff[2 * j + kh];
-  for (int tile = wave; tile < ntiles; tile += RB_CONV_WAVES) {   // wave-uniform
-    int col = tile * 32 + nl;
-    const bool cv = col < K;
-    if (!cv) col = K - 1;
-    const int c = col / G::KK, r = col % G::KK;
-    const int koff = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
-    rb_f32x16 acc;
+  for (int j = 0; j < TPW; ++j) {
+    const int tile = wave + j * RB_CONV_WAVES;
+    if (tile < ntiles) {
+      const bool cv = tile * 32 + nl < K;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < PCP / 2; ++j) acc = rb_mfma32(s_a[(2 * j + kh) * 33 + nl], s_patch[koff + pofs[j]], acc);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = co0 + rb_mfma_row(q, lane);
-      if (cv && m < a.cout) out[(int64_t)m * (K + 1) + tile * 32 + nl] = acc[q];
+      for (int q = 0; q < 16; ++q) {
+        const int m = co0 + rb_mfma_row(q, lane);
+        if (cv && m < a.cout) out[(int64_t)m * (K + 1) + tile * 32 + nl] = acc[j][q];
+      }
     }
   }
 }
@@ -563,7 +589,7 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 template <class G, int RC, int KMAX, bool FIRST>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a) {
   __shared__ float smem[ConvDwLdsSize<G, RC, KMAX>::FLOATS];
-  rb_conv_dw_body<G, RC, KMAX, FIRST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+  rb_conv_dw_body<G, RC, KMAX, FIRST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, 1, (int)gridDim.z, smem);
 }
 
 // Every conv layer's weight gradient in ONE launch (they only feed the optimiser and are independent of each other
@@ -574,6 +600,7 @@ struct ConvDwAllArgs {
   int nblocks[3];          // workgroups of each layer
   int cotiles[3];
   int batch;
+  int ipb;                 // images summed per workgroup
 };
 template <class G0, int RC0, class G1, int RC1, int K1, class G2, int RC2, int K2, int NL>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a) {
@@ -586,18 +613,18 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a
   int b = (int)blockIdx.x;
   if (b < a.nblocks[0]) {                              // decode: chunk fastest, then cout tile, then image
     constexpr int CH = (G0::OH + RC0 - 1) / RC0;
-    rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], b % CH, (b / CH) % a.cotiles[0], b / (CH * a.cotiles[0]), CH, smem);
+    rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], b % CH, (b / CH) % a.cotiles[0], b / (CH * a.cotiles[0]), CH, a.ipb, a.batch, smem);
     return;
   }
   b -= a.nblocks[0];
   if (b < a.nblocks[1]) {
     constexpr int CH = (G1::OH + RC1 - 1) / RC1;
-    rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], b % CH, (b / CH) % a.cotiles[1], b / (CH * a.cotiles[1]), CH, smem);
+    rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], b % CH, (b / CH) % a.cotiles[1], b / (CH * a.cotiles[1]), CH, a.ipb, a.batch, smem);
     return;
   }
   if (NL > 2) {
     b -= a.nblocks[1];
     constexpr int CH = (G2::OH + RC2 - 1) / RC2;
-    rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], b % CH, (b / CH) % a.cotiles[2], b / (CH * a.cotiles[2]), CH, smem);
+    rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], b % CH, (b / CH) % a.cotiles[2], b / (CH * a.cotiles[2]), CH, a.ipb, a.batch, smem);
   }
 }

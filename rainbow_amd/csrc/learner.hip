@@ -835,6 +835,8 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   const Layout& L = l->L;
   ConvDwAllArgs a;
   a.batch = L.B;
+  a.ipb = L.B > 32 ? (int)rb_div_up(L.B, 32) : 1;      // keep about 32 image groups: the slice count stays at its batch-32 size
+  const int groups = (int)rb_div_up(L.B, a.ipb);
   unsigned total = 0;
   for (int i = 0; i < L.nconv; ++i) {
     const ConvLayer& c = L.conv[i];
@@ -844,8 +846,8 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
     const int rc = i == 0 ? (c.ks == 8 ? 5 : 4) : c.oh;                 // later layers: the whole image is one chunk
     const int chunks = (c.oh + rc - 1) / rc;
     a.cotiles[i] = (int)rb_div_up(c.cout, 32);
-    a.nblocks[i] = chunks * a.cotiles[i] * L.B;
-    l->dw_slices[i] = chunks * L.B;
+    a.nblocks[i] = chunks * a.cotiles[i] * groups;
+    l->dw_slices[i] = chunks * groups;
     total += (unsigned)a.nblocks[i];
   }
   for (int i = L.nconv; i < 3; ++i) { a.nblocks[i] = 0; a.cotiles[i] = 1; a.layer[i] = a.layer[0]; }

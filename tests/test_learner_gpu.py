@@ -199,11 +199,12 @@ def test_graph_replay_matches_eager(hip, monkeypatch):
     np.testing.assert_allclose(tg, te, rtol=1e-4)
 
 
-def test_wide_batch_matches_oracle(hip, monkeypatch):
-    """Batch 64 (128 online rows): the noisy-linear forward switches to 64-row m-chunks (k_nl_fwd2<0, 4>); loss,
-    gradient norm and every gradient against the oracle on the same inputs."""
+@pytest.mark.parametrize("base", ["dataeff", "canon"])
+def test_wide_batch_matches_oracle(hip, monkeypatch, base):
+    """Batch 64 (128 online rows): the noisy-linear forward switches to 64-row m-chunks (k_nl_fwd2<0, 4>) and the conv
+    weight-gradient workgroups sum two images each; loss and every gradient against the oracle on the same inputs."""
     from cabi_adapter import CAbiLearnAdapter, TorchMem
-    cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=64, multi_step=3)
+    cfgd = dict(scenarios.LEARN_CONFIGS[base], batch=64, multi_step=3)
     monkeypatch.setitem(scenarios.LEARN_CONFIGS, "wide", cfgd)
     cfg = O.Config(**cfgd)
     ad = CAbiLearnAdapter(hip, TorchMem(), "wide")
