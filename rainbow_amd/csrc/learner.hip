@@ -1255,20 +1255,27 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     zw.g_mu = l->grads + L.z_mu; zw.g_sigma = l->grads + L.z_sigma; zw.g_bmu = l->grads + L.z_bmu;
     zw.g_bsigma = l->grads + L.z_bsigma; zw.eout = on.z_eout; zw.ein = on.z_ein;
     // sum-of-squares slots (clip_grad_norm_ without re-reading the gradient): [fc_z dW waves | fc_h dW waves | conv reduce blocks]
-    const int z_slots = 4 * (int)rb_div_up(L.H, 256) * (vt + at);
-    const int h_slots = 4 * (int)rb_div_up(L.F, 256) * 2 * (int)rb_div_up(L.H, 16);
+    // pipelined weight-gradient body (one reduction pass per tile, i.e. batch <= 32): column tiles per wave
+    static const int ct_env = getenv("RB_DW_CT") ? atoi(getenv("RB_DW_CT")) : -1;      // A/B switch
+    const bool pipe = B <= 32 && !side;                  // (the side-stream variant launches the plain k_nl_dw)
+    const int z_ct = pipe ? (ct_env >= 0 ? (ct_env > 2 ? 2 : ct_env) : 2) : 0;
+    const int h_ct = pipe ? (ct_env >= 0 ? ct_env : 4) : 0;
+    const int z_dwx = (int)rb_div_up(L.H, 256 * (z_ct > 0 ? z_ct : 1)), h_dwx = (int)rb_div_up(L.F, 256 * (h_ct > 0 ? h_ct : 1));
+    const int z_slots = 4 * z_dwx * (vt + at);
+    const int h_slots = 4 * h_dwx * 2 * (int)rb_div_up(L.H, 16);
     int64_t conv_out = 0;
     for (int layer = 0; layer < L.nconv; ++layer) conv_out += (int64_t)L.conv[layer].cout * (L.conv[layer].K() + 1);
     const int c_slots = (int)rb_div_up(conv_out, 64);
     const bool fuse_norm = !side && z_slots + h_slots + c_slots <= 16384;
     zw.sq_part = fuse_norm ? l->norm_part : nullptr;
+    zw.ct = z_ct;
     NlDxArgs zx;
     zx.dy = l->dlogits; zx.ldy = L.NZ; zx.M = B; zx.w = nl_z(on); zx.K = L.H; zx.n_prob = 2;
     zx.prob[0] = NlDxProblem{0, L.Z, 1 << 30, 0, 0, 0};
     zx.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
     zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
     zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
-    NlBwdGrid zg{(int)rb_div_up(L.H, 256), vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
+    NlBwdGrid zg{z_dwx, vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
     // ---- hidden layer
     NlDwArgs hw_;
     hw_.dy = l->dh; hw_.x = feat; hw_.ldy = 2 * L.H; hw_.ldx = L.F; hw_.M = B; hw_.K = L.F; hw_.n_prob = 2;
@@ -1278,6 +1285,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hw_.g_mu = l->grads + L.h_mu; hw_.g_sigma = l->grads + L.h_sigma; hw_.g_bmu = l->grads + L.h_bmu;
     hw_.g_bsigma = l->grads + L.h_bsigma; hw_.eout = on.h_eout; hw_.ein = on.h_ein;
     hw_.sq_part = fuse_norm ? l->norm_part + z_slots : nullptr;
+    hw_.ct = h_ct;
     l->norm_slots = fuse_norm ? z_slots + h_slots + c_slots : 0;
     l->norm_conv_base = z_slots + h_slots;
     NlDxArgs hx;
@@ -1287,7 +1295,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hx.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
     const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
     hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
-    NlBwdGrid hg{(int)rb_div_up(L.F, 256), 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
+    NlBwdGrid hg{h_dwx, 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
     NlPriorityUpdate up;
     memset(&up, 0, sizeof(up));
     if (l->sink && B <= 256) {

@@ -412,6 +412,7 @@ struct NlDwArgs {
   const float *eout, *ein;
   float* sq_part;            // optional: one slot per (block, wave) receiving the sum of squares of what that wave wrote
                              // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
+  int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave
 };
 
 // grid = (256-column tiles, 16-row tiles), block = 256: wave w owns columns [256*bx + 64*w, +64)
@@ -497,6 +498,109 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
     if (lane == 0) a.sq_part[slot_base + wave] = sq;
   }
 }
+// Pipelined variant for M <= 32 (one reduction pass per tile): a wave walks `ct` column tiles 256 apart with the same dY
+// operand, requesting tile j+1's activations before it multiplies and stores tile j — with one tile per wave every
+// wave of the launch loaded, then multiplied, then stored at the same time (a read burst followed by a write burst).
+// grid.x = ceil(K / (256 ct)); the sum-of-squares slot of a wave covers all its tiles.
+__device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, int by, int slot_base) {
+  const int lane = rb_lane(), wave = rb_wave();
+  const int ct = a.ct;
+  const int kt0 = bx * ct * 256 + wave * 64;
+  if (kt0 >= a.K) {                                      // wave-uniform, no barriers below
+    if (a.sq_part && lane == 0) a.sq_part[slot_base + wave] = 0.0f;
+    return;
+  }
+  const int g = (a.n_prob > 1 && by >= a.prob[1].tile_begin) ? 1 : 0;
+  const NlDwProblem pr = a.prob[g];
+  const int row0 = pr.row_begin + (by - pr.tile_begin) * 16;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  const int c = lane & 15, q = lane >> 4;
+  int arow = row0 + c;
+  const bool av_ok = arow < row_end;
+  if (!av_ok) arow = row_end - 1;
+  float eo4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    eo4[e] = a.eout[n < row_end ? n : row_end - 1];
+  }
+  float avs[8];
+  const float* xrow[8];
+  float xmask[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int m = 4 * st + q;
+    const bool mv = m < a.M;
+    const int mcl = mv ? m : a.M - 1;
+    avs[st] = (mv && av_ok) ? a.dy[(int64_t)mcl * a.ldy + arow] : 0.0f;
+    xrow[st] = a.x + (int64_t)mcl * a.ldx + pr.x_off;
+    xmask[st] = mv ? 1.0f : 0.0f;
+  }
+  auto col_of = [&](int j) { int col4 = kt0 + j * 256 + 4 * c; return col4 < a.K ? col4 : a.K - 4; };
+  float4 xs[8], xn[8], e4, e4n;
+  {
+    const int col4 = col_of(0);
+    e4 = rb_ld4(a.ein + pr.ein_off + col4);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) xs[st] = rb_ld4(xrow[st] + col4);
+  }
+  float sq = 0.0f;
+  for (int j = 0; j < ct; ++j) {
+    const int kt = kt0 + j * 256;
+    if (kt >= a.K) break;                                // wave-uniform
+    {                                                    // next tile's operands (clamped: always a legal address)
+      const int coln = col_of(j + 1 < ct ? j + 1 : j);
+      e4n = rb_ld4(a.ein + pr.ein_off + coln);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) xn[st] = rb_ld4(xrow[st] + coln);
+    }
+    const bool cv = kt + 4 * c < a.K;
+    const int col4 = col_of(j);
+    const bool do_bias = kt == 0;
+    rb_f32x4 acc[4], accb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      if (4 * st < a.M) {                                // uniform
+        acc[0] = rb_mfma16(avs[st], xs[st].x * xmask[st], acc[0]);
+        acc[1] = rb_mfma16(avs[st], xs[st].y * xmask[st], acc[1]);
+        acc[2] = rb_mfma16(avs[st], xs[st].z * xmask[st], acc[2]);
+        acc[3] = rb_mfma16(avs[st], xs[st].w * xmask[st], acc[3]);
+        if (do_bias) accb = rb_mfma16(avs[st], 1.0f, accb);   // wave-uniform
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = row0 + 4 * q + e;
+      if (n < row_end) {
+        const float eo = eo4[e];
+        if (cv) {
+          float4 gm, gs;
+          gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
+          gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
+          rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
+          rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+          sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
+          sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
+        }
+        if (do_bias && c == 0) {
+          const float gb = accb[e], gbs = accb[e] * eo;
+          a.g_bmu[n] = gb;
+          a.g_bsigma[n] = gbs;
+          sq = fmaf(gb, gb, sq); sq = fmaf(gbs, gbs, sq);
+        }
+      }
+    }
+    e4 = e4n;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) xs[st] = xn[st];
+  }
+  if (a.sq_part) {                                        // wave-uniform
+    sq = rb_wave_sum(sq);
+    if (lane == 0) a.sq_part[slot_base + wave] = sq;
+  }
+}
 __global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
   rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y, 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x));
 }
@@ -525,7 +629,8 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
   const int ndw = g.dw_x * g.dw_y;
   const int ndx = g.dx_x * g.dx_y * g.dx_z;
   if (b < ndw) {
-    rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
+    if (dw.ct > 0) rb_nl_dw_body_pipe(dw, b % g.dw_x, b / g.dw_x, 4 * b);
+    else rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
   } else if (b < ndw + ndx) {
     const int r = b - ndw;
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
