@@ -139,7 +139,6 @@ struct rb_learner {
   float* zero_noise;    // [n_noise] zeros (eval mode, model.py:46)
   float* norm_part;     // sum-of-squares partials: [0,1024) k_sumsq; fused producers use [0, norm_slots)
   int norm_conv_base;   // first slot of the conv reduction blocks
-  int dfeat_pending;    // > 0: dact[last conv] is still `dfeat_pending` split partials in dfeat_part (see ConvLdsDxArgs)
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   int hs, xs, ws[3];    // split counts
@@ -797,12 +796,6 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     ConvLdsDxArgs a;
     a.cin = c.cin; a.cout = c.cout;
     a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
-    a.dy_part = nullptr; a.dy_mask = nullptr; a.dy_out = nullptr; a.dy_splits = 0; a.dy_stride = 0;
-    if (layer == L.nconv - 1 && l->dfeat_pending > 0) {   // fold the hidden layer's split-partial finish into the staging
-      a.dy_part = l->dfeat_part; a.dy_mask = l->act[layer]; a.dy_out = l->dact[layer];
-      a.dy_splits = l->dfeat_pending; a.dy_stride = (int64_t)L.B * L.F;
-      l->dfeat_pending = 0;
-    }
     constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
     constexpr int NT_ALL = (NPOS + 31) / 32;
     // few images at batch 32: spread each phase's positions over several workgroups (weights are re-staged from L2)
@@ -1326,12 +1319,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     }
     l->sink_done = (up.enabled && !side) ? 1 : 0;
     RB_LAUNCH_CHECK();
-    // Folding this finish into the last conv layer's input-gradient staging (ConvLdsDxArgs::dy_part) is implemented but
-    // measured slower (every workgroup of an image re-sums the partials: 32 us vs 13.2 + 4.7), so it stays opt-in.
-    static const bool fold = getenv("RB_FOLD_DFEAT") && getenv("RB_FOLD_DFEAT")[0] == '1';
-    if (fold && l->fast_conv && !side && L.nconv > 1 && feat == l->act[L.nconv - 1]) {
-      l->dfeat_pending = hsplits;     // consumed by the last conv layer's input-gradient launch (conv_bwd)
-    } else {
+    {
       const int64_t total = (int64_t)B * L.F;
       RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
                 hsplits, total, feat, l->dact[L.nconv - 1]);
@@ -1381,7 +1369,6 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (l->fast_conv && !side) {
     for (int layer = L.nconv - 1; layer > 0; --layer)                 // the input-gradient chain first ...
       if ((rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;
-    RB_REQUIRE(l->dfeat_pending == 0, "learn: the hidden layer's input-gradient partials were never finished");
     if ((rc = conv_dw_all(l, stream)) != RB_OK) return rc;            // ... then every weight gradient in one launch
   } else {
     for (int layer = L.nconv - 1; layer >= 0; --layer) {
