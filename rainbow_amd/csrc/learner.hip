@@ -836,7 +836,9 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
     ConvLdsDwArgs& d = a.layer[i];
     d.cin = c.cin; d.cout = c.cout; d.dy = l->dact[i]; d.part = l->dw_part[i];
     d.src = l->cur_src; d.x_f = i > 0 ? l->act[i - 1] : nullptr;
-    const int rc = i == 0 ? (c.ks == 8 ? 5 : 4) : c.oh;                 // later layers: the whole image is one chunk
+    // first layer: 7-row chunks (3 per image) so that all layers together are 96 + 64 + 64 = 224 workgroups at batch 32,
+    // ONE round over the 256 CUs (5-row chunks gave 288 workgroups at one per CU: a second round for 32 of them)
+    const int rc = i == 0 ? (c.ks == 8 ? 7 : 4) : c.oh;                 // later layers: the whole image is one chunk
     const int chunks = (c.oh + rc - 1) / rc;
     a.cotiles[i] = (int)rb_div_up(c.cout, 32);
     a.nblocks[i] = chunks * a.cotiles[i] * groups;
@@ -845,7 +847,7 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   }
   for (int i = L.nconv; i < 3; ++i) { a.nblocks[i] = 0; a.cotiles[i] = 1; a.layer[i] = a.layer[0]; }
   if (L.nconv == 3) {
-    RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomC1, 5, GeomC2, 9, 512, GeomC3, 7, 576, 3>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
+    RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomC1, 7, GeomC2, 9, 512, GeomC3, 7, 576, 3>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
   } else {
     RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomD1, 4, GeomD2, 3, 800, GeomD2, 3, 800, 2>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
   }
