@@ -3,12 +3,13 @@
 Same constructor and methods as the reference class (agent.py:12-118).  The networks are not
 nn.Modules: online / target parameters, gradients and factorised noise are flat float32 HBM
 buffers (torch tensors used purely as memory owners) and every forward / backward kernel is
-hand-written HIP behind librainbow_hip.so.  PyTorch-ROCm runs exactly one thing: the Adam step
-on the flat parameter buffer (agent.py:46,98).
+hand-written HIP behind librainbow_hip.so, the clip + Adam update included (`self.optimiser` is a
+torch.optim.Adam whose step() runs the library's one-pass kernel, agent.py:46,97-98); PyTorch-ROCm
+owns memory, streams and torch.distributed.
 
 learn(mem):  rainbow_amd.memory.ReplayMemory  -> fully device-resident step, no host sync:
-                 sample -> 3 forwards + projection + loss + backward -> [RCCL all-reduce]
-                 -> global-norm clip -> Adam -> priority update
+                 sample (+ noise) -> 3 forwards + projection + loss + backward (+ priority
+                 write-back) -> [RCCL all-reduce] -> global-norm clip + Adam
              any other object with the reference's sample()/update_priorities() -> compat path.
 
 Multi-GPU (BASELINE config 5): one process per GPU, identical parameters, each replica owns its
