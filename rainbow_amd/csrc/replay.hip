@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void k_find(ReplayView v, const double* values
 //      instead of 20 dependent HBM/L2 loads.
 // Every load index is clamped to tree_len-1, which IS memory.py:70-71 on the leaf level and a
 // no-op above it.
-#define RB_TOP_NODES 4095    // levels 0..11 = 16 KB of LDS (16383 nodes = one round trip fewer measured SLOWER: 17.3 vs 15.7 us)
+#define RB_TOP_NODES 4095    // levels 0..11 = 16 KB of LDS (16383 nodes = one round trip fewer measured SLOWER: 17.3 vs 15.7 us;
+                             // fetching each sample's whole remaining subtree cooperatively into LDS, one trip: 26.9 us)
 
 __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const float* s_top, int n_cached,
                                                         int32_t levels, int64_t tree_len, double value,
