@@ -88,12 +88,13 @@ __device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, i
 // PR = input rows staged per channel (covers the output rows of one position chunk).
 #define RB_CONV_WAVES 8
 #define RB_CONV_THREADS (64 * RB_CONV_WAVES)
-template <class G, int NT, int PR, int KMAX, bool FIRST>
+// PCH = output positions per workgroup (<= 32 NT; a multiple of the row length keeps the patch at PR rows).
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
   constexpr int KPAD = (KMAX + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES) * (2 * RB_CONV_WAVES);
   constexpr int PLANE = PR * G::IH;                 // floats per channel in the patch
   constexpr int CMAX = KMAX / G::KK;
-  constexpr int RED = RB_CONV_WAVES * NT * 16 * 64; // reduction scratch (floats), overlays s_w + s_patch
+  constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
   constexpr int OPS = KPAD * 33 + CMAX * PLANE;     // weights then patch, contiguous
   constexpr int WSZ = OPS > RED ? OPS : RED;
   __shared__ float s_all[WSZ];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
   const int img = (int)blockIdx.z;
   const int net = img < a.n_on ? 0 : 1;
   const int cout0 = (int)blockIdx.y * 32;
-  const int p0 = (int)blockIdx.x * (32 * NT);
+  const int p0 = (int)blockIdx.x * PCH;
   const int cin = a.cin;
   const int K = cin * G::KK;
   const int oy0 = p0 / G::OH;
@@ -224,25 +225,28 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
-  __syncthreads();                                    // everyone is done reading the operands: reuse them for the reduction
+  // cross-wave sum one 32-position tile at a time (32 KB of scratch whatever NT is: the LDS footprint decides how many
+  // workgroups share a CU), fixed order w0..w7
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt) {
+    __syncthreads();                                  // operands (nt == 0) / the previous tile's sums are no longer read
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_all[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
-  __syncthreads();
-  for (int idx = t; idx < NT * 16 * 64; idx += RB_CONV_THREADS) {
-    const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
-    float v = s_all[((0 * NT + nt) * 16 + r) * 64 + l];
+    for (int r = 0; r < 16; ++r) s_all[(wave * 16 + r) * 64 + lane] = acc[nt][r];
+    __syncthreads();
+    for (int idx = t; idx < 16 * 64; idx += RB_CONV_THREADS) {
+      const int l = idx & 63, r = idx >> 6;
+      float v = s_all[(0 * 16 + r) * 64 + l];
 #pragma unroll
-    for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
-    const int m = cout0 + rb_mfma_row(r, l);
-    const int p = p0 + nt * 32 + (l & 31);
-    if (m < a.cout && p < G::P && p < p0 + 32 * NT) {
-      const float o = fmaxf(v + a.bias[net][m], 0.0f);
-      a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
-      if (a.out_blocked) {
-        const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
-        a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+      for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[(wv * 16 + r) * 64 + l];
+      const int m = cout0 + rb_mfma_row(r, l);
+      const int p = p0 + nt * 32 + (l & 31);
+      if (m < a.cout && p < G::P && p < p0 + PCH) {
+        const float o = fmaxf(v + a.bias[net][m], 0.0f);
+        a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+        if (a.out_blocked) {
+          const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+          a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+        }
       }
     }
   }

@@ -619,7 +619,7 @@ static int launch_conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const I
   return RB_OK;
 }
 
-template <class G, int NT, int PR, int KMAX, bool FIRST>
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT>
 static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                                const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
@@ -629,8 +629,8 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
-  RB_LAUNCH((k_conv_fwd_lds<G, NT, PR, KMAX, FIRST>),
-            dim3((unsigned)rb_div_up(G::P, 32 * NT), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
+  RB_LAUNCH((k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH>),
+            dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
             dim3(RB_CONV_THREADS), stream, a);
   RB_LAUNCH_CHECK();
   return RB_OK;
@@ -640,7 +640,14 @@ static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& 
                     const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
   if (l->fast_conv) {
-    if (c.ks == 8) return launch_conv_fwd_lds<GeomC1, 2, 20, 256, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ks == 8) {
+      // 80 positions (4 output rows) per workgroup: 5 x 96 = 480 workgroups at batch 32, one round at two per CU
+      // (64 positions gave 672, the seventh chunk of each image nearly empty: 224.4 vs 222.6 us per step; 100 positions
+      // = 384 workgroups measured 225); RB_CONV1_PCH=64 restores the former shape for A/B
+      static const bool old64 = getenv("RB_CONV1_PCH") && atoi(getenv("RB_CONV1_PCH")) == 64;
+      if (old64) return launch_conv_fwd_lds<GeomC1, 2, 20, 256, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+      return launch_conv_fwd_lds<GeomC1, 3, 20, 256, true, 80>(l, layer, n_on, n_tg, src, on, tg, stream);
+    }
     if (c.ks == 4) return launch_conv_fwd_lds<GeomC2, 3, 20, 512, false>(l, layer, n_on, n_tg, src, on, tg, stream);
     if (c.ks == 3) return launch_conv_fwd_lds<GeomC3, 2, 9, 576, false>(l, layer, n_on, n_tg, src, on, tg, stream);
     if (c.ih == 84) return launch_conv_fwd_lds<GeomD1, 2, 20, 100, true>(l, layer, n_on, n_tg, src, on, tg, stream);
