@@ -1,20 +1,24 @@
 // noisy_linear.h — the NoisyLinear layers (model.py:10-46) for skinny batches, streamed
-// straight from HBM into v_mfma_f32_16x16x4_f32.
+// from HBM into v_mfma_f32_16x16x4_f32.
 //
 // Why a dedicated family: with M = B..3B rows (32..96) against [1024 x 3136] weights the hidden
 // layer is a weight-bandwidth problem — 51 MB of mu/sigma per forward, 26 MB per input-gradient
-// pass, 26 MB of gradient written — and each weight is used once per block, so an LDS round trip
-// buys nothing (guide: "operand streamed once per block and not shared across waves: load
-// straight to VGPRs").  The 16x16x4 MFMA shape is chosen for the LOADS, not the math: its B
-// operand wants lane l to hold column l&15 for k-slot l>>4, so with one float4 per lane
-//   * forward (k contiguous in memory):   4 lanes x 16 B = 64 contiguous bytes per weight row,
-//   * input/weight gradients (output columns contiguous): 16 lanes x 16 B = 256 B per row,
-// and four MFMAs consume the float4 (the k / column permutation inside a step is irrelevant to a
-// sum).  Noisy weights are formed in registers, W = mu + sigma * (eps_out * eps_in), with the
-// reference's rounding order (model.py:39,44); eps_w is never materialised.
+// pass, 26 MB of gradient written — and each weight is used once per workgroup.  Noisy weights
+// are formed in registers, W = mu + sigma * (eps_out * eps_in), with the reference's rounding
+// order (model.py:39,44); eps_w is never materialised.
+//
+// The 16x16x4 MFMA wants lane l to hold weight row / output column l&15 for k-slot l>>4 and
+// four MFMAs consume one float4 per lane (the k permutation inside a step is irrelevant to a
+// sum).  What decides the speed is how many CACHE LINES a wave's load instruction touches:
+//   * input / weight gradients (output columns contiguous): 16 lanes x 16 B = 256 B per row,
+//     4 rows per instruction = 8 full lines — loaded straight in the operand layout;
+//   * forward (k contiguous): the operand layout would be 16 rows x 64 B = 16 half lines per
+//     instruction, which measured 31 us against 22 us for the same bytes read as full lines.
+//     k_nl_fwd2 therefore loads 8 rows x 128 B per instruction, forms W in that layout and
+//     transposes it to the operand layout through a private LDS tile per wave.
 //
 // Preconditions (checked by the host; the generic gemm_core path remains the fallback):
-// K % 16 == 0, all leading dimensions and offsets multiples of 4 floats.
+// K % 32 == 0, all leading dimensions and offsets multiples of 4 floats.
 #pragma once
 #include "rb_device.h"
 #include "replay_internal.h"
