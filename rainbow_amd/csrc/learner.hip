@@ -310,7 +310,10 @@ struct HeadWave {
   }
 };
 
-__global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
+// 8 waves: with 6 actions every action's softmax of the double-Q selection has a wave of its own (4 waves needed two
+// rounds: 2.4 us of the kernel's 8)
+#define RB_HEAD_THREADS 512
+__global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
                                                const float* returns, const float* nonterminals, const float* weights,
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
   const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
   const int b = (int)blockIdx.x;
   const int NZ = Z + A * Z;
-  for (int i = t; i < NZ; i += 256) {
+  for (int i = t; i < NZ; i += RB_HEAD_THREADS) {
     s_lg[0][i] = logits[(int64_t)b * NZ + i];
     s_lg[1][i] = logits[(int64_t)(B + b) * NZ + i];
     s_lg[2][i] = logits[(int64_t)(2 * B + b) * NZ + i];
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
 
   // ---------------- double-Q selection on online(next_states)   agent.py:71-73   (actions round-robin over waves)
   hw.mean_of(s_lg[1], Z, A, mean);
-  for (int a = wave; a < A; a += 4) {
+  for (int a = wave; a < A; a += RB_HEAD_THREADS / 64) {
     const float se = hw.softmax_of(s_lg[1], Z, mean, a, e, qm);
     float sv = 0.0f;
 #pragma unroll
@@ -400,10 +403,10 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
   // b is monotone in the atom index (support increasing, nt*gamma^n >= 0), so equal l (and equal u) form
   // contiguous runs: the first atom of a run owns its bin and adds the run left to right — exactly the order of
   // the reference's first index_add_ (all l bins, j ascending) followed by the second (u bins) on the same m.
-  for (int k = t; k < Z; k += 256) s_m[k] = 0.0f;
+  for (int k = t; k < Z; k += RB_HEAD_THREADS) s_m[k] = 0.0f;
   __syncthreads();
   {
-    for (int j = t; j < Z; j += 256) {
+    for (int j = t; j < Z; j += RB_HEAD_THREADS) {
       const int key = s_l[j];
       if (j == 0 || s_l[j - 1] != key) {
         float acc = 0.0f;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
       }
     }
     __syncthreads();
-    for (int j = t; j < Z; j += 256) {
+    for (int j = t; j < Z; j += RB_HEAD_THREADS) {
       const int key = s_u[j];
       if (j == 0 || s_u[j - 1] != key) {
         float acc = s_m[key];
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
     }
   }
   __syncthreads();
-  for (int k = t; k < Z; k += 256) m_out[(int64_t)b * Z + k] = s_m[k];
+  for (int k = t; k < Z; k += RB_HEAD_THREADS) m_out[(int64_t)b * Z + k] = s_m[k];
   if (wave == 0) {                                                // loss = -sum m * log p   agent.py:94
     float pl = 0.0f, pm = 0.0f;
     for (int z = lane; z < Z; z += 64) { pl += s_m[z] * s_logp[z]; pm += s_m[z]; }
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void k_head(int B, int Z, int A, const float* 
   const float coef = wgt / (float)B;
   const float msum = s_scal[0];
   float* dl = dlogits + (int64_t)b * NZ;
-  for (int i = t; i < NZ; i += 256) {
+  for (int i = t; i < NZ; i += RB_HEAD_THREADS) {
     const int z = i < Z ? i : (i - Z) % Z;
     const float g = coef * (expf(s_logp[z]) * msum - s_m[z]);
     float o;
@@ -1230,7 +1233,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   const NetPtrs tg = net_ptrs(L, l->p_target, l->n_target);
   int rc = forward(l, 2 * B, B, src, on, tg, stream);
   if (rc != RB_OK) return rc;
-  RB_LAUNCH(k_head, dim3((unsigned)B), dim3(256), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
+  RB_LAUNCH(k_head, dim3((unsigned)B), dim3(RB_HEAD_THREADS), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
             l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
   RB_LAUNCH_CHECK();
