@@ -203,14 +203,48 @@ __global__ __launch_bounds__(256) void k_find(ReplayView v, const double* values
 // ---------------------------------------------------------------------- sample --
 // Latency-optimised search used by the sampler: identical arithmetic to rb_tree_descend, but
 //  (a) the top of the tree (<= 4095 nodes = 16 KB, levels 0..11) is staged once in LDS, and
-//  (b) below that, three levels are fetched per memory round trip: the descendants of node u at
-//      depth j are the 2^j consecutive entries starting at (u+1)*2^j - 1, so 2+4+8 independent
-//      loads replace three dependent ones.  For the 1M-leaf tree: 11 LDS steps + 3 round trips
+//  (b) below that, up to five levels are fetched per memory round trip: the descendants of node u at
+//      depth j are the 2^j consecutive entries starting at (u+1)*2^j - 1, so 2+4+8+16+32 independent
+//      loads replace five dependent ones.  For the 1M-leaf tree: 11 LDS steps + 2 round trips
 //      instead of 20 dependent HBM/L2 loads.
 // Every load index is clamped to tree_len-1, which IS memory.py:70-71 on the leaf level and a
 // no-op above it.
 #define RB_TOP_NODES 4095    // levels 0..11 = 16 KB of LDS (16383 nodes = one round trip fewer measured SLOWER: 17.3 vs 15.7 us;
                              // fetching each sample's whole remaining subtree cooperatively into LDS, one trip: 26.9 us)
+
+// D levels of the search with ONE batch of loads.  c holds level j (1..D) at [2^j - 2, 2^(j+1) - 2); `sel` is the path
+// taken so far inside the fetched subtree (bit per level).  Register arrays are indexed through select chains only.
+template <int D>
+__device__ __forceinline__ void rb_descend_levels(const float* tree, int64_t& node, double& value, int64_t last, float& nv) {
+  float c[(2 << D) - 2];
+#pragma unroll
+  for (int j = 1; j <= D; ++j) {
+    const int64_t base = ((node + 1) << j) - 1;
+#pragma unroll
+    for (int t = 0; t < (1 << j); ++t) {
+      const int64_t q = base + t;
+      c[(1 << j) - 2 + t] = tree[q > last ? last : q];
+    }
+  }
+  int sel = 0;
+#pragma unroll
+  for (int j = 1; j <= D; ++j) {
+    float lf = c[(1 << j) - 2];                       // left child of the current path node: entry 2*sel of level j
+#pragma unroll
+    for (int t = 1; t < (1 << (j - 1)); ++t) lf = sel == t ? c[(1 << j) - 2 + 2 * t] : lf;
+    const double l = (double)lf;
+    const bool r = value > l;
+    if (r) value = __dsub_rn(value, l);
+    const int64_t nx = 2 * node + 1 + (r ? 1 : 0);
+    node = nx > last ? last : nx;
+    sel = 2 * sel + (r ? 1 : 0);
+    if (j == D) {
+      nv = c[(1 << j) - 2];
+#pragma unroll
+      for (int t = 1; t < (1 << j); ++t) nv = sel == t ? c[(1 << j) - 2 + t] : nv;
+    }
+  }
+}
 
 __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const float* s_top, int n_cached,
                                                         int32_t levels, int64_t tree_len, double value,
@@ -232,53 +266,17 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
     nv = s_top[node];
     have_nv = true;
   }
-  while (lv < levels) {                             // global phase, up to 3 levels per round trip
-    const int32_t d = levels - lv < 3 ? levels - lv : 3;
-    float c1[2], c2[4], c3[8];
-    const int64_t b1 = 2 * node + 1, b2 = 4 * node + 3, b3 = 8 * node + 7;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { const int64_t q = b1 + t; c1[t] = tree[q > last ? last : q]; }
-    if (d >= 2) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { const int64_t q = b2 + t; c2[t] = tree[q > last ? last : q]; }
-    }
-    if (d >= 3) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { const int64_t q = b3 + t; c3[t] = tree[q > last ? last : q]; }
-    }
-    // depth 1
-    {
-      const double l = (double)c1[0];
-      const bool r = value > l;
-      if (r) value = __dsub_rn(value, l);
-      int64_t nx = b1 + (r ? 1 : 0);
-      node = nx > last ? last : nx;
-      int sel = r ? 1 : 0;
-      nv = c1[sel];
-      have_nv = true;
-      if (d >= 2) {
-        const double l2 = (double)(sel ? c2[2] : c2[0]);
-        const bool r2 = value > l2;
-        if (r2) value = __dsub_rn(value, l2);
-        nx = 2 * node + 1 + (r2 ? 1 : 0);
-        node = nx > last ? last : nx;
-        sel = sel * 2 + (r2 ? 1 : 0);
-        nv = sel == 0 ? c2[0] : (sel == 1 ? c2[1] : (sel == 2 ? c2[2] : c2[3]));
-        if (d >= 3) {
-          const float l3f = sel == 0 ? c3[0] : (sel == 1 ? c3[2] : (sel == 2 ? c3[4] : c3[6]));
-          const double l3 = (double)l3f;
-          const bool r3 = value > l3;
-          if (r3) value = __dsub_rn(value, l3);
-          nx = 2 * node + 1 + (r3 ? 1 : 0);
-          node = nx > last ? last : nx;
-          const int s3 = sel * 2 + (r3 ? 1 : 0);
-          nv = c3[0];
-#pragma unroll
-          for (int t = 1; t < 8; ++t) nv = s3 == t ? c3[t] : nv;
-        }
-      }
-    }
-    lv += d;
+  // global phase: D levels per memory round trip (all 2^(D+1)-2 descendants of the current node are requested at once,
+  // level j being the 2^j consecutive entries from (node+1)*2^j - 1), 5 while at least 5 remain: the 9 levels under the
+  // LDS top of the 1M-leaf tree take two trips (5 + 4)
+  while (lv < levels) {
+    const int32_t rem = levels - lv;
+    if (rem >= 5) { rb_descend_levels<5>(tree, node, value, last, nv); lv += 5; }
+    else if (rem == 4) { rb_descend_levels<4>(tree, node, value, last, nv); lv += 4; }
+    else if (rem == 3) { rb_descend_levels<3>(tree, node, value, last, nv); lv += 3; }
+    else if (rem == 2) { rb_descend_levels<2>(tree, node, value, last, nv); lv += 2; }
+    else { rb_descend_levels<1>(tree, node, value, last, nv); lv += 1; }
+    have_nv = true;
   }
   // a child index clamped to the last node may not be the entry that was loaded for the unclamped slot: re-read then
   if (!have_nv || node == last) nv = tree[node];   // rare: explicit branch so the common path carries no load
