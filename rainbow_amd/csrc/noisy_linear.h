@@ -59,7 +59,8 @@ struct NlRowGroup {
 // take contiguous K ranges and meet once in a 2 KB-per-wave LDS reduction; bias (+ReLU) is applied there and the
 // result is written directly (row-major and, optionally, k-blocked for the next layer) — no partial-sum round trip, no
 // separate finish kernel.  (Round-1 history: a K-split-across-workgroups variant with the activations shared through
-// LDS and a finish pass lost to this kernel, 251 vs 238.5 us per step; non-temporal weight loads measured +13 us on
+// LDS and a finish pass lost to this kernel twice: 251 vs 238.5 us per step before the line-wide loads, and, rebuilt
+// with them, 222.5 vs 221.0 (its main kernel 19 us bracketed + a 5 us finish pass); non-temporal weight loads measured +13 us on
 // the step, prefetching the bias terms before the loop measured nothing; a split-K variant with a finish kernel measured the same 30 us for the
 // pair; ablation shows the activation re-reads through the 64 B/clk L1 cost as much as the weight stream itself.)
 struct NlFwd2Args {
