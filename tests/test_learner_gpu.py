@@ -124,6 +124,8 @@ def test_agent_and_memory_classes_end_to_end_vs_oracle(hip, tmp_path):
     # vectorised actors: act_batch(states)[i] == act(states[i]) (batched forward through the training kernels)
     sts = torch.from_numpy(rs.randint(0, 256, size=(5, 4, 84, 84)).astype(np.float32) / np.float32(255)).cuda()
     assert list(agent.act_batch(sts)) == [agent.act(s) for s in sts]
+    many = sts.repeat(4, 1, 1, 1)[:19]                       # more than 2 * batch_size states: processed in chunks
+    assert list(agent.act_batch(many)) == [agent.act(s) for s in many]
     # checkpoint interchange: reference key names, round trip (agent.py:26-36,106-107)
     agent.save(str(tmp_path), "model.pth")
     sd = torch.load(str(tmp_path / "model.pth"), map_location="cpu")
