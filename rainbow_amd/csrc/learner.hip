@@ -533,6 +533,8 @@ struct ClipAdamArgs {
   float max_norm; float* norm_out;
   float w1, b2, w2, neg_step_size, bc2_sqrt, eps;
 };
+// (IEEE sqrt and divisions, as torch computes them: hardware rcp / approximate sqrt measured 1.5 us faster per launch
+// and stay far inside the test tolerance, but the update would no longer be the reference's formula rounding for rounding)
 __device__ __forceinline__ void rb_adam_elem(float& p, float& g, float& m, float& v, float coef, const ClipAdamArgs& a) {
   g = g * coef;
   m = fmaf(a.w1, g - m, m);
