@@ -202,17 +202,23 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float4 w4 = *reinterpret_cast<const float4*>(&wt[r * RB_FWD2_WT_LD + 16 * h + 4 * q]);
+        if constexpr (ABL & 4) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if constexpr (ABL & 4) {
+          for (int mt = 0; mt < MT; ++mt) {
             acc[mt][0] += r_x[d][h][mt].x * w4.x; acc[mt][1] += r_x[d][h][mt].y * w4.y;
             acc[mt][2] += r_x[d][h][mt].z * w4.z; acc[mt][3] += r_x[d][h][mt].w * w4.w;
-          } else {
-            acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4.x, acc[mt]);
-            acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4.y, acc[mt]);
-            acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4.z, acc[mt]);
-            acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4.w, acc[mt]);
           }
+        } else {
+          // k-slot outer, m-tile inner: consecutive MFMAs write different accumulators (back-to-back MFMAs on the
+          // same accumulator wait for each other's result)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4.x, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4.y, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4.z, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4.w, acc[mt]);
         }
       }
       if constexpr (!(ABL & 2)) {
