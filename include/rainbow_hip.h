@@ -142,6 +142,15 @@ int rb_replay_sample_fused_noise(rb_replay_t* r, int32_t batch, double priority_
                                  int64_t* actions_dev, float* returns_dev, float* nonterminals_dev,
                                  float* weights_dev, const rb_noise_job_t* noise_job, rb_stream_t stream);
 
+/* The reference's sampler retries until a batch is valid (memory.py:128-132); the device sampler is bounded by
+ * max_attempts.  When the bound is hit it writes ZERO importance weights (the learn step that consumes the batch then
+ * has an exactly zero gradient), sets last_status = 1 in the device header and increments a pinned host counter.
+ * This call reads that counter WITHOUT synchronising: the number of failed sampler launches that have completed so far. */
+int rb_replay_failed_samples(rb_replay_t* r, int64_t* count_host);
+/* SegmentTree.index / .full (memory.py:14,16) from the library's host mirror, without touching the device: exact as long
+ * as every append went through this handle (a header restored with rb_copy_to_device is picked up as well).        */
+int rb_replay_position(rb_replay_t* r, int64_t* index_host, int32_t* full_host);
+
 /* Graph replay support: when set (non-NULL), rb_replay_sample reads -beta (float32, i.e.
  * float32(-priority_weight), memory.py:153) from this DEVICE location instead of its by-value
  * argument, so main.py:161's per-step annealing works under a captured hipGraph.           */

@@ -169,10 +169,10 @@ class ReplayOracle:
             blank[:, t] = blank[:, t - 1] | first[:, t]
         return ring, blank
 
-    def sample_with_uniforms(self, batch, unit_uniforms):
-        """ReplayMemory.sample (memory.py:124-155).  unit_uniforms[a] are the U[0,1) draws of
-        attempt a: np.random.uniform(0.0, seg, B) == 0.0 + seg*u elementwise (memory.py:129).
-        Returns a dict with the 7-tuple's fields as numpy arrays (states as uint8 stacks)."""
+    def draw_indices(self, batch, unit_uniforms):
+        """The rejection loop of ReplayMemory._get_samples_from_segments (memory.py:124-132) alone: returns
+        (probs f32[B], data_idxs i64[B], tree_idxs i64[B], attempts).  Touches the tree and the write head only, so a
+        test can run it on a tree downloaded from the device without the 7 GB frame store."""
         tr = self.transitions
         h, n = self.history, self.n
         p_total = tr.total()                                               # np.float32
@@ -188,17 +188,20 @@ class ReplayOracle:
                   and np.all((idxs - tr.index) % self.capacity >= h)
                   and np.all(probs != 0))                                  # memory.py:131
             if ok:
-                break
-        else:
-            raise RuntimeError("oracle sampler: no valid batch within the supplied attempts")
+                return probs, idxs, tree_idxs, attempts
+        raise RuntimeError("oracle sampler: no valid batch within the supplied attempts")
+
+    def batch_scalars(self, idxs, probs):
+        """Everything of the sampled batch except the pixels (memory.py:111-121,140-145,149-154): the window's ring
+        slots and blank mask, actions, n-step returns, nonterminals and importance-sampling weights."""
+        tr = self.transitions
+        h, n = self.history, self.n
+        batch = len(idxs)
+        p_total = tr.total()
         ring, blank = self.window(idxs)
-        frames = tr.frames[ring]                                           # [B, h+n, 84, 84]
-        frames[blank] = 0                                                  # memory.py:120
         rewards = np.where(blank, np.float32(0), tr.reward[ring]).astype(np.float32)
         nonterm = np.where(blank, False, tr.nonterminal[ring])
         actions = np.where(blank, 0, tr.action[ring])
-        states = frames[:, :h]                                             # memory.py:137
-        next_states = frames[:, n:n + h]                                   # memory.py:138
         R = np.zeros(batch, dtype=np.float32)                              # memory.py:142-143
         for k in range(n):
             R = R + rewards[:, h - 1 + k] * self.n_step_scaling[k]
@@ -206,11 +209,26 @@ class ReplayOracle:
         cap = self.capacity if tr.full else tr.index                       # memory.py:152
         weights = (np.float32(cap) * probs_n) ** np.float32(-self.priority_weight)  # memory.py:153
         weights = (weights / weights.max()).astype(np.float32)             # memory.py:154
-        return dict(tree_idxs=tree_idxs.astype(np.int64), data_idxs=idxs.astype(np.int64), probs=probs,
-                    states=states, next_states=next_states,
+        return dict(ring=ring, blank=blank,
                     actions=actions[:, h - 1].astype(np.int64),           # memory.py:140
                     returns=R, nonterminals=nonterm[:, h + n - 1].astype(np.float32)[:, None],  # memory.py:145
-                    weights=weights, attempts=attempts)
+                    weights=weights)
+
+    def sample_with_uniforms(self, batch, unit_uniforms):
+        """ReplayMemory.sample (memory.py:124-155).  unit_uniforms[a] are the U[0,1) draws of
+        attempt a: np.random.uniform(0.0, seg, B) == 0.0 + seg*u elementwise (memory.py:129).
+        Returns a dict with the 7-tuple's fields as numpy arrays (states as uint8 stacks)."""
+        tr = self.transitions
+        h, n = self.history, self.n
+        probs, idxs, tree_idxs, attempts = self.draw_indices(batch, unit_uniforms)
+        sc = self.batch_scalars(idxs, probs)
+        frames = tr.frames[sc["ring"]]                                     # [B, h+n, 84, 84]
+        frames[sc["blank"]] = 0                                            # memory.py:120
+        states = frames[:, :h]                                             # memory.py:137
+        next_states = frames[:, n:n + h]                                   # memory.py:138
+        return dict(tree_idxs=tree_idxs.astype(np.int64), data_idxs=idxs.astype(np.int64), probs=probs,
+                    states=states, next_states=next_states, actions=sc["actions"], returns=sc["returns"],
+                    nonterminals=sc["nonterminals"], weights=sc["weights"], attempts=attempts)
 
     def update_priorities(self, tree_idxs, priorities):
         """memory.py:157-159.  NOTE numpy's float32 power is SIMD (SVML) on AVX-512 hosts and

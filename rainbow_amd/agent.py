@@ -283,8 +283,8 @@ class Agent:
 
     def learn(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         """agent.py:61-100.  With a rainbow_amd ReplayMemory the whole step (sample .. priority update) is
-        device-resident; after GRAPH_WARMUP eager calls it is captured once into a hipGraph and replayed
-        (set RAINBOW_AMD_GRAPH=0 to stay eager).  The injected-randomness arguments are parity-test hooks."""
+        device-resident and launched eagerly.  hipGraph replay is OPT-IN (RAINBOW_AMD_GRAPH=1): after GRAPH_WARMUP eager
+        calls the step is then captured once and replayed.  The injected-randomness arguments are parity-test hooks."""
         injected = _target_raw_normals is not None or _unit_uniforms is not None
         if (self._use_graph and not injected and not self._dist and isinstance(mem, ReplayMemory)):
             if self._graph is not None and self._graph_mem is mem:
@@ -314,6 +314,10 @@ class Agent:
     def _learn_eager(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
+        if device_mem and mem.failed_samples():
+            raise RuntimeError("ReplayMemory: %d sampler launch(es) found no valid batch in %d attempts (replay too small "
+                               "for batch %d?); those steps ran with zero importance weights"
+                               % (mem.failed_samples(), mem.MAX_ATTEMPTS, B))
         zero_copy = (device_mem and bool(self._lib.rb_learner_zero_copy_ok(self._h)) and mem.history == self._cfg.history
                      and mem.n == self.n)
         noise_job = None

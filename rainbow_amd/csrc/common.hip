@@ -35,6 +35,8 @@ bool rb_prof_begin(const char* kernel_expr, hipStream_t stream) {
 void rb_prof_end(hipStream_t stream) { (void)hipEventRecord(g_prof_events[g_prof_used++], stream); }
 #endif
 
+void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nbytes);   // replay.hip
+
 extern "C" {
 int rb_profile_select(const char* kernel_substr) {
 #if !defined(RB_HOST_INTERP)
@@ -105,6 +107,7 @@ int rb_copy_to_device(void* dst_dev, const void* src_host, size_t nbytes, rb_str
   RB_REQUIRE(dst_dev && src_host, "rb_copy_to_device: NULL argument");
   RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   RB_HIP_TRY(hipMemcpy(dst_dev, src_host, nbytes, hipMemcpyHostToDevice));
+  rb_replay_note_device_write(dst_dev, src_host, nbytes);   // a restored replay header also refreshes the host mirror
   return RB_OK;
 }
 }

@@ -42,6 +42,7 @@ struct rb_replay {
   float* scaling_dev;
   int32_t max_batch;
   const float* neg_beta_dev;   // optional device-resident -beta (graph replay: no by-value argument may change)
+  int32_t* fail_host;          // pinned, device-mapped: number of sampler launches that found no valid batch (see k_sample)
   // host mirror of the deterministic part of the header
   int64_t host_index;
   int32_t host_full;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                  float* weights_out, NoiseJob job) {
+                                                  float* weights_out, NoiseJob job, int32_t* fail_count) {
   if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
     const int nb = (int)blockIdx.x - 1;
     rb_noise_body(job.noise, job.noise2, nullptr, job.map, job.seed, job.ctr, nb % job.nblk, job.nblk, nb / job.nblk, job.nets);
@@ -441,11 +442,17 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     tree_idx_out[i] = leaf;
   }
   const float w_max = rb_block_max(active ? w : -INFINITY, s_red);
-  if (active) weights_out[i] = __fdiv_rn(w, w_max);                     // memory.py:154
+  // The reference retries until a batch is valid (memory.py:128-132); this loop is bounded.  If the bound is hit (a
+  // buffer too small for the batch: some stratum lies inside the write head's exclusion zone) the last draw is NOT a
+  // legal batch — windows may straddle the write head and a zero-priority leaf would give w = inf.  Make it harmless:
+  // every importance weight is 0, so the step's gradient is exactly zero, and the failure is counted in host-visible
+  // memory (rb_replay_failed_samples) so the caller can raise without a device synchronisation.
+  if (active) weights_out[i] = ok ? __fdiv_rn(w, w_max) : 0.0f;         // memory.py:154
   if (threadIdx.x == 0) {
     v.hdr->last_attempts = attempts_used;
     v.hdr->last_status = ok ? 0 : 1;
     if (!unit_uniforms) v.hdr->rng_counter = rng_base + (uint64_t)attempts_used;
+    if (!ok && fail_count) *(volatile int32_t*)fail_count = *(volatile int32_t*)fail_count + 1;
   }
 }
 
@@ -515,6 +522,25 @@ __global__ __launch_bounds__(256) void k_u8_to_unit(const uint8_t* src, float* d
 }
 
 // ================================================================ host entry points
+// Live handles, so that a raw header restore through rb_copy_to_device (state load, main.py:118) refreshes the host
+// mirror of index/full that rb_replay_append_batch plans its ancestor rebuild from.
+static rb_replay* g_live[64];
+static void live_add(rb_replay* r) { for (auto& p : g_live) if (!p) { p = r; return; } }
+static void live_del(rb_replay* r) { for (auto& p : g_live) if (p == r) p = nullptr; }
+void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nbytes) {
+  for (rb_replay* r : g_live) {
+    if (!r || !r->hdr) continue;
+    const char* h = (const char*)r->hdr;
+    const char* d = (const char*)dst_dev;
+    if (d <= h && h + sizeof(rb_replay_header_t) <= d + nbytes) {
+      rb_replay_header_t hd;
+      memcpy(&hd, (const char*)src_host + (h - d), sizeof(hd));
+      r->host_index = hd.index;
+      r->host_full = hd.full;
+    }
+  }
+}
+
 int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega) {
   if (!r || !view || !omega) return RB_ERR_INVALID;
   *view = view_of(r);
@@ -545,7 +571,7 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   r->neg_beta_dev = nullptr;
   r->host_index = 0; r->host_full = 0;
   r->tree = nullptr; r->frames = nullptr; r->timestep = nullptr; r->action = nullptr; r->reward = nullptr;
-  r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr;
+  r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr; r->fail_host = nullptr;
 #define RB_ALLOC(ptr, bytes)                                                                      \
   do {                                                                                            \
     hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                                   \
@@ -565,6 +591,15 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_ALLOC(r->win, (int64_t)r->max_batch * 64 * sizeof(int32_t));
   RB_ALLOC(r->scaling_dev, 64 * sizeof(float));
 #undef RB_ALLOC
+  {
+    hipError_t e_ = hipHostMalloc((void**)&r->fail_host, sizeof(int32_t), hipHostMallocMapped);
+    if (e_ != hipSuccess) {
+      rb_set_error("rb_replay_create: hipHostMalloc failed: %s", hipGetErrorString(e_));
+      rb_replay_destroy(r);
+      return RB_ERR_OOM;
+    }
+    *r->fail_host = 0;
+  }
   // blank_trans everywhere (memory.py:8,19), zero tree (memory.py:18)
   RB_HIP_TRY(hipMemset(r->tree, 0, r->tree_len * sizeof(float)));
   RB_HIP_TRY(hipMemset(r->frames, 0, capacity * (int64_t)RB_FRAME_BYTES));
@@ -576,12 +611,14 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_LAUNCH(k_replay_init, dim3(1), dim3(64), nullptr, r->hdr);
   RB_LAUNCH_CHECK();
   RB_HIP_TRY(hipDeviceSynchronize());
+  live_add(r);
   *out = r;
   return RB_OK;
 }
 
 int rb_replay_destroy(rb_replay_t* r) {
   if (!r) return RB_OK;
+  live_del(r);
   if (r->tree) (void)hipFree(r->tree);
   if (r->frames) (void)hipFree(r->frames);
   if (r->timestep) (void)hipFree(r->timestep);
@@ -591,6 +628,7 @@ int rb_replay_destroy(rb_replay_t* r) {
   if (r->hdr) (void)hipFree(r->hdr);
   if (r->win) (void)hipFree(r->win);
   if (r->scaling_dev) (void)hipFree(r->scaling_dev);
+  if (r->fail_host) (void)hipHostFree(r->fail_host);
   delete r;
   return RB_OK;
 }
@@ -667,6 +705,19 @@ int rb_replay_append_batch(rb_replay_t* r, const uint8_t* frames_dev, const int3
   return RB_OK;
 }
 
+int rb_replay_failed_samples(rb_replay_t* r, int64_t* count) {
+  RB_REQUIRE(r && count, "rb_replay_failed_samples: NULL argument");
+  *count = (int64_t)*(volatile int32_t*)r->fail_host;   // pinned host word the sampler increments: no synchronisation
+  return RB_OK;
+}
+
+int rb_replay_position(rb_replay_t* r, int64_t* index, int32_t* full) {
+  RB_REQUIRE(r != nullptr, "rb_replay_position: NULL handle");
+  if (index) *index = r->host_index;
+  if (full) *full = r->host_full;
+  return RB_OK;
+}
+
 int rb_replay_set_beta_source(rb_replay_t* r, const float* neg_beta_dev) {
   RB_REQUIRE(r != nullptr, "rb_replay_set_beta_source: NULL handle");
   r->neg_beta_dev = neg_beta_dev;
@@ -705,7 +756,7 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
     blocks += (unsigned)(job.nblk * job.nets);
   }
   RB_LAUNCH(k_sample, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-            r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job);
+            r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host);
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
     RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win,

@@ -28,24 +28,37 @@ class _TransitionsView:
     def _hdr(self):
         return self._o._header()
 
+    def _pos(self):
+        idx, full = C.c_int64(0), C.c_int32(0)
+        L.check(self._o._lib, self._o._lib.rb_replay_position(self._o._h, C.byref(idx), C.byref(full)))
+        return int(idx.value), bool(full.value)
+
     @property
     def index(self):
-        return int(self._hdr().index)
+        """memory.py:14 — from the library's host mirror: no device synchronisation (safe to poll in the env loop)."""
+        return self._pos()[0]
 
     @property
     def full(self):
-        return bool(self._hdr().full)
+        """memory.py:16 — host mirror, no synchronisation."""
+        return self._pos()[1]
 
     @property
     def max(self):
+        """memory.py:20 — lives on the device (updated by priority write-backs): SYNCHRONISES the stream."""
         return float(self._hdr().max)
 
     def total(self):
+        """memory.py:88-89 — tree root: SYNCHRONISES the stream."""
         return float(self._hdr().total)
 
 
 class ReplayMemory:
-    MAX_ATTEMPTS = 32   # device-side whole-batch rejection attempts per sample() (memory.py:128-132)
+    # The reference redraws until the batch is valid (memory.py:128-132).  The device loop is bounded, but generously: a
+    # redraw costs ~4 us inside the one sampler launch, and hitting the bound means no valid batch exists at all (buffer
+    # too small for the batch).  Then the batch gets zero importance weights (a zero-gradient step) and
+    # failed_samples() counts it; Agent.learn raises on the next call.
+    MAX_ATTEMPTS = 1024
 
     def __init__(self, args, capacity, seed=None):
         self.device = torch.device(args.device)
@@ -139,6 +152,13 @@ class ReplayMemory:
         L.check(self._lib, self._lib.rb_replay_append_batch(self._h, fr.data_ptr(), ts_d.data_ptr(), ac_d.data_ptr(),
                                                             rw_d.data_ptr(), nt_d.data_ptr(), n, self._stream()))
         torch.cuda.current_stream(d).synchronize()   # the temporaries above must outlive the kernels
+
+    def failed_samples(self):
+        """Sampler launches completed so far that found no valid batch within MAX_ATTEMPTS (read from pinned host memory
+        the kernel writes: no synchronisation)."""
+        n = C.c_int64(0)
+        L.check(self._lib, self._lib.rb_replay_failed_samples(self._h, C.byref(n)))
+        return int(n.value)
 
     def frame_source(self):
         """(frames_ptr, windows_ptr, window_len): lets the learner read frames straight from the ring (zero-copy)."""

@@ -48,3 +48,27 @@ def assert_learn_trace_matches(trace, golden, label="", grad_rtol=2e-4, grad_ato
             np.testing.assert_allclose(got, want, rtol=0, atol=param_atol, err_msg="%s %s" % (label, key))
         else:  # loss, grad norms, q values
             np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7, err_msg="%s %s" % (label, key))
+
+
+def oracle_view_of_device_replay(mem, beta=None):
+    """A ReplayOracle whose sum-tree and scalar columns ARE the device's (downloaded), without the frame store: lets the
+    oracle's index draw / window / scalar code (oracle.replay_oracle.draw_indices, batch_scalars) run against a
+    full-size (1M) device replay, whose 7 GB of frames no host copy is made of."""
+    from oracle.replay_oracle import ReplayOracle, SumTreeOracle, tree_geometry
+    ora = ReplayOracle.__new__(ReplayOracle)
+    ora.capacity, ora.history, ora.n = mem.capacity, mem.history, mem.n
+    ora.discount = mem.discount
+    ora.priority_weight = mem.priority_weight if beta is None else beta
+    ora.priority_exponent = mem.priority_exponent
+    ora.n_step_scaling = np.array([mem.discount ** i for i in range(mem.n)], dtype=np.float32)
+    st = SumTreeOracle.__new__(SumTreeOracle)
+    st.capacity = mem.capacity
+    st.levels, st.tree_start, st.tree_len = tree_geometry(mem.capacity)
+    st.tree = mem._grab("tree")
+    st.timestep, st.action, st.reward = mem._grab("timestep"), mem._grab("action"), mem._grab("reward")
+    st.nonterminal = mem._grab("nonterminal").astype(bool)
+    st.frames = None
+    hdr = mem._header()
+    st.index, st.full, st.max = int(hdr.index), bool(hdr.full), np.float32(hdr.max)
+    ora.transitions = st
+    return ora

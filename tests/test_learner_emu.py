@@ -34,6 +34,17 @@ def test_generic_gemm_fallback_still_matches_golden(emu, monkeypatch):
     ad.close()
 
 
+def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
+    """The hidden layer's input gradient split over 4 row ranges + k_dfeat_finish(splits = 4) — the shape the canonical
+    hidden-512 network runs (xs = 2H/256 = 4, learner.hip) — forced on the small canonical fixture with RB_XS=4."""
+    monkeypatch.setenv("RB_XS", "4")
+    name = "canon"
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    trace = scenarios.learn_scenario(ad, name, O)
+    assert_learn_trace_matches(trace, load_golden("learn_%s.npz" % name), label="emu-xs4/" + name)
+    ad.close()
+
+
 def test_unit_conversion_is_exact():
     """rb_unit's multiply + Newton step equals the correctly rounded x/255 for every byte (memory.py:137)."""
     x = np.arange(256, dtype=np.float32)

@@ -62,25 +62,29 @@ def _args(**kw):
     return types.SimpleNamespace(**base)
 
 
-def test_agent_and_memory_classes_end_to_end_vs_oracle(hip, tmp_path):
-    """The drop-in classes (Agent.learn(mem) on the device-resident fast path) against oracle replay + oracle
-    learner for several consecutive steps with injected sampler uniforms and noise; then save/load."""
+@pytest.mark.parametrize("hidden,batch,cap,appends", [(64, 8, 1024, 1500), (512, 32, 4096, 6000)],
+                         ids=["small", "baseline-cfg2-h512-b32"])
+def test_agent_and_memory_classes_end_to_end_vs_oracle(hip, tmp_path, hidden, batch, cap, appends):
+    """The drop-in classes (Agent.learn(mem) on the device-resident fast path: zero-copy frames, noise riding in the
+    sampler launch, fused priority write-back, one-pass clip + Adam — exactly what bench.py times) against oracle replay +
+    oracle learner for several consecutive steps with injected sampler uniforms and noise; then save/load.  The second
+    parametrisation is BASELINE config 2's network and batch (canonical, hidden 512, batch 32, 6 actions)."""
     from rainbow_amd.agent import Agent
     from rainbow_amd.memory import ReplayMemory
-    args = _args()
-    A, B, cap = 6, args.batch_size, 1024
+    args = _args(hidden_size=hidden, batch_size=batch)
+    A, B = 6, args.batch_size
     env = types.SimpleNamespace(action_space=lambda: A)
     torch.manual_seed(3)
     agent = Agent(args, env)
     mem = ReplayMemory(args, cap, seed=11)
     ora_mem = ReplayOracle(cap)
     rs = np.random.RandomState(21)
-    for _ in range(1500):
+    for _ in range(appends):
         st = rs.randint(0, 256, size=(4, 84, 84)).astype(np.float32) / np.float32(255)
         a, r, term = int(rs.randint(0, A)), float(rs.choice([-1.0, 0.0, 1.0])), bool(rs.random_sample() < 0.02)
         mem.append(torch.from_numpy(st).cuda(), a, r, term)
         ora_mem.append(st, a, r, term)
-    cfg = O.Config(batch=B, atoms=51, actions=A, history=4, hidden=64, architecture="canonical", multi_step=3)
+    cfg = O.Config(batch=B, atoms=51, actions=A, history=4, hidden=hidden, architecture="canonical", multi_step=3)
     online = {k: v.cpu().numpy() for k, v in agent.state_dict().items() if "epsilon" not in k}
     target = {k: v.copy() for k, v in online.items()}
     adam = O.AdamOracle(online, args.learning_rate, args.adam_eps)
@@ -131,8 +135,8 @@ def test_agent_and_memory_classes_end_to_end_vs_oracle(hip, tmp_path):
     sd = torch.load(str(tmp_path / "model.pth"), map_location="cpu")
     assert list(sd.keys())[:8] == ["convs.0.weight", "convs.0.bias", "convs.2.weight", "convs.2.bias", "convs.4.weight",
                                    "convs.4.bias", "fc_h_v.weight_mu", "fc_h_v.weight_sigma"]
-    assert tuple(sd["fc_h_v.weight_epsilon"].shape) == (64, 3136) and tuple(sd["fc_z_a.bias_epsilon"].shape) == (A * 51,)
-    args2 = _args(model=str(tmp_path / "model.pth"))
+    assert tuple(sd["fc_h_v.weight_epsilon"].shape) == (hidden, 3136) and tuple(sd["fc_z_a.bias_epsilon"].shape) == (A * 51,)
+    args2 = _args(model=str(tmp_path / "model.pth"), hidden_size=hidden, batch_size=batch)
     agent2 = Agent(args2, env)
     for k, v in agent2.state_dict().items():
         if "epsilon" not in k:
@@ -224,3 +228,114 @@ def test_wide_batch_matches_oracle(hip, monkeypatch, base):
         scale = float(np.max(np.abs(g))) if g.size else 0.0
         np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
     ad.close()
+
+
+# BASELINE.json configs 2, 3, 4 — the shapes bench.py times.  At these shapes the step runs code no
+# small fixture reaches: the 4-way row split of the hidden layer's input gradient + k_dfeat_finish(splits=4) (H = 512),
+# 64-row m-chunks and image-group sums (B = 256), the n = 20 data-efficient network at hidden 256.
+BASELINE_SHAPES = {
+    "cfg2-canonical-h512-b32-a6": dict(architecture="canonical", hidden=512, actions=6, atoms=51, batch=32, multi_step=3,
+                                       discount=0.99, history=4, v_min=-10.0, v_max=10.0),
+    "cfg3-canonical-h512-b256-a4": dict(architecture="canonical", hidden=512, actions=4, atoms=51, batch=256, multi_step=3,
+                                        discount=0.99, history=4, v_min=-10.0, v_max=10.0),
+    "cfg4-dataeff-h256-n20-b32-a6": dict(architecture="data-efficient", hidden=256, actions=6, atoms=51, batch=32,
+                                         multi_step=20, discount=0.99, history=4, v_min=-10.0, v_max=10.0),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(BASELINE_SHAPES))
+def test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape):
+    """TWO consecutive learn steps through the C ABI at the exact network / batch of each BASELINE config against the CPU
+    oracle on the same inputs: per-sample loss, global gradient norm, all 22 (clipped) gradients and the post-Adam
+    parameters, with the tolerances of helpers.assert_learn_trace_matches (agent.py:61-100)."""
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    cfgd = BASELINE_SHAPES[shape]
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
+    cfg = O.Config(**cfgd)
+    hy = scenarios.LEARN_HYPER
+    ad = CAbiLearnAdapter(hip, TorchMem(), shape)
+    online, target = O.init_params(cfg, 901), O.init_params(cfg, 902)
+    ad.load(online, target)
+    adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
+    draws = O.noise_draw_count(cfg)
+    rs = np.random.RandomState(55)
+    got_t, want_t = {}, {}
+    for k in range(2):
+        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+        ad.reset_noise_online(raw_on)
+        batch = scenarios.make_batch(cfgd, 700 + k)
+        got = ad.learn_step(batch, raw_tg)
+        want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+        total, clipped = O.clip_grads(want["grads"], hy["norm_clip"])
+        online = adam.step(clipped)
+        got_t["s%d_loss" % k], want_t["s%d_loss" % k] = got["loss"], want["loss"]
+        got_t["s%d_grad_norm" % k], want_t["s%d_grad_norm" % k] = np.float32(got["grad_norm"]), np.float32(total)
+        for name in clipped:
+            got_t["s%d_grad/%s" % (k, name)], want_t["s%d_grad/%s" % (k, name)] = got["grads"][name], clipped[name]
+        for name, p in ad.params().items():
+            got_t["s%d_param/%s" % (k, name)], want_t["s%d_param/%s" % (k, name)] = p, online[name]
+        if k == 0:
+            B, Z = cfgd["batch"], cfgd["atoms"]
+            assert np.array_equal(ad.debug(2, (B,), np.int32), want["a_star"].astype(np.int32))
+            np.testing.assert_allclose(ad.debug(1, (B, Z), np.float32), want["m"], rtol=1e-4, atol=1e-6)
+    assert_learn_trace_matches(got_t, want_t, label="hip/" + shape)
+    ad.close()
+
+
+def test_device_rng_noise_statistics(hip):
+    """The PRODUCTION noise path (rb_learner_reset_noise with raw = NULL: device Philox + Box-Muller, then
+    f(x) = sign(x) sqrt|x|, model.py:32-40): >= 10^6 values, moments and a Kolmogorov-Smirnov distance against the exact
+    law of f(N(0,1)); the three `which` modes consume distinct Philox epochs (no two resamples ever repeat)."""
+    import math
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    from scipy import stats
+    name = "cfg2-canonical-h512-b32-a6"
+    scenarios.LEARN_CONFIGS[name] = BASELINE_SHAPES[name]
+    try:
+        ad = CAbiLearnAdapter(hip, TorchMem(), name)
+    finally:
+        del scenarios.LEARN_CONFIGS[name]
+    from rainbow_amd import _lib as L
+    m = ad.mem
+    n_noise = ad.n_noise
+    layout = cabi_noise_layout(hip, ad.cfg)
+    live = np.zeros(n_noise, dtype=bool)
+    for _name, (off, shape) in layout.items():
+        live[off:off + shape[0]] = True
+    draws, seen = [], []
+    for rep in range(130):                            # 130 x 8.7k values > 10^6
+        which = rep % 3
+        L.check(hip, hip.rb_learner_reset_noise(ad.h, which, None, m.stream))
+        m.sync()
+        z_on, z_tg = m.download(ad.z_on)[live], m.download(ad.z_tg)[live]
+        fresh = {0: [z_on], 1: [z_tg], 2: [z_on, z_tg]}[which]
+        for v in fresh:
+            draws.append(v.copy())
+            key = v[:64].tobytes()
+            assert key not in seen, "a noise resample repeated an earlier epoch's values (rep %d, which %d)" % (rep, which)
+            seen.append(key)
+        if which == 2:
+            assert not np.array_equal(z_on, z_tg)
+    x = np.concatenate(draws).astype(np.float64)
+    assert x.size >= 1_000_000
+    g = np.sign(x) * x * x                            # invert f: g ~ N(0,1) if and only if x ~ f(N(0,1))
+    n = g.size
+    assert abs(g.mean()) < 5.0 / math.sqrt(n)
+    assert abs(g.var() - 1.0) < 5.0 * math.sqrt(2.0 / n)
+    assert abs((g ** 4).mean() - 3.0) < 5.0 * math.sqrt(96.0 / n)
+    assert abs((g ** 3).mean()) < 5.0 * math.sqrt(15.0 / n)
+    d, _p = stats.kstest(g, "norm")
+    assert d < 1.95 / math.sqrt(n), d                 # KS critical value at alpha ~ 1e-3
+    # E|f(x)| = E sqrt|N| = 2^(1/4) Gamma(3/4) / sqrt(pi)
+    want = 2 ** 0.25 * math.gamma(0.75) / math.sqrt(math.pi)
+    assert abs(np.abs(x).mean() - want) < 5.0 * math.sqrt((math.sqrt(2 / math.pi) - want ** 2) / n)
+    # independence across positions and epochs: lag-1 autocorrelation and epoch-to-epoch correlation ~ 0
+    assert abs(np.corrcoef(g[:-1], g[1:])[0, 1]) < 5.0 / math.sqrt(n)
+    a, b = draws[0].astype(np.float64), draws[3].astype(np.float64)
+    assert abs(np.corrcoef(a, b)[0, 1]) < 5.0 / math.sqrt(a.size)
+    ad.close()
+
+
+def cabi_noise_layout(lib, cfg):
+    from cabi_adapter import query_layout
+    return query_layout(lib, cfg, lib.rb_learner_noise_layout)

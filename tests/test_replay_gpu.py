@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import scenarios
-from helpers import F32_ULP_RTOL, assert_trace_matches, load_golden
+from helpers import F32_ULP_RTOL, assert_trace_matches, load_golden, oracle_view_of_device_replay
 from oracle.replay_oracle import ReplayOracle, tree_geometry
 
 pytestmark = pytest.mark.gpu
@@ -123,25 +123,39 @@ def test_pickle_round_trip(hip):
     assert np.array_equal(x, y)
 
 
-def test_full_size_tree_properties(hip):
-    """BASELINE config 2 capacity (1M): size-independent invariants instead of an oracle replay."""
-    from rainbow_amd.memory import ReplayMemory
-    cap = 1_000_000
-    mem = ReplayMemory(_args(), cap, seed=6)
-    g = torch.Generator(device="cuda").manual_seed(0)
-    chunk = 50_000
-    rs = np.random.RandomState(0)
-    for lo in range(0, cap + chunk, chunk):    # 1.05M appends: full, write head mid-buffer
+def _fill_full(mem, cap, chunk, seed, actions=6):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    for lo in range(0, cap + chunk, chunk):    # cap + chunk appends: full, write head mid-buffer
         fr = torch.randint(0, 256, (chunk, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
-        mem.append_batch(fr, rs.randint(0, 6, chunk), rs.choice([-1.0, 0.0, 1.0], size=chunk, p=[0.05, 0.9, 0.05]),
+        mem.append_batch(fr, rs.randint(0, actions, chunk), rs.choice([-1.0, 0.0, 1.0], size=chunk, p=[0.05, 0.9, 0.05]),
                          rs.random_sample(chunk) < 1e-3)
-    hdr = mem._header()
-    assert hdr.full == 1 and hdr.index == chunk
-    # non-uniform priorities through the public update path, 1024 leaves at a time
     levels, tree_start, tree_len = tree_geometry(cap)
-    for r in range(40):
+    for r in range(40):        # non-uniform priorities through the public update path, 1024 leaves at a time
         idx = torch.randint(0, cap, (1024,), device="cuda", generator=g) + tree_start
         mem.update_priorities(idx, torch.rand(1024, device="cuda", generator=g) * 3 + 1e-3)
+    return g
+
+
+@pytest.fixture(scope="module")
+def full_mem(hip):
+    """BASELINE config 2/3 replay: 1M capacity (7 GB of HBM), filled once for every full-size test of this module."""
+    from rainbow_amd.memory import ReplayMemory
+    cap, chunk = 1_000_000, 50_000
+    mem = ReplayMemory(_args(), cap, seed=6)
+    _fill_full(mem, cap, chunk, 0)
+    yield mem, chunk
+    del mem
+    torch.cuda.empty_cache()
+
+
+def test_full_size_tree_properties(hip, full_mem):
+    """BASELINE config 2 capacity (1M): size-independent invariants instead of an oracle replay."""
+    mem, chunk = full_mem
+    cap = mem.capacity
+    hdr = mem._header()
+    assert hdr.full == 1 and hdr.index == chunk
+    levels, tree_start, tree_len = tree_geometry(cap)
     tree = mem._grab("tree")
     leaves = tree[tree_start:]
     # every internal node is fl32(left + right) of its children  (memory.py:25,39)
@@ -158,8 +172,7 @@ def test_full_size_tree_properties(hip):
     from rainbow_amd import _lib as L
     L.check(hip, hip.rb_replay_find(mem._h, v_d.data_ptr(), 4096, probs.data_ptr(), di.data_ptr(), ti.data_ptr(), mem._stream()))
     di = di.cpu().numpy()
-    ora = ReplayOracle.__new__(ReplayOracle)   # oracle search on the device's own tree: indices must be identical
-    from oracle.replay_oracle import SumTreeOracle
+    from oracle.replay_oracle import SumTreeOracle     # oracle search on the device's own tree: indices must be identical
     st = SumTreeOracle.__new__(SumTreeOracle)
     st.capacity, st.levels, st.tree_start, st.tree_len, st.tree = cap, levels, tree_start, tree_len, tree
     _, want_di, want_ti = st.find(vals)
@@ -177,3 +190,126 @@ def test_full_size_tree_properties(hip):
     s = o["states"].cpu().numpy()
     for b in (0, 100, 255):
         assert np.array_equal(s[b, 3], mem._grab("frames", int(idx[b]), 1)[0])
+
+
+def _check_sampler_against_oracle(hip, mem, batches, seed, beta=0.6):
+    """sample_device with INJECTED uniforms on a full-size device replay against the oracle's draw on the downloaded tree:
+    tree indices bit-exact (memory.py:64-82,124-131 — this is the sampler's multi-level descent, rb_descend_levels<5>/<4>
+    on the 1M tree, <5>/<1> on the 100k tree), == rb_replay_find on the same sample values, and every scalar output of
+    the batch (actions, n-step returns, nonterminals, IS weights, window slots + blanking) against the oracle."""
+    from rainbow_amd import _lib as L
+    ora = oracle_view_of_device_replay(mem, beta=beta)
+    tr = ora.transitions
+    rs = np.random.RandomState(seed)
+    mem.priority_weight = beta
+    for B in batches:
+        for rep in range(3):
+            uu = rs.random_sample((32, B))
+            o = mem.sample_device(B, torch.from_numpy(uu))
+            torch.cuda.synchronize()
+            assert mem._header().last_status == 0
+            probs, idxs, tree_idxs, attempts = ora.draw_indices(B, uu)
+            got_ti = o["tree_idxs"].cpu().numpy()
+            assert np.array_equal(got_ti, tree_idxs), "B=%d rep=%d" % (B, rep)
+            assert mem._header().last_attempts == attempts
+            # the plain one-level-per-step search (k_find) on the very sample values of the accepted attempt
+            seg = np.float32(tr.total()) / np.float32(B)
+            samples = (0.0 + np.float64(seg) * uu[attempts - 1]) + np.arange(B, dtype=np.int64) * np.float64(seg)
+            v_d = torch.from_numpy(samples).cuda()
+            pr, di, ti = (torch.empty(B, dtype=torch.float32, device="cuda"), torch.empty(B, dtype=torch.int64, device="cuda"),
+                          torch.empty(B, dtype=torch.int64, device="cuda"))
+            L.check(hip, hip.rb_replay_find(mem._h, v_d.data_ptr(), B, pr.data_ptr(), di.data_ptr(), ti.data_ptr(), mem._stream()))
+            assert np.array_equal(ti.cpu().numpy(), got_ti)
+            assert np.array_equal(pr.cpu().numpy(), probs)
+            sc = ora.batch_scalars(idxs, probs)
+            assert np.array_equal(o["actions"].cpu().numpy(), sc["actions"])
+            np.testing.assert_allclose(o["returns"].cpu().numpy(), sc["returns"], rtol=1e-6, atol=1e-7)
+            assert np.array_equal(o["nonterminals"].cpu().numpy(), sc["nonterminals"][:, 0])
+            np.testing.assert_allclose(o["weights"].cpu().numpy(), sc["weights"], rtol=F32_ULP_RTOL)
+            # pixels: every stack slot is the ring frame the oracle's window names, or zeros when blanked
+            s, ns = o["states"].cpu().numpy(), o["next_states"].cpu().numpy()
+            h, n = mem.history, mem.n
+            for b in (0, B // 2, B - 1):
+                for t in range(h):
+                    for arr, slot in ((s, t), (ns, n + t)):
+                        want = (np.zeros((84, 84), np.uint8) if sc["blank"][b, slot]
+                                else mem._grab("frames", int(sc["ring"][b, slot]), 1)[0])
+                        assert np.array_equal(arr[b, t], want), (B, b, t, slot)
+
+
+def test_sampler_indices_match_oracle_at_1m(hip, full_mem):
+    """the 5-levels-per-trip descent of the sampler is pinned to the oracle on the 1M tree."""
+    mem, _ = full_mem
+    _check_sampler_against_oracle(hip, mem, (32, 256), seed=77)
+
+
+def test_sampler_indices_match_oracle_at_100k_nstep20(hip):
+    """BASELINE config 4's replay: C = 100k (tree depth 17: one 5-level trip + one 1-level trip), n = 20 windows."""
+    from rainbow_amd.memory import ReplayMemory
+    cap = 100_000
+    mem = ReplayMemory(_args(multi_step=20), cap, seed=8)
+    _fill_full(mem, cap, 20_000, 3)
+    _check_sampler_against_oracle(hip, mem, (32, 256), seed=78)
+
+
+def test_device_rng_sampler_frequencies(hip):
+    """The PRODUCTION random path of the sampler (device Philox, no injected uniforms): over 10^4 batches on a small tree
+    every stratum yields exactly one sample per batch (memory.py:125-129) and the empirical leaf frequencies follow
+    priority / total (each leaf's count is Binomial: within 5 sigma, and a chi-square over the leaves)."""
+    from rainbow_amd.memory import ReplayMemory
+    cap, B, rounds = 256, 16, 10_000
+    mem = ReplayMemory(_args(), cap, seed=12345)
+    _fill(mem, None, cap + 40, seed=3, p_term=0.0)          # full; write head at 40
+    tree_start = tree_geometry(cap)[1]
+    rs = np.random.RandomState(4)
+    pri = (rs.random_sample(cap) * 2 + 0.05).astype(np.float32)
+    mem.update_priorities(np.arange(cap) + tree_start, pri)    # leaves = pri ** 0.5
+    tree = mem._grab("tree")
+    leaves = tree[tree_start:].astype(np.float64)
+    total = float(tree[0])
+    out = torch.empty(rounds, B, dtype=torch.int64, device="cuda")
+    attempts = np.empty(rounds, dtype=np.int64)
+    for r in range(rounds):
+        o = mem.sample_device(B)
+        out[r].copy_(o["tree_idxs"])
+        if r % 500 == 0:
+            assert mem._header().last_status == 0
+    torch.cuda.synchronize()
+    idx = out.cpu().numpy() - tree_start
+    # one sample per stratum: sample i lies in [i*seg, (i+1)*seg) => its leaf's prefix bracket intersects the stratum
+    csum = np.cumsum(leaves)
+    seg = total / B
+    lo, hi = csum[idx] - leaves[idx], csum[idx]
+    i = np.arange(B)[None, :]
+    tol = 1e-5 * total
+    assert np.all(hi >= i * seg - tol) and np.all(lo <= (i + 1) * seg + tol)
+    assert np.all(np.diff(idx, axis=1) >= 0)
+    # frequencies: a batch is rejected as a whole when any leaf is within the write head's exclusion zone
+    # (memory.py:131), which conditions the distribution; compare on leaves whose stratum never contains an excluded leaf
+    head = 40
+    bad = np.zeros(cap, dtype=bool)
+    bad[[(head - k) % cap for k in range(0, 4)]] = True         # (index - idx) % C <= n
+    bad[[(head + k) % cap for k in range(0, 4)]] = True         # (idx - index) % C < h
+    counts = np.bincount(idx.ravel(), minlength=cap).astype(np.float64)
+    # P(leaf j drawn by stratum i) = overlap(j, i) / seg; rejection is independent across strata, so conditioning on
+    # "no stratum drew an excluded leaf" leaves the clean strata's distributions unchanged
+    edges = np.concatenate([[0.0], csum])
+    expect = np.zeros(cap)
+    clean = np.ones(cap, dtype=bool)
+    for s in range(B):
+        a, b = s * seg, (s + 1) * seg
+        ov = np.clip(np.minimum(edges[1:], b) - np.maximum(edges[:-1], a), 0, None)
+        touched = ov > 0
+        if np.any(bad & touched):
+            clean[touched] = False
+        else:
+            expect += ov / seg
+    sel = clean & (expect > 0)
+    assert sel.sum() > cap // 2
+    n_exp = expect[sel] * rounds
+    sigma = np.sqrt(np.maximum(n_exp * (1 - np.minimum(expect[sel], 1.0)), 1.0))
+    z = (counts[sel] - n_exp) / sigma
+    assert np.max(np.abs(z)) < 5.0, float(np.max(np.abs(z)))
+    chi2 = float(np.sum(z ** 2))
+    dof = int(sel.sum())
+    assert abs(chi2 - dof) < 6.0 * np.sqrt(2.0 * dof), (chi2, dof)
