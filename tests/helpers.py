@@ -46,7 +46,12 @@ def assert_learn_trace_matches(trace, golden, label="", grad_rtol=2e-4, grad_ato
             np.testing.assert_allclose(got, want, rtol=grad_rtol, atol=atol, err_msg="%s %s" % (label, key))
         elif "_param/" in key:
             np.testing.assert_allclose(got, want, rtol=0, atol=param_atol, err_msg="%s %s" % (label, key))
-        else:  # loss, grad norms, q values
+        elif key.endswith("grad_norm"):
+            # the reference's own clip_grad_norm_ total is a float32 reduction over 3.2 M-element tensors: measured
+            # 1.5e-5 .. 2.3e-5 away from the exact (float64) norm of its own gradients at the BASELINE shapes, while the
+            # device norm is within 1e-7 of exact (tools/diag_shape.py) — so the bound is the reference's noise
+            np.testing.assert_allclose(got, want, rtol=5e-5, atol=1e-7, err_msg="%s %s" % (label, key))
+        else:  # loss, q values
             np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7, err_msg="%s %s" % (label, key))
 
 
