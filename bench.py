@@ -2,23 +2,26 @@
 """bench.py — Rainbow learn-step throughput on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 without a launcher: the script re-executes itself under torch.distributed.run with N ranks (one per GPU) and
+  fails loudly when fewer than N GPUs are visible; under a launcher (WORLD_SIZE set) it checks WORLD_SIZE == N.
 
 One "step" = one complete gradient step of the hot path on synthetic transitions already
-resident in HBM:  online noise resample -> Agent.learn(mem) = PER sample (sum-tree search +
-frame-stack gather) -> 3 forwards -> C51 projection / loss -> backward -> [RCCL all-reduce]
+resident in HBM:  online noise resample -> Agent.learn(mem) = PER sample (sum-tree search, frames
+read in place) -> 3 forwards -> C51 projection / loss -> backward -> [replica exchange over RCCL]
 -> global-norm clip -> Adam -> priority update.          (reference: main.py:151,164; agent.py:61-100)
 
 Workload (SURVEY §8d / BASELINE.md §3): config 2 — canonical network, batch 32, 51 atoms,
 6 actions, n=3, 1M-capacity replay filled to capacity with the write head mid-buffer,
-non-uniform priorities.  Multi-GPU = independent replicas (own replay, own noise) with one
-gradient all-reduce per step; weak scaling (per-GPU work fixed).
+non-uniform priorities.  Multi-GPU = independent replicas (own replay, own noise) that exchange
+gradient information once per step (rainbow_amd/dist.py); weak scaling (per-GPU work fixed).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — dominant kernel (clip+Adam pass), timed live with HIP events on its own stream (rb_profile_*);
-                 roofline_others: the hidden-layer forward / backward streams, timed the same way
-  cpu_baseline — the CPU oracle (a port of the reference's algorithm: numpy replay + torch-CPU
-                 learner) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline        — the step's dominant kernel by time (chosen by a bracketed probe over every candidate),
+                    timed live with HIP events on its launch stream over the timed region (rb_profile_*)
+  roofline_others — every other candidate kernel, timed the same way in short passes after the timed region
+  roofline_step   — the whole step against SURVEY §8d's per-step algorithmic bytes / FLOPs
+  cpu_baseline    — the CPU oracle (a port of the reference's algorithm: numpy replay + torch-CPU
+                    learner) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
 """
 import argparse
 import ctypes as C
@@ -83,21 +86,73 @@ def fill_replay(mem, capacity, actions, seed):
     torch.cuda.synchronize(dev)
 
 
+CONV_GEOM = {   # (cin, cout, kernel, stride, in, out) per layer, model.py:55-63
+    "canonical": [(4, 32, 8, 4, 84, 20), (32, 64, 4, 2, 20, 9), (64, 64, 3, 1, 9, 7)],
+    "data-efficient": [(4, 32, 5, 5, 84, 16), (32, 64, 5, 5, 16, 3)],
+}
+
+
 def kernel_table(cfg, n_params):
-    """Algorithmic work per launch of the candidate dominant kernels."""
-    B, A = cfg["batch_size"], cfg["actions"]
-    H = cfg["hidden_size"]
-    F = 3136 if cfg["architecture"] == "canonical" else 576
+    """Algorithmic work per launch of the kernels that can dominate a step, with the roofline that bounds
+    each: the streamed hidden layer and the optimiser pass are HBM-bound, the conv kernels f32-MFMA-bound.
+    Keys are the profiling tags of the launches (RB_LAUNCH_T in csrc/learner.hip)."""
+    B, H = cfg["batch_size"], cfg["hidden_size"]
+    conv = CONV_GEOM[cfg["architecture"]]
+    F = conv[-1][1] * conv[-1][5] ** 2
     wh = 2 * H * F * 4                      # one of mu / sigma of the fused hidden layer, bytes
-    return {
-        # clip + Adam over the flat buffers: reads p, g, m, v and writes p, m, v once (the step's largest kernel)
+    t = {
+        # clip + Adam over the flat buffers: reads p, g, m, v and writes p, m, v once
         "clip_adam": dict(bound="hbm", work=7 * 4 * n_params, unit="GB/s"),
         # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident
         "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4 + 3 * B * 2 * H * 4 * 2, unit="GB/s"),
-        # hidden layer weight grads: writes d_mu + d_sigma once
         # hidden layer backward (one launch): streams mu+sigma of the online net once (dX), writes d_mu + d_sigma once (dW)
         "fc_h_bwd": dict(bound="hbm", work=2 * wh + 2 * wh + B * (F + 2 * H) * 4, unit="GB/s"),
     }
+    dw = 0
+    for i, (cin, cout, ks, _s, _ih, oh) in enumerate(conv):
+        K, P = cin * ks * ks, oh * oh
+        t["conv%d_fwd" % (i + 1)] = dict(bound="mfma", work=2 * 3 * B * cout * P * K, unit="TFLOP/s")     # 3B images
+        if i > 0:
+            t["conv%d_dx" % (i + 1)] = dict(bound="mfma", work=2 * B * cout * P * K, unit="TFLOP/s")
+        dw += 2 * B * cout * P * (K + 1)
+    t["conv_dw_all"] = dict(bound="mfma", work=dw, unit="TFLOP/s")
+    return t
+
+
+def step_work(cfg, n_params):
+    """Per-step algorithmic work: FLOPs = B (5 F - F_conv1), bytes = 4P (2 weight reads + grad write + 7 Adam)
+    + frame windows."""
+    B, H, A = cfg["batch_size"], cfg["hidden_size"], cfg["actions"]
+    conv = CONV_GEOM[cfg["architecture"]]
+    fl = [2 * cout * oh * oh * cin * ks * ks for (cin, cout, ks, _s, _ih, oh) in conv]
+    F = conv[-1][1] * conv[-1][5] ** 2
+    fc = 2 * (2 * H * F + (51 + A * 51) * H)
+    per_sample = sum(fl) + fc
+    flops = B * (5 * per_sample - fl[0])
+    nbytes = 4 * n_params * 10 + B * (4 + cfg["multi_step"]) * 7056
+    return flops, nbytes
+
+
+def achieved(k, seconds):
+    if k["bound"] == "hbm":
+        return k["work"] / seconds / 1e9, HBM_PEAK_GBS
+    return k["work"] / seconds / 1e12, F32_MFMA_PEAK_TF
+
+
+def respawn_under_torchrun(opt):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) under
+    torch.distributed.run on this node and hand the terminal over to it."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < opt.gpus:
+        sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (opt.gpus, n_dev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opt.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
 
 
 def time_cpu_baseline(cfg, seconds=20.0):
@@ -171,7 +226,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="pong-canonical-b32", choices=sorted(CONFIGS))
-    ap.add_argument("--roofline-kernel", default="clip_adam")
+    ap.add_argument("--roofline-kernel", default="auto",
+                    help="profiling tag of the kernel the roofline object reports (default: the dominant one, measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
     ap.add_argument("--graph", action="store_true",
@@ -180,9 +236,13 @@ def main():
     opt = ap.parse_args()
 
     os.environ["RAINBOW_AMD_GRAPH"] = "1" if opt.graph else "0"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(opt)          # does not return
+    if world != opt.gpus and not (world == 1 and os.environ.get("RAINBOW_AMD_FORCE_DIST") == "1"):
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (opt.gpus, world))
     import __graft_entry__
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         __graft_entry__.build()
@@ -190,6 +250,8 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         torch.distributed.barrier()
@@ -197,6 +259,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from rainbow_amd import _lib as L
+    from rainbow_amd import dist as rdist
     from rainbow_amd.agent import Agent
     from rainbow_amd.memory import ReplayMemory
 
@@ -216,12 +279,29 @@ def main():
         agent.reset_noise()      # main.py:151
         agent.learn(mem)         # main.py:164
 
+    def bracketed(tag, n):
+        """n steps with every launch tagged `tag` bracketed by two HIP events on its own stream -> mean seconds / launch."""
+        lib.rb_profile_select(tag.encode())
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize(dev)
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        lib.rb_profile_read(C.byref(ms), C.byref(cnt))
+        lib.rb_profile_select(None)
+        return (ms.value / cnt.value * 1e-3, cnt.value) if cnt.value > 0 else (None, 0)
+
     for _ in range(opt.warmup):
         step()
     torch.cuda.synchronize(dev)
 
     ktab = kernel_table(cfg, int(agent.params.numel()))
-    kname = opt.roofline_kernel if opt.roofline_kernel in ktab else "clip_adam"
+    # the kernel the roofline object reports = the step's DOMINANT kernel by time, found by a short bracketed pass over
+    # every candidate before the timed region (or forced with --roofline-kernel)
+    if opt.roofline_kernel in ktab:
+        kname = opt.roofline_kernel
+    else:
+        probe = {k: bracketed(k, 30)[0] for k in ktab}
+        kname = max((k for k in probe if probe[k] is not None), key=lambda k: probe[k])
     lib.rb_profile_select(kname.encode())
     if world > 1 or force_dist:
         torch.distributed.barrier()
@@ -240,26 +320,26 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    # the other GB-scale kernels, each timed the same way in a short pass of its own AFTER the timed region
+    # the same number of steps WITHOUT the event pair around the dominant kernel (what the bracketing itself costs)
+    torch.cuda.synchronize(dev)
+    t_plain = time.perf_counter()
+    for _ in range(min(opt.steps, 500)):
+        step()
+    torch.cuda.synchronize(dev)
+    plain_ms = (time.perf_counter() - t_plain) / min(opt.steps, 500) * 1e3
+    # every other candidate, each timed the same way in a short pass of its own AFTER the timed region
     others = {}
     for other in ktab:
-        if other == kname:
-            continue
-        lib.rb_profile_select(other.encode())
-        for _ in range(min(200, opt.steps)):
-            step()
-        torch.cuda.synchronize(dev)
-        o_ms, o_n = C.c_double(0), C.c_int64(0)
-        lib.rb_profile_read(C.byref(o_ms), C.byref(o_n))
-        lib.rb_profile_select(None)
-        if o_n.value > 0:
-            others[other] = (o_ms.value / o_n.value * 1e-3, o_n.value)
+        if other != kname:
+            t, n = bracketed(other, min(200, opt.steps))
+            if t is not None:
+                others[other] = (t, n)
     ev_ms = C.c_double(0)
     lib.rb_profile_overhead(torch.cuda.current_stream(dev).cuda_stream, 256, C.byref(ev_ms))
     ev_us = ev_ms.value * 1e3          # what an EMPTY event pair reads: reported, not subtracted (rocprof's duration of
                                        # the same kernel sits between avg_us and avg_us - event_pair_overhead_us)
     hdr = mem._header()
-    assert hdr.last_status == 0, "device sampler failed"
+    assert hdr.last_status == 0 and mem.failed_samples() == 0, "device sampler failed"
     assert bool(torch.isfinite(agent._loss).all()), "non-finite loss"
 
     # PER-only throughput (sample + priority update, no learner), same replay
@@ -279,6 +359,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / opt.steps * 1e3
+        par = "single device" if world == 1 else "replicas x%d, exchange=%s" % (world, rdist.mode())
         out = {
             "metric": "gradient-steps/sec (batch=%d, atoms=51)" % B, "value": world * opt.steps / elapsed,
             "unit": "gradient-steps/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
@@ -286,27 +367,35 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": opt.config, "architecture": cfg["architecture"], "batch_per_gpu": B,
                        "global_batch": B * world, "atoms": 51, "actions": cfg["actions"], "multi_step": cfg["multi_step"],
-                       "replay_capacity_per_gpu": cfg["capacity"], "parallelism": "replicas x%d + grad all-reduce" % world},
+                       "replay_capacity_per_gpu": cfg["capacity"], "parallelism": par},
             "per_samples_per_s": per_rate * world,
+            "ms_per_step_unbracketed": plain_ms,
         }
-        k = ktab[kname]
+        # counter traffic: only from a PMC pass of THIS config that is committed under profiles/ (tools/gpu_pmc.sh);
+        # null otherwise — never a number measured on another workload
+        pmc_path = os.path.join(ROOT, "profiles", "round2_pmc_%s.json" % opt.config)
+        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+
+        def roof(name, seconds, n):
+            k = ktab[name]
+            ach, peak = achieved(k, seconds)
+            return {"kernel": name, "bound": k["bound"], "achieved": ach, "peak": peak, "unit": k["unit"], "frac": ach / peak,
+                    "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"), "avg_us": seconds * 1e6, "launches": n,
+                    "algorithmic_work_per_launch": k["work"]}
+
         if launches.value > 0:
-            avg_s = tot_ms.value / launches.value * 1e-3     # raw event-pair time (includes the bracketing, see below)
-            if k["bound"] == "hbm":
-                achieved, peak = k["work"] / avg_s / 1e9, HBM_PEAK_GBS
-            else:
-                achieved, peak = k["work"] / avg_s / 1e12, F32_MFMA_PEAK_TF
-            pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")   # rocprofv3 --pmc passes (tools/gpu_pmc.sh), per launch
-            pmc = json.load(open(pmc)) if os.path.exists(pmc) else {}
-            out["roofline"] = {"kernel": kname, "bound": k["bound"], "achieved": achieved, "peak": peak, "unit": k["unit"],
-                               "frac": achieved / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
-                               "avg_us": avg_s * 1e6, "launches": launches.value,
-                               "algorithmic_work_per_launch": k["work"], "event_pair_overhead_us": ev_us}
-            out["roofline_others"] = [
-                {"kernel": o, "bound": "hbm", "achieved": ktab[o]["work"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": ktab[o]["work"] / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get(o, {}).get("hbm_bytes_per_launch"),
-                 "avg_us": t * 1e6, "launches": n, "algorithmic_work_per_launch": ktab[o]["work"]}
-                for o, (t, n) in others.items()]
+            out["roofline"] = roof(kname, tot_ms.value / launches.value * 1e-3, launches.value)
+            out["roofline"]["event_pair_overhead_us"] = ev_us
+            out["roofline"]["selected"] = "forced" if opt.roofline_kernel in ktab else "largest mean launch time of a 30-step probe"
+            out["roofline_others"] = [roof(o, t, n) for o, (t, n) in sorted(others.items(), key=lambda kv: -kv[1][0])]
+        flops, nbytes = step_work(cfg, int(agent.params.numel()))
+        t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (F32_MFMA_PEAK_TF * 1e12)
+        sec = elapsed / opt.steps
+        out["roofline_step"] = ({"bound": "hbm", "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": t_hbm / sec} if t_hbm >= t_mfma else
+                                {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": t_mfma / sec})
+        out["roofline_step"].update(algorithmic_flops=flops, algorithmic_bytes=nbytes)
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(cfg)
         print(json.dumps(out))

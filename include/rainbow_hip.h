@@ -278,6 +278,26 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg_dev, fl
 int rb_learner_set_priority_sink(rb_learner_t* l, rb_replay_t* replay, const int64_t* tree_idx_dev);
 int rb_learner_priority_written(rb_learner_t* l);
 
+/* ---- Replica exchange (the reference is single-device, the insert point is between agent.py:96 and :97).
+ * Every replica must apply the MEAN gradient.  27 MB of it are the noisy-linear weight gradients, and those are rank-B
+ * products  dW = dY^T X  of two thin matrices: instead of all-reducing dW (2 x 7/8 x 27 MB through each GPU's xGMI links),
+ * the replicas all-gather the FACTORS (dlogits, h, dh, feat rows of their batch: `factor_floats` per rank, 0.7 MB at the
+ * canonical shape) and each computes the mean gradient of the global batch from the gathered rows itself — identical
+ * inputs, identical kernel, identical bits on every replica.  Only the conv gradients ([small_offset, +small_floats) of
+ * grads_dev, 0.3 MB) are all-reduced.
+ *   rb_learner_set_exchange(world > 1, local block, gathered blocks [world][factor_floats])   once
+ *   per step:  rb_learner_learn*            input-gradient chain, conv grads, local factor block; NO FC weight grads
+ *              rb_learner_wait_factors(s)   stream s waits until the local block is complete (it is after the output
+ *                                           layer's backward launch, i.e. the all-gather overlaps the rest of the backward)
+ *              [caller: all-gather factors on s; all-reduce(mean) grads_dev[small range]; join s]
+ *              rb_learner_finish_grads      FC weight/bias gradients of the global batch (x 1/world) + norm partials
+ *              rb_learner_clip_adam / rb_learner_clip_grad as usual
+ * world == 1 (default) restores the single-device step.                                                           */
+int rb_learner_exchange_layout(rb_learner_t* l, int64_t* factor_floats, int64_t* small_offset, int64_t* small_floats);
+int rb_learner_set_exchange(rb_learner_t* l, int32_t world, float* factors_local_dev, const float* factors_all_dev);
+int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream);
+int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream);
+
 /* Tell the library the caller changed grads_dev after rb_learner_learn (e.g. the RCCL
  * all-reduce of the replica path): the sum of squares the backward kernels accumulated on
  * the fly is then stale and rb_learner_clip_grad re-reads the gradient.                    */

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librainbow_hip.so")
+# RAINBOW_AMD_LIB: another build of the SAME sources (e.g. with an experiment's -D switch) for same-box A/B runs
+LIB_PATH = os.environ.get("RAINBOW_AMD_LIB") or os.path.join(_HERE, "librainbow_hip.so")
 
 c_void_p, c_int, c_int32, c_int64, c_uint64 = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64
 c_float, c_double, c_char_p = C.c_float, C.c_double, C.c_char_p
@@ -90,6 +91,10 @@ SIGNATURES = {
     "rb_learner_set_priority_sink": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rb_learner_priority_written": (c_int, [c_void_p]),
     "rb_learner_grads_modified": (c_int, [c_void_p]),
+    "rb_learner_exchange_layout": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int64)]),
+    "rb_learner_set_exchange": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "rb_learner_wait_factors": (c_int, [c_void_p, c_void_p]),
+    "rb_learner_finish_grads": (c_int, [c_void_p, c_void_p]),
     "rb_learner_sync_target": (c_int, [c_void_p, c_void_p]),
     "rb_learner_debug_read": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
 }

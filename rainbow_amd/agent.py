@@ -13,8 +13,10 @@ learn(mem):  rainbow_amd.memory.ReplayMemory  -> fully device-resident step, no 
              any other object with the reference's sample()/update_priorities() -> compat path.
 
 Multi-GPU (BASELINE config 5): one process per GPU, identical parameters, each replica owns its
-replay; gradients are averaged with ONE RCCL all-reduce of the flat buffer between backward and
-clip.  Enabled automatically when torch.distributed is initialised.
+replay; between backward and clip every replica obtains the mean gradient of the global batch
+(rainbow_amd/dist.py: all-gather of the FC gradient FACTORS + all-reduce of the conv gradients by
+default, or one all-reduce of the flat buffer).  Enabled automatically when torch.distributed is
+initialised.
 """
 import ctypes as C
 import math
@@ -158,9 +160,12 @@ class Agent:
         self._ev_upd = torch.cuda.Event()
         self._world = rdist.world_size()
         self._dist = rdist.active()
+        self._exchange = None
         if self._dist:        # identical replicas: rank 0's initial parameters everywhere
             rdist.broadcast_parameters(self.params.detach(), 0)
             self.update_target_net()
+            if rdist.mode() == "factored" and isinstance(self.optimiser, _FlatAdam):
+                self._exchange = rdist.FactoredExchange(self._lib, self._h, self.grads)
 
     # ------------------------------------------------------------------ plumbing
     def __del__(self):
@@ -380,7 +385,11 @@ class Agent:
                 self._side.wait_event(self._ev_loss)
                 mem.update_priorities(idxs, self._loss)
                 self._ev_upd.record(self._side)
-        if self._dist:        # replicas: average the flat gradient over xGMI (one RCCL all-reduce, 4*P bytes)
+        if self._exchange is not None:
+            # replicas, factored exchange: all-gather the FC gradient factors (0.7 MB, side stream, under the rest of the
+            # backward), all-reduce the conv gradients (0.3 MB), finish the FC gradients of the global batch on device
+            self._exchange.run()
+        elif self._dist:      # replicas, plain exchange: one RCCL all-reduce of the flat gradient (4*P bytes)
             rdist.average_gradients(self.grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         if isinstance(self.optimiser, _FlatAdam):

@@ -153,6 +153,16 @@ struct rb_learner {
   int use_side;
   hipStream_t side[2];
   hipEvent_t ev[8];
+  // replica exchange: world > 1 defers the noisy-linear WEIGHT gradients — instead of all-reducing 27 MB of
+  // gradient, the replicas all-gather the two factors of every FC gradient (dY and X rows, 0.7 MB per rank) and each
+  // computes the replica-mean gradient from the gathered rows itself (rb_learner_finish_grads)
+  int world;
+  float* fact_local;        // [fact_stride] this rank's factor block, written by the learn call
+  const float* fact_all;    // [world][fact_stride] every rank's block (the all-gather's output)
+  int64_t fact_off[5];      // dlogits [B][NZ] | h [B][2H] | dh [B][2H] | feat [B][F] | this rank's online noise [n_noise]
+  int64_t fact_stride;
+  hipEvent_t ev_fact;       // recorded when fact_local is complete (the all-gather may start under the rest of the backward)
+  int exch_pending;         // a learn call left its FC weight gradients to rb_learner_finish_grads
   float gamma_n;        // float32(discount ** n)        agent.py:79
   float delta_z;        // float32((Vmax - Vmin)/(Z-1))   agent.py:19,82
 };
@@ -251,6 +261,24 @@ __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
     my = rb_wave_sum(my);
     if (threadIdx.x == 0) a.sq_part[blockIdx.x] = my;
   }
+}
+
+// the four factor matrices of the FC weight gradients, rows [0, B), packed into one block for the replica all-gather
+struct PackArgs {
+  const float* src[5];
+  int64_t count[5];
+  int64_t dst_off[5];
+  float* dst;
+};
+__global__ __launch_bounds__(256) void k_pack_factors(PackArgs a) {
+  const int which = (int)blockIdx.y;
+  const int64_t n4 = a.count[which] >> 2;      // all segment sizes are multiples of 4 floats (fast_fc preconditions)
+  const float* src = a.src[which];
+  float* dst = a.dst + a.dst_off[which];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    rb_st4(dst + 4 * i, rb_ld4(src + 4 * i));
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < a.count[which]; i += blockDim.x) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------- head --
@@ -503,6 +531,25 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* g, int64_t n, float*
   acc = rb_block_sum(acc, s_red);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
+// rb_learner_finish_grads as ONE launch (three dependent-free jobs would otherwise queue as three ~10 us kernels on the
+// replica step's critical path): block ranges [fc_z dW tiles | fc_h dW tiles | sum of squares of the all-reduced conv range]
+struct FinishArgs {
+  NlDwArgs z, h;
+  int z_x, z_n, h_x, h_n;      // grid.x and block count of each weight-gradient problem
+  const float* g; int64_t n; float* part; int nparts;
+};
+__global__ __launch_bounds__(256) void k_finish_grads(FinishArgs a) {
+  __shared__ float s_red[16];
+  int b = (int)blockIdx.x;
+  if (b < a.z_n) { rb_nl_dw_body_ranks(a.z, b % a.z_x, b / a.z_x, 4 * b); return; }
+  b -= a.z_n;
+  if (b < a.h_n) { rb_nl_dw_body_ranks(a.h, b % a.h_x, b / a.h_x, 4 * b); return; }
+  b -= a.h_n;
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < a.n; i += (int64_t)a.nparts * 256) acc = fmaf(a.g[i], a.g[i], acc);
+  acc = rb_block_sum(acc, s_red);
+  if (threadIdx.x == 0) a.part[b] = acc;
+}
 // Stage 2: every block re-reduces the partials (same order everywhere), then scales its slice.
 __global__ __launch_bounds__(256) void k_clip_scale(float* g, int64_t n, const float* part, int nparts, float max_norm,
                                                      float* norm_out) {
@@ -634,9 +681,10 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
-  RB_LAUNCH((k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH>),
-            dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
-            dim3(RB_CONV_THREADS), stream, a);
+  static const char* const tags[3] = {"conv1_fwd:k_conv_fwd_lds", "conv2_fwd:k_conv_fwd_lds", "conv3_fwd:k_conv_fwd_lds"};
+  RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH>),
+              dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
+              dim3(RB_CONV_THREADS), stream, a);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }
@@ -813,8 +861,9 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     // few images at batch 32: spread each phase's positions over several workgroups (weights are re-staged from L2)
     constexpr int NT = NT_ALL >= 4 ? 2 : 1;
     const unsigned groups = (unsigned)rb_div_up(NT_ALL, NT);
-    RB_LAUNCH((k_conv_dx_lds<G, NT, 64>), dim3((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B),
-              dim3(RB_CONV_THREADS), stream, a);
+    static const char* const tags[3] = {"conv1_dx:k_conv_dx_lds", "conv2_dx:k_conv_dx_lds", "conv3_dx:k_conv_dx_lds"};
+    RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64>), dim3((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B),
+                dim3(RB_CONV_THREADS), stream, a);
     RB_LAUNCH_CHECK();
   } else if (layer > 0) {
     ConvDxProb<G> p;
@@ -977,6 +1026,7 @@ int rb_learner_destroy(rb_learner_t* l) {
     if (*p) (void)hipFree(*p);
   if (l->a_star) (void)hipFree(l->a_star);
   if (l->noise_ctr) (void)hipFree(l->noise_ctr);
+  if (l->ev_fact) (void)hipEventDestroy(l->ev_fact);
   if (l->use_side) {
     for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
     for (int i = 0; i < 8; ++i) if (l->ev[i]) (void)hipEventDestroy(l->ev[i]);
@@ -1000,6 +1050,13 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->p_online = online_params_dev; l->p_target = target_params_dev; l->grads = grads_dev;
   l->n_online = online_noise_dev; l->n_target = target_noise_dev;
   l->seed = seed; l->noise_epoch = 0;
+  l->world = 1;
+  {
+    const int64_t seg[5] = {(int64_t)L.B * L.NZ, (int64_t)L.B * 2 * L.H, (int64_t)L.B * 2 * L.H, (int64_t)L.B * L.F, L.n_noise};
+    int64_t off = 0;
+    for (int i = 0; i < 5; ++i) { l->fact_off[i] = off; off = align64(off + seg[i]); }
+    l->fact_stride = off;
+  }
   l->gamma_n = (float)pow(cfg->discount, (double)cfg->multi_step);
   l->delta_z = (float)(((double)cfg->v_max - (double)cfg->v_min) / (double)(cfg->atoms - 1));
   const int B = L.B, NI = 3 * B;
@@ -1197,6 +1254,41 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
                       const float* returns_dev, const float* nonterminals_dev, const float* weights_dev, float* loss_dev,
                       hipStream_t stream);
 
+// Weight-gradient problem of one noisy layer pair (which = 0: fc_z_v | fc_z_a, 1: fc_h_v | fc_h_a) over M reduction rows
+// of dy / x.  ct > 0 selects the pipelined body (M <= 32).  slots = sum-of-squares partials the launch writes.
+struct FcDwPlan {
+  NlDwArgs a;
+  int dw_x, dw_y, slots;
+};
+static FcDwPlan fc_dw_plan(rb_learner* l, const NetPtrs& on, int which, const float* dy, const float* x, int M, int ct) {
+  const Layout& L = l->L;
+  FcDwPlan p;
+  NlDwArgs& w = p.a;
+  memset(&w, 0, sizeof(w));
+  w.dy = dy; w.x = x; w.M = M; w.n_prob = 2; w.ct = ct; w.rpb = 0; w.bstride = 0; w.scale = 1.0f; w.sq_part = nullptr;
+  w.noise_blocks = nullptr; w.eout_noff = 0; w.ein_noff = 0;
+  if (which == 0) {
+    const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
+    w.ldy = L.NZ; w.ldx = 2 * L.H; w.K = L.H;
+    w.prob[0] = NlDwProblem{0, L.Z, 0, 0, 0};
+    w.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
+    w.g_mu = l->grads + L.z_mu; w.g_sigma = l->grads + L.z_sigma; w.g_bmu = l->grads + L.z_bmu; w.g_bsigma = l->grads + L.z_bsigma;
+    w.eout = on.z_eout; w.ein = on.z_ein;
+    p.dw_y = vt + at;
+  } else {
+    const int ht = (int)rb_div_up(L.H, 16);
+    w.ldy = 2 * L.H; w.ldx = L.F; w.K = L.F;
+    w.prob[0] = NlDwProblem{0, L.H, 0, 0, 0};
+    w.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
+    w.g_mu = l->grads + L.h_mu; w.g_sigma = l->grads + L.h_sigma; w.g_bmu = l->grads + L.h_bmu; w.g_bsigma = l->grads + L.h_bsigma;
+    w.eout = on.h_eout; w.ein = on.h_ein;
+    p.dw_y = 2 * ht;
+  }
+  p.dw_x = (int)rb_div_up(w.K, 256 * (ct > 0 ? ct : 1));
+  p.slots = 4 * p.dw_x * p.dw_y;
+  return p;
+}
+
 int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* next_states_dev,
                      const int64_t* actions_dev, const float* returns_dev, const float* nonterminals_dev,
                      const float* weights_dev, float* loss_dev, rb_stream_t stream_) {
@@ -1255,49 +1347,38 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     return RB_OK;
   };
   const float* feat = l->act[L.nconv - 1];
+  const bool exch = l->world > 1 && l->fact_local != nullptr && l->fast_fc;   // replica exchange: FC weight grads deferred
+  if (exch && side) { rb_set_error("rb_learner_learn: RB_SIDE_STREAMS and the replica exchange are mutually exclusive"); return RB_ERR_STATE; }
+  l->exch_pending = 0;
   if (l->fast_fc) {
     // ---- output layer: weight/bias grads and (ReLU-masked) input grads in one launch
-    NlDwArgs zw;
-    zw.dy = l->dlogits; zw.x = l->h; zw.ldy = L.NZ; zw.ldx = 2 * L.H; zw.M = B; zw.K = L.H; zw.n_prob = 2;
-    const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
-    zw.prob[0] = NlDwProblem{0, L.Z, 0, 0, 0};
-    zw.prob[1] = NlDwProblem{L.Z, L.NZ - L.Z, L.H, L.H, vt};
-    zw.g_mu = l->grads + L.z_mu; zw.g_sigma = l->grads + L.z_sigma; zw.g_bmu = l->grads + L.z_bmu;
-    zw.g_bsigma = l->grads + L.z_bsigma; zw.eout = on.z_eout; zw.ein = on.z_ein;
     // sum-of-squares slots (clip_grad_norm_ without re-reading the gradient): [fc_z dW waves | fc_h dW waves | conv reduce blocks]
     // pipelined weight-gradient body (one reduction pass per tile, i.e. batch <= 32): column tiles per wave
     static const int ct_env = getenv("RB_DW_CT") ? atoi(getenv("RB_DW_CT")) : -1;      // A/B switch
-    const bool pipe = B <= 32 && !side;                  // (the side-stream variant launches the plain k_nl_dw)
+    const bool pipe = B <= 32 && !side && !exch;         // (the side-stream variant launches the plain k_nl_dw)
     const int z_ct = pipe ? (ct_env >= 0 ? (ct_env > 2 ? 2 : ct_env) : 2) : 0;
     const int h_ct = pipe ? (ct_env >= 0 ? ct_env : 4) : 0;
-    const int z_dwx = (int)rb_div_up(L.H, 256 * (z_ct > 0 ? z_ct : 1)), h_dwx = (int)rb_div_up(L.F, 256 * (h_ct > 0 ? h_ct : 1));
-    const int z_slots = 4 * z_dwx * (vt + at);
-    const int h_slots = 4 * h_dwx * 2 * (int)rb_div_up(L.H, 16);
+    FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
+    FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, feat, B, h_ct);
     int64_t conv_out = 0;
     for (int layer = 0; layer < L.nconv; ++layer) conv_out += (int64_t)L.conv[layer].cout * (L.conv[layer].K() + 1);
     const int c_slots = (int)rb_div_up(conv_out, 64);
-    const bool fuse_norm = !side && z_slots + h_slots + c_slots <= 16384;
+    const bool fuse_norm = !side && !exch && zp.slots + hp.slots + c_slots <= 16384;
+    NlDwArgs& zw = zp.a;
+    NlDwArgs& hw_ = hp.a;
     zw.sq_part = fuse_norm ? l->norm_part : nullptr;
-    zw.ct = z_ct;
+    hw_.sq_part = fuse_norm ? l->norm_part + zp.slots : nullptr;
+    l->norm_slots = fuse_norm ? zp.slots + hp.slots + c_slots : 0;
+    l->norm_conv_base = zp.slots + hp.slots;
+    const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16), ht = (int)rb_div_up(L.H, 16);
     NlDxArgs zx;
     zx.dy = l->dlogits; zx.ldy = L.NZ; zx.M = B; zx.w = nl_z(on); zx.K = L.H; zx.n_prob = 2;
     zx.prob[0] = NlDxProblem{0, L.Z, 1 << 30, 0, 0, 0};
     zx.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
     zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
     zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
-    NlBwdGrid zg{z_dwx, vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
+    NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
     // ---- hidden layer
-    NlDwArgs hw_;
-    hw_.dy = l->dh; hw_.x = feat; hw_.ldy = 2 * L.H; hw_.ldx = L.F; hw_.M = B; hw_.K = L.F; hw_.n_prob = 2;
-    const int ht = (int)rb_div_up(L.H, 16);
-    hw_.prob[0] = NlDwProblem{0, L.H, 0, 0, 0};
-    hw_.prob[1] = NlDwProblem{L.H, L.H, 0, L.F, ht};
-    hw_.g_mu = l->grads + L.h_mu; hw_.g_sigma = l->grads + L.h_sigma; hw_.g_bmu = l->grads + L.h_bmu;
-    hw_.g_bsigma = l->grads + L.h_bsigma; hw_.eout = on.h_eout; hw_.ein = on.h_ein;
-    hw_.sq_part = fuse_norm ? l->norm_part + z_slots : nullptr;
-    hw_.ct = h_ct;
-    l->norm_slots = fuse_norm ? z_slots + h_slots + c_slots : 0;
-    l->norm_conv_base = z_slots + h_slots;
     NlDxArgs hx;
     hx.dy = l->dh; hx.ldy = 2 * L.H; hx.M = B; hx.w = nl_h(on); hx.K = L.F; hx.n_prob = 1;
     hx.prob[0] = NlDxProblem{0, 2 * L.H, L.H, 0, L.F, 0};
@@ -1305,7 +1386,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hx.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
     const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
     hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
-    NlBwdGrid hg{h_dwx, 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
+    NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
     NlPriorityUpdate up;
     memset(&up, 0, sizeof(up));
     if (l->sink && B <= 256) {
@@ -1328,6 +1409,20 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
       RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd,
                   dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z + (up.enabled ? 1 : 0))), dim3(256), stream,
                   zw, zx, zg, up);
+      if (exch) {
+        // every factor of the FC weight gradients exists now (dlogits, h, dh, feat rows [0, B)): pack them for the
+        // all-gather, which the caller starts on a side stream as soon as ev_fact fires — under the rest of the backward
+        PackArgs pk;
+        pk.src[0] = l->dlogits; pk.src[1] = l->h; pk.src[2] = l->dh; pk.src[3] = feat; pk.src[4] = l->n_online;
+        pk.count[0] = (int64_t)B * L.NZ; pk.count[1] = (int64_t)B * 2 * L.H; pk.count[2] = (int64_t)B * 2 * L.H; pk.count[3] = (int64_t)B * L.F;
+        pk.count[4] = L.n_noise;
+        for (int i = 0; i < 5; ++i) pk.dst_off[i] = l->fact_off[i];
+        pk.dst = l->fact_local;
+        RB_LAUNCH(k_pack_factors, dim3(16, 5), dim3(256), stream, pk);
+        RB_LAUNCH_CHECK();
+        if (l->ev_fact) RB_HIP_TRY(hipEventRecord(l->ev_fact, stream));
+        l->exch_pending = 1;
+      }
       RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z)), dim3(256),
                   stream, hw_, hx, hg, none);
     }
@@ -1471,6 +1566,70 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
                 stream, a);
   }
   RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_exchange_layout(rb_learner_t* l, int64_t* factor_floats, int64_t* small_offset, int64_t* small_floats) {
+  RB_REQUIRE(l != nullptr, "rb_learner_exchange_layout: NULL handle");
+  if (factor_floats) *factor_floats = l->fact_stride;
+  if (small_offset) *small_offset = 0;            // the conv parameters lead the flat buffers (make_layout)
+  if (small_floats) *small_floats = l->L.h_mu;
+  return RB_OK;
+}
+
+int rb_learner_set_exchange(rb_learner_t* l, int32_t world, float* factors_local_dev, const float* factors_all_dev) {
+  RB_REQUIRE(l != nullptr, "rb_learner_set_exchange: NULL handle");
+  RB_REQUIRE(world >= 1 && world <= 64, "rb_learner_set_exchange: world must be in [1,64]");
+  if (world == 1) { l->world = 1; l->fact_local = nullptr; l->fact_all = nullptr; return RB_OK; }
+  RB_REQUIRE(factors_local_dev && factors_all_dev, "rb_learner_set_exchange: NULL factor buffer");
+  if (!l->fast_fc) {
+    rb_set_error("rb_learner_set_exchange: the factored exchange needs the streamed noisy-linear kernels (F, H multiples of 32); "
+                 "all-reduce the flat gradient and call rb_learner_grads_modified instead");
+    return RB_ERR_STATE;
+  }
+  if (!l->ev_fact) RB_HIP_TRY(hipEventCreateWithFlags(&l->ev_fact, hipEventDisableTiming));
+  l->world = world; l->fact_local = factors_local_dev; l->fact_all = factors_all_dev;
+  return RB_OK;
+}
+
+int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_wait_factors: NULL handle");
+  RB_REQUIRE(l->exch_pending, "rb_learner_wait_factors: no learn call with a pending exchange");
+  RB_HIP_TRY(hipStreamWaitEvent((hipStream_t)side_stream, l->ev_fact, 0));
+  return RB_OK;
+}
+
+int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
+  RB_REQUIRE(l != nullptr, "rb_learner_finish_grads: NULL handle");
+  RB_REQUIRE(l->exch_pending, "rb_learner_finish_grads: no learn call with a pending exchange");
+  hipStream_t stream = (hipStream_t)stream_;
+  const Layout& L = l->L;
+  const NetPtrs on = net_ptrs(L, l->p_online, l->n_online);
+  const int M = l->world * L.B;
+  const float* f = l->fact_all;
+  FcDwPlan zp = fc_dw_plan(l, on, 0, f + l->fact_off[0], f + l->fact_off[1], M, 0);
+  FcDwPlan hp = fc_dw_plan(l, on, 1, f + l->fact_off[2], f + l->fact_off[3], M, 0);
+  const int64_t conv_n = L.h_mu;
+  int c_slots = (int)rb_div_up(conv_n, 256 * 16);
+  if (c_slots > 1024) c_slots = 1024;
+  RB_REQUIRE(zp.slots + hp.slots + c_slots <= 16384, "rb_learner_finish_grads: too many norm partials");
+  for (FcDwPlan* p : {&zp, &hp}) {
+    p->a.rpb = L.B; p->a.bstride = l->fact_stride; p->a.scale = 1.0f / (float)l->world;
+    p->a.noise_blocks = f + l->fact_off[4];
+  }
+  zp.a.eout_noff = L.z_eout; zp.a.ein_noff = L.z_ein;
+  hp.a.eout_noff = L.h_eout; hp.a.ein_noff = L.h_ein;
+  zp.a.sq_part = l->norm_part;
+  hp.a.sq_part = l->norm_part + zp.slots;
+  FinishArgs fa;
+  fa.z = zp.a; fa.h = hp.a;
+  fa.z_x = zp.dw_x; fa.z_n = zp.dw_x * zp.dw_y; fa.h_x = hp.dw_x; fa.h_n = hp.dw_x * hp.dw_y;
+  // the conv gradients were all-reduced by the caller: their sum of squares is re-derived from the reduced values (0.3 MB)
+  fa.g = l->grads; fa.n = conv_n; fa.part = l->norm_part + zp.slots + hp.slots; fa.nparts = c_slots;
+  RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads, dim3((unsigned)(fa.z_n + fa.h_n + c_slots)), dim3(256), stream, fa);
+  RB_LAUNCH_CHECK();
+  l->norm_slots = zp.slots + hp.slots + c_slots;
+  l->exch_pending = 0;
   return RB_OK;
 }
 

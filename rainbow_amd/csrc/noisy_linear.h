@@ -424,6 +424,17 @@ struct NlDwArgs {
   float* sq_part;            // optional: one slot per (block, wave) receiving the sum of squares of what that wave wrote
                              // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
   int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave
+  // Replica exchange: the reduction rows are the all-gathered factor blocks of `world` ranks — row m lives in
+  // block m / rpb at row m % rpb, blocks `bstride` floats apart (rpb == 0: one plain matrix) — and the result is the
+  // replica MEAN: scale = 1 / world (a power of two for 2/4/8 replicas, i.e. exact; 1.0f otherwise leaves every bit alone)
+  int rpb;
+  int64_t bstride;
+  float scale;
+  // ... and every rank's gradient is noisy with ITS OWN epsilon (each replica resamples its own noise, agent.py:49,74):
+  // g_sigma = mean_r g_mu_r * (eps_out_r x eps_in_r).  The gathered blocks therefore carry each rank's noise buffer:
+  // rank r's eps_out / eps_in of this layer sit at noise_blocks + r * bstride + eout_noff / ein_noff.
+  const float* noise_blocks;
+  int64_t eout_noff, ein_noff;
 };
 
 // grid = (256-column tiles, 16-row tiles), block = 256: wave w owns columns [256*bx + 64*w, +64)
@@ -501,6 +512,113 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
         a.g_bmu[n] = gb;
         a.g_bsigma[n] = gbs;
         sq = fmaf(gb, gb, sq); sq = fmaf(gbs, gbs, sq);
+      }
+    }
+  }
+  if (a.sq_part) {                                        // wave-uniform
+    sq = rb_wave_sum(sq);
+    if (lane == 0) a.sq_part[slot_base + wave] = sq;
+  }
+}
+// Replica-exchange variant (rb_learner_finish_grads): the reduction rows are `M / rpb` rank blocks of rpb rows each.  Every
+// rank's block is reduced on its own (same MFMA order as the single-device bodies, so acc_r has the bits that rank alone
+// would have produced), then folded in rank order:  g_mu += acc_r ;  g_sigma += acc_r * (eps_out_r * eps_in_r) ; the sums
+// are scaled by 1 / world at the end — the arithmetic of "every replica computes its gradient, then all-reduce(mean)".
+__device__ __forceinline__ void rb_nl_dw_body_ranks(const NlDwArgs& a, int bx, int by, int slot_base) {
+  const int lane = rb_lane(), wave = rb_wave();
+  const int kt = bx * 256 + wave * 64;
+  if (kt >= a.K) {                                       // wave-uniform, no barriers below
+    if (a.sq_part && lane == 0) a.sq_part[slot_base + wave] = 0.0f;
+    return;
+  }
+  const int g = (a.n_prob > 1 && by >= a.prob[1].tile_begin) ? 1 : 0;
+  const NlDwProblem pr = a.prob[g];
+  const int row0 = pr.row_begin + (by - pr.tile_begin) * 16;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  const int c = lane & 15, q = lane >> 4;
+  int col4 = kt + 4 * c;
+  const bool cv = col4 < a.K;
+  if (!cv) col4 = a.K - 4;
+  int arow = row0 + c;
+  const bool av_ok = arow < row_end;
+  if (!av_ok) arow = row_end - 1;
+  const bool do_bias = kt == 0;
+  const int nranks = a.M / a.rpb;
+  rb_f32x4 gm[4], gs[4], gbm, gbs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    gbm[e] = 0.0f; gbs[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[j][e] = 0.0f; gs[j][e] = 0.0f; }
+  }
+  for (int r = 0; r < nranks; ++r) {
+    const float* dy = a.dy + (int64_t)r * a.bstride;
+    const float* x = a.x + (int64_t)r * a.bstride;
+    const float* nz = a.noise_blocks + (int64_t)r * a.bstride;
+    const float4 e4 = rb_ld4(nz + a.ein_noff + pr.ein_off + col4);
+    float eo4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = row0 + 4 * q + e;
+      eo4[e] = nz[a.eout_noff + (n < row_end ? n : row_end - 1)];
+    }
+    rb_f32x4 acc[4], accb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+    for (int mb = 0; mb < a.rpb; mb += 32) {
+      float avs[8];
+      float4 xs[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int m = mb + 4 * st + q;
+        const bool mv = m < a.rpb;
+        const int mcl = mv ? m : a.rpb - 1;
+        avs[st] = (mv && av_ok) ? dy[(int64_t)mcl * a.ldy + arow] : 0.0f;
+        xs[st] = rb_ld4(x + (int64_t)mcl * a.ldx + pr.x_off + col4);
+        if (!mv) { xs[st].x = 0.0f; xs[st].y = 0.0f; xs[st].z = 0.0f; xs[st].w = 0.0f; }
+      }
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        if (mb + 4 * st < a.rpb) {                         // uniform
+          acc[0] = rb_mfma16(avs[st], xs[st].x, acc[0]);
+          acc[1] = rb_mfma16(avs[st], xs[st].y, acc[1]);
+          acc[2] = rb_mfma16(avs[st], xs[st].z, acc[2]);
+          acc[3] = rb_mfma16(avs[st], xs[st].w, acc[3]);
+          if (do_bias) accb = rb_mfma16(avs[st], 1.0f, accb);   // wave-uniform
+        }
+      }
+    }
+    const float ej[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gm[j][e] = gm[j][e] + acc[j][e];
+        gs[j][e] = gs[j][e] + acc[j][e] * (eo4[e] * ej[j]);
+      }
+      gbm[e] = gbm[e] + accb[e];
+      gbs[e] = gbs[e] + accb[e] * eo4[e];
+    }
+  }
+  float sq = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    if (n < row_end) {
+      if (cv) {
+        float4 m4, s4;
+        m4.x = gm[0][e] * a.scale; m4.y = gm[1][e] * a.scale; m4.z = gm[2][e] * a.scale; m4.w = gm[3][e] * a.scale;
+        s4.x = gs[0][e] * a.scale; s4.y = gs[1][e] * a.scale; s4.z = gs[2][e] * a.scale; s4.w = gs[3][e] * a.scale;
+        rb_st4(a.g_mu + (int64_t)n * a.K + col4, m4);
+        rb_st4(a.g_sigma + (int64_t)n * a.K + col4, s4);
+        sq = fmaf(m4.x, m4.x, sq); sq = fmaf(m4.y, m4.y, sq); sq = fmaf(m4.z, m4.z, sq); sq = fmaf(m4.w, m4.w, sq);
+        sq = fmaf(s4.x, s4.x, sq); sq = fmaf(s4.y, s4.y, sq); sq = fmaf(s4.z, s4.z, sq); sq = fmaf(s4.w, s4.w, sq);
+      }
+      if (do_bias && c == 0) {
+        const float gb = gbm[e] * a.scale, gbsv = gbs[e] * a.scale;
+        a.g_bmu[n] = gb;
+        a.g_bsigma[n] = gbsv;
+        sq = fmaf(gb, gb, sq); sq = fmaf(gbsv, gbsv, sq);
       }
     }
   }
@@ -613,7 +731,9 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
   }
 }
 __global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
-  rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y, 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x));
+  const int slot = 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x);
+  if (a.rpb > 0) rb_nl_dw_body_ranks(a, (int)blockIdx.x, (int)blockIdx.y, slot);
+  else rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y, slot);
 }
 
 // Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in

@@ -288,6 +288,12 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
 // ReplayMemory.sample on device (memory.py:124-155).  ONE workgroup, thread i = sample i
 // (batch <= 1024).  The rejection loop (memory.py:128-132) runs inside the kernel so the
 // steady-state learn step has no host round trip.
+#if defined(RB_STAMP)
+__device__ long long g_stamp[32];
+#define RB_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamp[i] = wall_clock64(); } while (0)
+#else
+#define RB_STAMP_AT(i) ((void)0)
+#endif
 __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
+  RB_STAMP_AT(0);
   const int i = (int)threadIdx.x;
   const bool active = i < batch;
   const int64_t C = v.capacity;
@@ -319,6 +326,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
   const int32_t full = v.hdr->full;
   const uint64_t rng_base = v.hdr->rng_counter;
   __syncthreads();
+  RB_STAMP_AT(1);
   const float p_total = s_top[0];                               // memory.py:149
   // segment_length = p_total / batch_size: float32 / python int -> float32 (NEP 50)
   const float seg_f = __fdiv_rn(p_total, (float)batch);         // memory.py:125
@@ -347,9 +355,11 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
       valid = (rb_wrap(w_index, -idx, C) > (int64_t)n) && (rb_wrap(idx, -w_index, C) >= (int64_t)h) &&
               (prob != 0.0f);
     }
+    RB_STAMP_AT(2);
     ok = rb_block_all(valid, s_flag);
     if (ok) break;
   }
+  RB_STAMP_AT(3);
   const int attempts_used = ok ? attempt + 1 : max_attempts;
 
   // ---- window (memory.py:111-121), scalars (memory.py:140-145), IS weights (151-154)
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (nt_last ? 1.0f : 0.0f);
     tree_idx_out[i] = leaf;
   }
+  RB_STAMP_AT(4);
   const float w_max = rb_block_max(active ? w : -INFINITY, s_red);
   // The reference retries until a batch is valid (memory.py:128-132); this loop is bounded.  If the bound is hit (a
   // buffer too small for the batch: some stratum lies inside the write head's exclusion zone) the last draw is NOT a
@@ -454,6 +465,7 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     if (!unit_uniforms) v.hdr->rng_counter = rng_base + (uint64_t)attempts_used;
     if (!ok && fail_count) *(volatile int32_t*)fail_count = *(volatile int32_t*)fail_count + 1;
   }
+  RB_STAMP_AT(5);
 }
 
 // Frame-stack gather (memory.py:136-138 minus the /255): block = (sample, stack slot),
@@ -705,6 +717,9 @@ int rb_replay_append_batch(rb_replay_t* r, const uint8_t* frames_dev, const int3
   return RB_OK;
 }
 
+#if defined(RB_STAMP)
+int rb_debug_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(long long) * 32) == hipSuccess ? 0 : -2; }
+#endif
 int rb_replay_failed_samples(rb_replay_t* r, int64_t* count) {
   RB_REQUIRE(r && count, "rb_replay_failed_samples: NULL argument");
   *count = (int64_t)*(volatile int32_t*)r->fail_host;   // pinned host word the sampler increments: no synchronisation

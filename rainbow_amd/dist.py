@@ -2,14 +2,31 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Nothing is sharded:
 every replica owns its own env stream, HBM replay and noise, and an identical copy of the
-parameters + Adam state.  The ONLY exchange per step is one all-reduce (mean) of the flat
-float32 gradient buffer between backward (agent.py:96) and clip (agent.py:97); identical inputs
-to clip + Adam keep the replicas bit-identical.
+parameters + Adam state.  Between backward (agent.py:96) and clip (agent.py:97) every replica
+must end up with the MEAN gradient of the global batch; identical inputs to clip + Adam then
+keep the replicas bit-identical.
+
+Two exchanges (RAINBOW_AMD_EXCHANGE):
+
+  factored (default) — xGMI is point-to-point (7 links per GPU, a ring all-reduce of the 27.5 MB
+      flat gradient pushes 2 x 7/8 x 27.5 = 48 MB through every GPU's links: longer than the
+      whole 0.2 ms step).  But 94 % of those bytes are the noisy-linear weight gradients, rank-B
+      products dW = dY^T X.  So the replicas ALL-GATHER THE FACTORS (dlogits, h, dh, feat rows of
+      their batch — 0.71 MB per rank at the canonical shape) on a side stream, overlapped with
+      the rest of the backward, all-reduce only the conv gradients (0.3 MB), and every replica
+      computes the mean FC gradient of the global batch from the gathered rows with the same
+      kernel (rb_learner_finish_grads).  39x fewer bytes on the wire, no re-read of the gradient
+      for the norm (the finishing kernels produce the sum-of-squares partials).
+  allreduce — one all-reduce (mean) of the flat gradient buffer, then the library re-derives
+      the norm (rb_learner_grads_modified).  Kept as the reference point.
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
 
 
 def world_size():
@@ -18,22 +35,32 @@ def world_size():
 
 def active():
     """True when the replica exchange must run.  RAINBOW_AMD_FORCE_DIST=1 also runs it in a one-rank group, which is
-    how the RCCL plumbing (init, broadcast, all-reduce, re-derived norm) is exercised on a single-GPU box."""
+    how the RCCL plumbing (init, broadcast, collectives, finishing kernels) is exercised on a single-GPU box."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or os.environ.get("RAINBOW_AMD_FORCE_DIST") == "1"
 
 
-def average_gradients(flat_grads):
-    """In-place mean over replicas of the flat gradient buffer (4*P bytes, one collective)."""
-    w = world_size()
-    if not active():
-        return flat_grads
+def mode():
+    m = os.environ.get("RAINBOW_AMD_EXCHANGE", "factored")
+    if m not in ("factored", "allreduce"):
+        raise ValueError("RAINBOW_AMD_EXCHANGE must be 'factored' or 'allreduce', got %r" % m)
+    return m
+
+
+def _mean_reduce(t):
     if dist.get_backend() == "nccl":
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.AVG)
+        dist.all_reduce(t, op=dist.ReduceOp.AVG)
     else:   # gloo (CPU tests) has no AVG
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
-        flat_grads.div_(w)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(world_size())
+    return t
+
+
+def average_gradients(flat_grads):
+    """In-place mean over replicas of the flat gradient buffer (4*P bytes, one collective): the 'allreduce' exchange."""
+    if active():
+        _mean_reduce(flat_grads)
     return flat_grads
 
 
@@ -42,3 +69,59 @@ def broadcast_parameters(flat_params, src=0):
         with torch.no_grad():
             dist.broadcast(flat_params, src)
     return flat_params
+
+
+class FactoredExchange:
+    """The 'factored' exchange of one learner handle (see the module docstring and include/rainbow_hip.h).
+    `flat_grads` is the learner's gradient buffer as a torch tensor (CUDA in production; a CPU tensor over the
+    host-interpreted test build, where streams do not exist and every call is synchronous)."""
+
+    def __init__(self, lib, handle, flat_grads):
+        self.lib, self.h = lib, handle
+        f, off, n = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.check(lib, lib.rb_learner_exchange_layout(handle, C.byref(f), C.byref(off), C.byref(n)))
+        self.world = max(world_size(), 1)
+        dev = flat_grads.device
+        self.cuda = dev.type == "cuda"
+        self.local = torch.zeros(f.value, dtype=torch.float32, device=dev)
+        self.all = torch.zeros(self.world * f.value, dtype=torch.float32, device=dev)
+        self.small = flat_grads.detach()[off.value:off.value + n.value]
+        self.side = torch.cuda.Stream(device=dev) if self.cuda else None
+        # a one-rank group (RAINBOW_AMD_FORCE_DIST) still runs the deferred-gradient path: the library needs world >= 2 to
+        # defer, so the lone rank's block is presented twice and the mean of two equal halves is the gradient itself
+        self.lib_world = max(self.world, 2)
+        if self.lib_world != self.world:
+            self.all = torch.zeros(self.lib_world * f.value, dtype=torch.float32, device=dev)
+        L.check(lib, lib.rb_learner_set_exchange(handle, self.lib_world, self.local.data_ptr(), self.all.data_ptr()))
+        self.bytes_per_step = 4 * (f.value + n.value)
+
+    def close(self):
+        if self.h:
+            self.lib.rb_learner_set_exchange(self.h, 1, None, None)
+            self.h = None
+
+    def run(self, stream_handle=None):
+        """Call right after rb_learner_learn*: all-gather the factor blocks (side stream, as soon as the local block is
+        complete), all-reduce the conv gradients, then let the library finish the FC gradients of the global batch."""
+        lib = self.lib
+        if self.cuda:
+            main = torch.cuda.current_stream(self.local.device)
+            L.check(lib, lib.rb_learner_wait_factors(self.h, self.side.cuda_stream))
+            with torch.cuda.stream(self.side):
+                self._gather()
+            _mean_reduce(self.small)          # main stream: waits for the conv gradients by stream order
+            main.wait_stream(self.side)
+            stream_handle = main.cuda_stream
+        else:
+            L.check(lib, lib.rb_learner_wait_factors(self.h, None))
+            self._gather()
+            _mean_reduce(self.small)
+        L.check(lib, lib.rb_learner_finish_grads(self.h, stream_handle))
+
+    def _gather(self):
+        if self.lib_world != self.world:      # one-rank plumbing run
+            n = self.local.numel()
+            dist.all_gather_into_tensor(self.all[:n], self.local)
+            self.all[n:2 * n].copy_(self.all[:n])
+        else:
+            dist.all_gather_into_tensor(self.all, self.local)

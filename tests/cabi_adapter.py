@@ -264,6 +264,7 @@ class CAbiLearnAdapter:
         m.sync()
 
     grad_hook = None   # e.g. rainbow_amd.dist.average_gradients between backward and clip
+    exchange = None    # or a rainbow_amd.dist.FactoredExchange over this handle
 
     def learn_step(self, batch, target_raw):
         m = self.mem
@@ -280,7 +281,10 @@ class CAbiLearnAdapter:
                                                     m.ptr(bufs["actions"]), m.ptr(bufs["returns"]),
                                                     m.ptr(bufs["nonterminals"]), m.ptr(bufs["weights"]), m.ptr(loss),
                                                     m.stream))
-        if self.grad_hook is not None:
+        if self.exchange is not None:       # rainbow_amd.dist.FactoredExchange: FC gradients from all-gathered factors
+            m.sync()
+            self.exchange.run(m.stream)
+        elif self.grad_hook is not None:
             m.sync()
             self.grad_hook(self._as_torch(self.grads))
             L.check(self.lib, self.lib.rb_learner_grads_modified(self.h))

@@ -13,7 +13,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, outdir):
+# the factored exchange runs on the streamed noisy-linear kernels (F and H multiples of 32): the data-efficient fixture
+_NAME = {"factored": "dataeff", "allreduce": "atoms21"}
+
+
+def _worker(rank, world, port, outdir, mode="allreduce"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -25,11 +29,14 @@ def _worker(rank, world, port, outdir):
     from hipemu import loader
     from oracle import learner_oracle as O
     from rainbow_amd import dist as rdist
-    name = "atoms21"
+    name = _NAME[mode]
     c = scenarios.LEARN_CONFIGS[name]
     cfg = O.Config(**c)
     ad = CAbiLearnAdapter(loader.load(), NumpyMem(), name)
-    ad.grad_hook = rdist.average_gradients
+    if mode == "factored":     # all-gather of the FC gradient factors + all-reduce of the conv gradients
+        ad.exchange = rdist.FactoredExchange(ad.lib, ad.h, torch.from_numpy(ad.grads))
+    else:                      # one all-reduce of the flat gradient
+        ad.grad_hook = rdist.average_gradients
     online, target = O.init_params(cfg, 5), O.init_params(cfg, 6)
     if rank != 0:   # replicas start different on purpose; broadcast must fix it
         online = {k: v + 1.0 for k, v in online.items()}
@@ -49,10 +56,11 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_replicas_stay_identical(tmp_path):
+@pytest.mark.parametrize("mode", ["factored", "allreduce"])
+def test_two_replicas_stay_identical(tmp_path, mode):
     world = 2
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode == "factored" else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["params"], r1["params"]), "replicas diverged"
@@ -65,7 +73,7 @@ def test_two_replicas_stay_identical(tmp_path):
     from hipemu import loader
     from cabi_adapter import CAbiLearnAdapter, NumpyMem
     from oracle import learner_oracle as O
-    name = "atoms21"
+    name = _NAME[mode]
     c = scenarios.LEARN_CONFIGS[name]
     cfg = O.Config(**c)
     online, target = O.init_params(cfg, 5), O.init_params(cfg, 6)

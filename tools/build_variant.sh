@@ -1,0 +1,14 @@
+# usage: bash tools/build_variant.sh <name> [-DFLAG ...]  -> rainbow_amd/librainbow_hip_<name>.so (same sources, extra -D switches)
+# for same-box A/B runs: RAINBOW_AMD_LIB=$PWD/rainbow_amd/librainbow_hip_<name>.so python bench.py ...
+set -e
+NAME=$1; shift
+CS=rainbow_amd/csrc
+OBJS=""
+for f in $CS/*.hip; do
+  o=/tmp/rbv_${NAME}_$(basename $f .hip).o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result "$@" -c $f -o $o &
+  OBJS="$OBJS $o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o rainbow_amd/librainbow_hip_${NAME}.so
+echo built rainbow_amd/librainbow_hip_${NAME}.so
