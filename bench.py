@@ -37,6 +37,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_STRIDE = 8         # the dominant kernel's launches bracketed by HIP events inside the timed region: 1 in 8
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 
@@ -116,6 +117,11 @@ def kernel_table(cfg, n_params):
             t["conv%d_dx" % (i + 1)] = dict(bound="mfma", work=2 * B * cout * P * K, unit="TFLOP/s")
         dw += 2 * B * cout * P * (K + 1)
     t["conv_dw_all"] = dict(bound="mfma", work=dw, unit="TFLOP/s")
+    # PER sampler: one workgroup, a chain of dependent loads — its useful bytes are tiny (tree nodes on the search paths,
+    # window scalars), so its HBM fraction is ~0 by construction: it is listed because at the data-efficient config it is
+    # the longest launch of the step (latency-bound)
+    L = (cfg["capacity"] - 1).bit_length()
+    t["sample"] = dict(bound="hbm", work=B * (4 * L + 4 * (4 + cfg["multi_step"]) + 4 * cfg["multi_step"] + 12), unit="GB/s")
     return t
 
 
@@ -303,6 +309,7 @@ def main():
         probe = {k: bracketed(k, 30)[0] for k in ktab}
         kname = max((k for k in probe if probe[k] is not None), key=lambda k: probe[k])
     lib.rb_profile_select(kname.encode())
+    lib.rb_profile_stride(PROFILE_STRIDE)       # 1 launch in 8 is bracketed inside the timed region
     if world > 1 or force_dist:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
@@ -316,6 +323,7 @@ def main():
     tot_ms, launches = C.c_double(0), C.c_int64(0)
     lib.rb_profile_read(C.byref(tot_ms), C.byref(launches))
     lib.rb_profile_select(None)
+    lib.rb_profile_stride(1)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -386,6 +394,7 @@ def main():
         if launches.value > 0:
             out["roofline"] = roof(kname, tot_ms.value / launches.value * 1e-3, launches.value)
             out["roofline"]["event_pair_overhead_us"] = ev_us
+            out["roofline"]["bracketed"] = "every %dth launch of the timed region" % PROFILE_STRIDE
             out["roofline"]["selected"] = "forced" if opt.roofline_kernel in ktab else "largest mean launch time of a 30-step probe"
             out["roofline_others"] = [roof(o, t, n) for o, (t, n) in sorted(others.items(), key=lambda kv: -kv[1][0])]
         flops, nbytes = step_work(cfg, int(agent.params.numel()))

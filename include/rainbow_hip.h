@@ -59,6 +59,9 @@ int rb_copy_to_device(void* dst_dev, const void* src_host, size_t nbytes, rb_str
  * rb_profile_read synchronises the recorded events, returns their summed elapsed time and
  * the number of launches, and resets the counters.                                        */
 int rb_profile_select(const char* kernel_substr);
+/* Bracket only every `every`-th matching launch (default 1 = all): an event pair costs the stream ~5 us, so a timed
+ * region that samples 1 launch in 8 is perturbed by 0.6 us per step instead of 5.                                    */
+int rb_profile_stride(int32_t every);
 int rb_profile_read(double* total_ms, int64_t* launches);
 /* Cost of an event pair with NOTHING between them on `stream` (mean of n pairs, ms): what the
  * bracketing itself adds to every rb_profile_read sample.  Blocks until the stream drains.     */
@@ -167,6 +170,11 @@ int rb_replay_update_priorities(rb_replay_t* r, const int64_t* tree_idx_dev,
  * as f32 /255, out_dev f32[history][7056].                                          */
 int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_stream_t stream);
 
+/* The same for n data indices in ONE launch (the validation pass of test.py:38-39 walks the whole validation memory):
+ * data_index_dev i64[n], each in [0, capacity); out_dev f32[n][history][7056].                                        */
+int rb_replay_states_at(rb_replay_t* r, const int64_t* data_index_dev, int32_t n, float* out_dev,
+                        rb_stream_t stream);
+
 /* u8 -> f32 x/255 (memory.py:137-138 `.div_(255)`), correctly-rounded division.    */
 int rb_u8_to_unit_f32(const uint8_t* src_dev, float* dst_dev, int64_t n, rb_stream_t stream);
 
@@ -226,7 +234,8 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
                    float* q_dev, rb_stream_t stream);
 /* The same for n states at once (vectorised actors; the reference acts on one state per call,
  * main.py:153 — this is that call batched): states f32[n][history][7056],
- * 1 <= n <= 2*batch; actions_dev i32[n], q_dev f32[n] (either may be NULL).  action_dev /
+ * 1 <= n <= 4096 (beyond the learn step's 3*batch images the forward buffers are regrown once, synchronising — batched
+ * evaluation of a validation memory, test.py:38-39); actions_dev i32[n], q_dev f32[n] (either may be NULL).  action_dev /
  * q_dev of both calls may point to pinned host memory mapped on the device, which saves the
  * caller a device-to-host copy: the values are final once the stream has drained.         */
 int rb_learner_act_batch(rb_learner_t* l, const float* states_dev, int32_t n, int32_t noisy,
@@ -302,6 +311,12 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream);
  * all-reduce of the replica path): the sum of squares the backward kernels accumulated on
  * the fly is then stale and rb_learner_clip_grad re-reads the gradient.                    */
 int rb_learner_grads_modified(rb_learner_t* l);
+
+/* Exact resume: the noise generator is Philox(seed, epoch, index) with a device-resident epoch that
+ * every resample advances; a checkpoint that carries (seed, epoch) — next to parameters, Adam moments and the noise
+ * buffers — continues the very same random stream.  Both calls synchronise `stream`.                               */
+int rb_learner_get_rng(rb_learner_t* l, uint64_t* seed_host, uint64_t* epoch_host, rb_stream_t stream);
+int rb_learner_set_rng(rb_learner_t* l, uint64_t seed, uint64_t epoch, rb_stream_t stream);
 
 /* Agent.update_target_net (agent.py:102-103): params AND noise, device-to-device.   */
 int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "rb_copy_to_host": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "rb_copy_to_device": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "rb_profile_select": (c_int, [c_char_p]),
+    "rb_profile_stride": (c_int, [c_int32]),
     "rb_profile_read": (c_int, [C.POINTER(c_double), C.POINTER(c_int64)]),
     "rb_profile_overhead": (c_int, [c_void_p, c_int32, C.POINTER(c_double)]),
     "rb_replay_create": (c_int, [C.POINTER(c_void_p), c_int64, c_int32, c_int32, c_double, c_double, c_uint64]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "rb_replay_update_leaves": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_update_priorities": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_state_at": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rb_replay_states_at": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "rb_u8_to_unit_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rb_learner_sizes": (c_int, [C.POINTER(LearnerConfig), C.POINTER(c_int64), C.POINTER(c_int64)]),
     "rb_learner_param_layout": (c_int, [C.POINTER(LearnerConfig), C.POINTER(TensorDesc), C.POINTER(c_int32)]),
@@ -96,6 +98,8 @@ SIGNATURES = {
     "rb_learner_wait_factors": (c_int, [c_void_p, c_void_p]),
     "rb_learner_finish_grads": (c_int, [c_void_p, c_void_p]),
     "rb_learner_sync_target": (c_int, [c_void_p, c_void_p]),
+    "rb_learner_get_rng": (c_int, [c_void_p, C.POINTER(c_uint64), C.POINTER(c_uint64), c_void_p]),
+    "rb_learner_set_rng": (c_int, [c_void_p, c_uint64, c_uint64, c_void_p]),
     "rb_learner_debug_read": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
 }
 

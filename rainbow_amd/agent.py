@@ -117,13 +117,16 @@ class Agent:
                 self.grads.data_ptr(), self.noise.data_ptr(), self.target_noise.data_ptr(), seed))
 
         self._init_parameters(float(getattr(args, "noisy_std", 0.1)))
+        self._noise_pending = False
+        self.reset_noise()                                           # NoisyLinear.__init__ (model.py:23)
         if getattr(args, "model", None):                             # agent.py:26-36
             if os.path.isfile(args.model):
+                # load_state_dict restores the epsilon buffers of the checkpoint too (they are registered buffers,
+                # model.py:19,22): the noise drawn above is overwritten, exactly as in the reference
                 self.load_state_dict(torch.load(args.model, map_location="cpu"))
                 print("Loading pretrained model: " + args.model)
             else:
                 raise FileNotFoundError(args.model)
-        self.reset_noise()                                           # NoisyLinear.__init__ (model.py:23)
         self.update_target_net()                                     # agent.py:41
 
         self.params.requires_grad_(True)
@@ -144,7 +147,6 @@ class Agent:
         self._graph = None
         self._graph_mem = None
         self._eager_steps = 0
-        self._noise_pending = False
         self._noise_jobs = {}
         # priority write-back beside clip + Adam on a second stream (one fork/join per step)
         self._overlap_update = os.environ.get("RAINBOW_AMD_UPDATE_OVERLAP", "0") == "1"
@@ -284,6 +286,38 @@ class Agent:
         self._forward_single(state)
         return float(self._q_np[0])
 
+    def evaluate_q_batch(self, states, chunk=512):
+        """Batched agent.py:110-112: `states` f32 [n, h, 84, 84] on the device -> numpy float32 [n],
+        [self.evaluate_q(s) for s in states] as ONE forward per `chunk` states (6 launches for a 500-state validation
+        memory, test.py:38-39, instead of 500 single-state launch chains with a stream sync each)."""
+        self._flush_noise()
+        st = states.to(device=self.device, dtype=torch.float32).contiguous()
+        n = int(st.shape[0])
+        out = np.empty(n, dtype=np.float32)
+        chunk = max(1, min(int(chunk), 4096))
+        if self._q_pin.numel() < min(n, chunk):
+            self._act_pin = torch.zeros(min(n, chunk), dtype=torch.int32).pin_memory()
+            self._q_pin = torch.zeros(min(n, chunk), dtype=torch.float32).pin_memory()
+            self._act_np, self._q_np = self._act_pin.numpy(), self._q_pin.numpy()
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            L.check(self._lib, self._lib.rb_learner_act_batch(self._h, st[lo:lo + m].data_ptr(), m,
+                                                              1 if self.training else 0, self._act_pin.data_ptr(),
+                                                              self._q_pin.data_ptr(), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+            out[lo:lo + m] = self._q_np[:m]
+        return out
+
+    def evaluate_q_memory(self, val_mem, chunk=512):
+        """test.py:38-39 in one call: Q of every state of a validation ReplayMemory (its first `len` = index-or-capacity
+        states), states built on the device by rb_replay_states_at."""
+        n = val_mem.capacity if val_mem.transitions.full else val_mem.transitions.index
+        qs = np.empty(n, dtype=np.float32)
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            qs[lo:hi] = self.evaluate_q_batch(val_mem.states_at(torch.arange(lo, hi, device=self.device)), chunk)
+        return qs
+
     GRAPH_WARMUP = 3   # eager steps before the learn step is captured into a hipGraph
 
     def learn(self, mem, _target_raw_normals=None, _unit_uniforms=None):
@@ -362,6 +396,9 @@ class Agent:
             # the learner writes the new priorities into mem's sum-tree itself (one extra workgroup of its backward)
             L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, mem._h, idxs.data_ptr()))
             self._sink_mem, self._sink_idx = mem, idxs
+            # the library caches raw pointers into `mem`: drop them when the memory goes away before the agent does
+            me = weakref.ref(self)
+            weakref.finalize(mem, lambda: me() is not None and me()._clear_sink())
         elif not device_mem and getattr(self, "_sink_mem", None) is not None:
             L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, None, None))
             self._sink_mem, self._sink_idx = None, None
@@ -406,6 +443,11 @@ class Agent:
         else:
             mem.update_priorities(idxs, self._loss.detach().cpu().numpy())                 # agent.py:100
 
+    def _clear_sink(self):
+        if getattr(self, "_h", None):
+            self._lib.rb_learner_set_priority_sink(self._h, None, None)
+        self._sink_mem, self._sink_idx = None, None
+
     def update_target_net(self):
         """agent.py:102-103."""
         self._flush_noise()
@@ -429,37 +471,110 @@ class Agent:
             e_out = self._noise_view(self.noise, layer + ".eps_out")
             sd[layer + ".weight_epsilon"] = torch.outer(e_out, e_in)    # model.py:39
             sd[layer + ".bias_epsilon"] = e_out.clone()                 # model.py:40
+        # nn.Module.state_dict order: a module's parameters, then its buffers (model.py:15-22)
         order = []
         for name, _o, _s in self._layout:
             order.append(name)
-            if name.endswith("weight_sigma"):
-                order.append(name.replace("weight_sigma", "weight_epsilon"))
             if name.endswith("bias_sigma"):
-                order.append(name.replace("bias_sigma", "bias_epsilon"))
+                layer = name.split(".")[0]
+                order += [layer + ".weight_epsilon", layer + ".bias_epsilon"]
         return {k: sd[k] for k in order}
 
-    def load_state_dict(self, state_dict):
+    def load_state_dict(self, state_dict, strict=True):
+        """nn.Module.load_state_dict of the reference's DQN (agent.py:33): STRICT by default — missing or unexpected keys
+        raise, as the reference's call does.  The [out, in] weight_epsilon buffers are rank-1 (model.py:39); the
+        factorised vectors are recovered EXACTLY (see _recover_eps_in), so save -> load -> save is bit-identical."""
         sd = dict(state_dict)
         if "conv1.weight" in sd:                                                           # agent.py:29-32
             for old, new in (("conv1.weight", "convs.0.weight"), ("conv1.bias", "convs.0.bias"),
                              ("conv2.weight", "convs.2.weight"), ("conv2.bias", "convs.2.bias"),
                              ("conv3.weight", "convs.4.weight"), ("conv3.bias", "convs.4.bias")):
                 sd[new] = sd.pop(old)
+        expected = [n for n, _o, _s in self._layout]
+        for layer in _LAYERS:
+            expected += [layer + ".weight_epsilon", layer + ".bias_epsilon"]
+        missing = [k for k in expected if k not in sd]
+        unexpected = [k for k in sd if k not in expected]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for DQN: missing key(s) %s; unexpected key(s) %s"
+                               % (missing, unexpected))
+        self._flush_noise()
         with torch.no_grad():
             for name, _off, shape in self._layout:
+                if name not in sd:
+                    continue
                 t = sd[name]
                 if tuple(t.shape) != tuple(shape):
                     raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(t.shape), shape))
                 self._view(self.params, name).copy_(t.to(self.device, torch.float32))
-            for layer in _LAYERS:   # epsilon buffers are rank-1: recover the factorised vectors
-                if layer + ".bias_epsilon" not in sd:
+            for layer in _LAYERS:
+                if layer + ".bias_epsilon" not in sd or layer + ".weight_epsilon" not in sd:
                     continue
                 e_out = sd[layer + ".bias_epsilon"].to(self.device, torch.float32)
                 e_w = sd[layer + ".weight_epsilon"].to(self.device, torch.float32)
-                j = int(torch.argmax(e_out.abs()).item())
-                e_in = e_w[j] / e_out[j] if float(e_out[j]) != 0.0 else torch.zeros_like(e_w[j])
-                self._noise_view(self.noise, layer + ".eps_in").copy_(e_in)
+                self._noise_view(self.noise, layer + ".eps_in").copy_(self._recover_eps_in(e_w, e_out))
                 self._noise_view(self.noise, layer + ".eps_out").copy_(e_out)
+
+    @staticmethod
+    def _recover_eps_in(e_w, e_out):
+        """weight_epsilon = fl32(eps_out[i] * eps_in[k]) (model.py:39, torch.ger).  A single division e_w[j] / e_out[j] can
+        land one ulp beside the true eps_in[k]; the true value is the neighbour that REPRODUCES the stored products.
+        Candidates {q - ulp, q, q + ulp} of the quotient on the row of largest |eps_out| are scored against the 64 rows
+        of largest |eps_out|; the best one per column wins (the true vector scores 0 mismatches by construction)."""
+        order = torch.argsort(e_out.abs(), descending=True)
+        j = int(order[0].item())
+        if float(e_out[j]) == 0.0:
+            return torch.zeros_like(e_w[0])
+        q = e_w[j] / e_out[j]
+        inf = torch.full_like(q, float("inf"))
+        cands = torch.stack([torch.nextafter(q, -inf), q, torch.nextafter(q, inf)])       # [3, K]
+        rows = order[:64]
+        prod = e_out[rows][None, :, None] * cands[:, None, :]                              # [3, R, K] float32 products
+        miss = (prod != e_w[rows][None, :, :]).sum(dim=1)                                  # [3, K]
+        miss[1] = miss[1] * 2 - 1                                                          # ties prefer the quotient itself
+        miss[0] *= 2
+        miss[2] *= 2
+        best = torch.argmin(miss, dim=0)
+        return cands.gather(0, best[None, :])[0]
+
+    # ------------------------------------------------------------------ exact resume (SURVEY 8f row 3)
+    def checkpoint(self, path=None):
+        """Everything the learner needs to continue bit-for-bit: online / target parameters, both noise buffers, Adam
+        moments + step, the Philox (seed, epoch) of the noise generator and the pending-resample flag.  The reference's
+        save() (weights only, agent.py:106-107) stays what main.py:182 calls; this is the superset a resumable run needs
+        (main.py has no such thing: it restarts the optimiser).  Returns the dict; writes it with torch.save if `path`."""
+        if not isinstance(self.optimiser, _FlatAdam):
+            raise NotImplementedError("checkpoint() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1, no graph)")
+        seed, epoch = C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib, self._lib.rb_learner_get_rng(self._h, C.byref(seed), C.byref(epoch), self._stream()))
+        st = self.optimiser.state[self.params]
+        ck = dict(version=1, config=bytes(self._cfg), params=self.params.detach().cpu(), target_params=self.target_params.cpu(),
+                  noise=self.noise.cpu(), target_noise=self.target_noise.cpu(), exp_avg=st["exp_avg"].cpu(),
+                  exp_avg_sq=st["exp_avg_sq"].cpu(), adam_step=float(st["step"]), rng_seed=int(seed.value),
+                  rng_epoch=int(epoch.value), noise_pending=bool(self._noise_pending), training=bool(self.training))
+        if path is not None:
+            torch.save(ck, path)
+        return ck
+
+    def restore(self, ck):
+        """Inverse of checkpoint(): `ck` is the dict or a path."""
+        if not isinstance(ck, dict):
+            ck = torch.load(ck, map_location="cpu")
+        if ck.get("version") != 1 or ck["config"] != bytes(self._cfg):
+            raise RuntimeError("checkpoint does not match this Agent's configuration")
+        with torch.no_grad():
+            self.params.copy_(ck["params"])
+            self.target_params.copy_(ck["target_params"])
+            self.noise.copy_(ck["noise"])
+            self.target_noise.copy_(ck["target_noise"])
+            st = self.optimiser.state[self.params]
+            st["exp_avg"].copy_(ck["exp_avg"])
+            st["exp_avg_sq"].copy_(ck["exp_avg_sq"])
+            st["step"].fill_(ck["adam_step"])
+        L.check(self._lib, self._lib.rb_learner_set_rng(self._h, int(ck["rng_seed"]), int(ck["rng_epoch"]), self._stream()))
+        self._noise_pending = bool(ck["noise_pending"])
+        self.training = bool(ck["training"])
+        self._noise_jobs = {}
 
     def save(self, path, name="model.pth"):
         torch.save(self.state_dict(), os.path.join(path, name))

@@ -19,9 +19,11 @@ int g_rb_prof_on = 0;
 static char g_prof_pat[128] = "";
 static std::vector<hipEvent_t> g_prof_events;   // pairs: [2i] before, [2i+1] after
 static size_t g_prof_used = 0;
+static int g_prof_stride = 1, g_prof_seen = 0;
 
 bool rb_prof_begin(const char* kernel_expr, hipStream_t stream) {
   if (!strstr(kernel_expr, g_prof_pat)) return false;
+  if (g_prof_stride > 1 && (g_prof_seen++ % g_prof_stride) != 0) return false;   // sample every stride-th matching launch
   if (g_prof_used + 2 > g_prof_events.size()) {
     if (g_prof_events.size() >= 65536) return false;
     for (int i = 0; i < 256; ++i) {
@@ -46,6 +48,16 @@ int rb_profile_select(const char* kernel_substr) {
   g_rb_prof_on = 1;
 #else
   (void)kernel_substr;
+#endif
+  return RB_OK;
+}
+
+int rb_profile_stride(int32_t every) {
+#if !defined(RB_HOST_INTERP)
+  g_prof_stride = every > 1 ? every : 1;
+  g_prof_seen = 0;
+#else
+  (void)every;
 #endif
   return RB_OK;
 }

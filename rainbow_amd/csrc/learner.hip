@@ -141,6 +141,7 @@ struct rb_learner {
   int norm_conv_base;   // first slot of the conv reduction blocks
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
+  int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
   ImgSrc cur_src;       // input frames of the learn step in flight
@@ -1103,6 +1104,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
       RB_ALLOC(l->dw_part[i], slices * c.cout * (c.K() + 1));
     }
   }
+  l->rows_cap = NI;
   RB_ALLOC(l->hpart, (int64_t)l->hs * NI * 2 * L.H);
   RB_ALLOC(l->h, (int64_t)NI * 2 * L.H);
   RB_ALLOC(l->feat_b, (int64_t)NI * (L.F + 16));
@@ -1232,11 +1234,41 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
   return RB_OK;
 }
 
+// The forward buffers are sized for the learn step's 3B images; batched evaluation (test.py:38-39 over a 500-state
+// validation memory) may ask for more rows: grow them (synchronising; happens once per size).
+static int ensure_rows(rb_learner* l, int rows) {
+  if (rows <= l->rows_cap) return RB_OK;
+  const Layout& L = l->L;
+  RB_HIP_TRY(hipDeviceSynchronize());
+  auto regrow = [&](float** p, int64_t count) -> int {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    hipError_t e = hipMalloc((void**)p, (size_t)count * 4);
+    if (e != hipSuccess) { rb_set_error("rb_learner_act_batch: hipMalloc(%lld B) failed: %s", (long long)count * 4, hipGetErrorString(e)); return RB_ERR_OOM; }
+    return RB_OK;
+  };
+  int rc;
+  for (int i = 0; i < L.nconv; ++i)
+    if ((rc = regrow(&l->act[i], (int64_t)rows * L.conv[i].cout * L.conv[i].P())) != RB_OK) return rc;
+  if ((rc = regrow(&l->hpart, (int64_t)l->hs * rows * 2 * L.H)) != RB_OK) return rc;
+  if ((rc = regrow(&l->h, (int64_t)rows * 2 * L.H)) != RB_OK) return rc;
+  if ((rc = regrow(&l->feat_b, (int64_t)rows * (L.F + 16))) != RB_OK) return rc;
+  if ((rc = regrow(&l->h_b, (int64_t)rows * (2 * L.H + 16))) != RB_OK) return rc;
+  if ((rc = regrow(&l->logits, (int64_t)rows * L.NZ)) != RB_OK) return rc;
+  RB_HIP_TRY(hipMemset(l->hpart, 0, (size_t)l->hs * rows * 2 * L.H * 4));
+  l->rows_cap = rows;
+  return RB_OK;
+}
+
 int rb_learner_act_batch(rb_learner_t* l, const float* states_dev, int32_t n, int32_t noisy, int32_t* actions_dev,
                          float* q_dev, rb_stream_t stream) {
   RB_REQUIRE(l && states_dev, "rb_learner_act_batch: NULL argument");
   const Layout& L = l->L;
-  RB_REQUIRE(n >= 1 && n <= 2 * L.B, "rb_learner_act_batch: n must be in [1, 2*batch] (activation buffers are sized for the learn step)");
+  RB_REQUIRE(n >= 1 && n <= 4096, "rb_learner_act_batch: n must be in [1, 4096]");
+  {
+    int rc0 = ensure_rows(l, n);
+    if (rc0 != RB_OK) return rc0;
+  }
   if (n == 1) return rb_learner_act(l, states_dev, noisy, actions_dev, q_dev, stream);
   ImgSrc src;
   memset(&src, 0, sizeof(src));
@@ -1630,6 +1662,24 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   RB_LAUNCH_CHECK();
   l->norm_slots = zp.slots + hp.slots + c_slots;
   l->exch_pending = 0;
+  return RB_OK;
+}
+
+int rb_learner_get_rng(rb_learner_t* l, uint64_t* seed, uint64_t* epoch, rb_stream_t stream) {
+  RB_REQUIRE(l && seed && epoch, "rb_learner_get_rng: NULL argument");
+  RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long e = 0;
+  RB_HIP_TRY(hipMemcpy(&e, l->noise_ctr, sizeof(e), hipMemcpyDeviceToHost));
+  *seed = l->seed; *epoch = (uint64_t)e;
+  return RB_OK;
+}
+
+int rb_learner_set_rng(rb_learner_t* l, uint64_t seed, uint64_t epoch, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_set_rng: NULL handle");
+  RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const unsigned long long e[2] = {(unsigned long long)epoch, 0ull};
+  RB_HIP_TRY(hipMemcpy(l->noise_ctr, e, sizeof(e), hipMemcpyHostToDevice));
+  l->seed = seed;
   return RB_OK;
 }
 

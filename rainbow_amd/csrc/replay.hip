@@ -528,6 +528,34 @@ __global__ __launch_bounds__(256) void k_state_at(ReplayView v, int64_t data_ind
   }
 }
 
+// The same for n data indices at once (one workgroup per state): the validation pass of test.py:38-39 walks the whole
+// validation memory — one launch instead of one launch + host loop per state.
+__global__ __launch_bounds__(256) void k_states_at(ReplayView v, const int64_t* data_index, float* out) {
+  __shared__ int s_blank[64];
+  const int h = v.history;
+  const int64_t di = data_index[blockIdx.x];
+  float* o = out + (int64_t)blockIdx.x * h * RB_FRAME_BYTES;
+  if (threadIdx.x == 0) {
+    int blank_next = 0;
+    s_blank[h - 1] = 0;
+    for (int t = h - 2; t >= 0; --t) {
+      const int64_t ring_next = rb_floor_mod(di - (h - 1) + (t + 1), v.capacity);
+      const int b = blank_next || (v.timestep[ring_next] == 0);
+      s_blank[t] = b;
+      blank_next = b;
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < h; ++t) {
+    const int64_t ring = rb_floor_mod(di - (h - 1) + t, v.capacity);
+    const uint8_t* src = v.frames + ring * RB_FRAME_BYTES;
+    float* dst = o + (int64_t)t * RB_FRAME_BYTES;
+    const bool blank = s_blank[t] != 0;
+    for (int p = (int)threadIdx.x; p < RB_FRAME_BYTES; p += (int)blockDim.x)
+      dst[p] = blank ? 0.0f : __fdiv_rn((float)src[p], 255.0f);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_u8_to_unit(const uint8_t* src, float* dst, int64_t n) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
     dst[t] = __fdiv_rn((float)src[t], 255.0f);  // memory.py:137 .div_(255)
@@ -770,7 +798,7 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
     RB_REQUIRE(job.noise && job.ctr && job.nblk > 0 && job.nets >= 1, "rb_replay_sample_fused_noise: empty noise job");
     blocks += (unsigned)(job.nblk * job.nets);
   }
-  RB_LAUNCH(k_sample, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+  RB_LAUNCH_T("sample:k_sample", k_sample, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
             r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host);
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
@@ -822,6 +850,15 @@ int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_st
   RB_REQUIRE(r && out_dev, "rb_replay_state_at: NULL argument");
   RB_REQUIRE(data_index >= 0 && data_index < r->capacity, "rb_replay_state_at: index out of range");
   RB_LAUNCH(k_state_at, dim3(1), dim3(256), stream, view_of(r), data_index, out_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_replay_states_at(rb_replay_t* r, const int64_t* data_index_dev, int32_t n, float* out_dev, rb_stream_t stream) {
+  RB_REQUIRE(r && data_index_dev && out_dev, "rb_replay_states_at: NULL argument");
+  RB_REQUIRE(n >= 0, "rb_replay_states_at: n must be >= 0");
+  if (n == 0) return RB_OK;
+  RB_LAUNCH(k_states_at, dim3((unsigned)n), dim3(256), stream, view_of(r), data_index_dev, out_dev);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }

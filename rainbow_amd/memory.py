@@ -234,6 +234,82 @@ class ReplayMemory:
 
     next = __next__
 
+    def states_at(self, indices):
+        """[__next__ at index i for i in indices] as ONE launch: float32 [n, h, 84, 84] on the device (memory.py:167-178).
+        `indices`: int64 device tensor or anything torch.as_tensor accepts, each in [0, capacity)."""
+        idx = torch.as_tensor(indices, dtype=torch.int64).to(self.device).contiguous()
+        n = int(idx.numel())
+        if n and (int(idx.min()) < 0 or int(idx.max()) >= self.capacity):
+            raise IndexError("states_at: index out of range")
+        out = torch.empty(n, self.history, 84, 84, dtype=torch.float32, device=self.device)
+        self._idx_keep = idx
+        L.check(self._lib, self._lib.rb_replay_states_at(self._h, idx.data_ptr(), n, out.data_ptr(), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ streaming dump / restore
+    _COLUMNS = ("tree", "frames", "timestep", "action", "reward", "nonterminal")
+
+    def _column_spec(self):
+        b = L.ReplayBuffers()
+        L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(b)))
+        cap = self.capacity
+        return b, {"tree": (b.sum_tree_dev, b.tree_len * 4), "frames": (b.frames_dev, cap * 7056),
+                   "timestep": (b.timestep_dev, cap * 4), "action": (b.action_dev, cap * 4),
+                   "reward": (b.reward_dev, cap * 4), "nonterminal": (b.nonterminal_dev, cap)}
+
+    def save_to(self, fileobj, chunk_bytes=64 << 20):
+        """Streams the replay to a binary file object in `chunk_bytes` pieces (64 MB of host staging instead of the 7 GB
+        a pickle of a 1M-capacity memory needs; main.py:94-100 `pickle.dump(memory, bz2 file)` still works through
+        __getstate__, this is the scalable alternative: `with bz2.open(path, 'wb') as f: mem.save_to(f)`)."""
+        import json
+        import struct
+        b, spec = self._column_spec()
+        hdr = self._header()
+        meta = dict(version=1, capacity=self.capacity, history=self.history, n=self.n, discount=self.discount,
+                    priority_weight=self.priority_weight, priority_exponent=self.priority_exponent, t=self.t,
+                    seed=self._seed, columns={k: spec[k][1] for k in self._COLUMNS}, header=bytes(hdr).hex())
+        blob = json.dumps(meta).encode()
+        fileobj.write(b"RBRPLY01" + struct.pack("<q", len(blob)) + blob)
+        stage = np.empty(chunk_bytes, dtype=np.uint8)
+        for k in self._COLUMNS:
+            ptr, nbytes = spec[k]
+            for lo in range(0, nbytes, chunk_bytes):
+                m = min(chunk_bytes, nbytes - lo)
+                L.check(self._lib, self._lib.rb_copy_to_host(stage.ctypes.data, ptr + lo, m, self._stream()))
+                fileobj.write(stage[:m].tobytes() if m < chunk_bytes else stage.data)
+
+    @classmethod
+    def load_from(cls, fileobj, device, chunk_bytes=64 << 20):
+        """Inverse of save_to: builds a ReplayMemory on `device` from the stream."""
+        import json
+        import struct
+        import types
+        magic = fileobj.read(8)
+        if magic != b"RBRPLY01":
+            raise ValueError("not a rainbow_amd replay stream")
+        (n,) = struct.unpack("<q", fileobj.read(8))
+        meta = json.loads(fileobj.read(n).decode())
+        args = types.SimpleNamespace(device=device, history_length=meta["history"], discount=meta["discount"],
+                                     multi_step=meta["n"], priority_weight=meta["priority_weight"],
+                                     priority_exponent=meta["priority_exponent"])
+        mem = cls(args, meta["capacity"], seed=meta["seed"])
+        mem.t = meta["t"]
+        b, spec = mem._column_spec()
+        for k in cls._COLUMNS:
+            ptr, nbytes = spec[k]
+            if nbytes != meta["columns"][k]:
+                raise ValueError("replay stream column %s has %d bytes, expected %d" % (k, meta["columns"][k], nbytes))
+            for lo in range(0, nbytes, chunk_bytes):
+                m = min(chunk_bytes, nbytes - lo)
+                buf = fileobj.read(m)
+                if len(buf) != m:
+                    raise EOFError("replay stream truncated in column %s" % k)
+                a = np.frombuffer(buf, dtype=np.uint8)
+                L.check(mem._lib, mem._lib.rb_copy_to_device(ptr + lo, a.ctypes.data, m, mem._stream()))
+        hdr = np.frombuffer(bytes.fromhex(meta["header"]), dtype=np.uint8).copy()
+        L.check(mem._lib, mem._lib.rb_copy_to_device(b.header_dev, hdr.ctypes.data, hdr.nbytes, mem._stream()))
+        return mem
+
     # ------------------------------------------------------------------ pickling (main.py:94-100,118)
     def _grab(self, field, start=0, count=None):
         """Copies rows [start, start+count) of one device column to a numpy array (tests / partial dumps)."""
@@ -268,7 +344,8 @@ class ReplayMemory:
 
     def __getstate__(self):
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev", "_neg_beta_val", "_bufs")}
+              if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev", "_neg_beta_val", "_bufs",
+                           "_idx_keep")}
         st["device"] = str(self.device)
         st["_dump"] = self._dump()
         return st

@@ -134,8 +134,9 @@ def test_agent_and_memory_classes_end_to_end_vs_oracle(hip, tmp_path, hidden, ba
     # checkpoint interchange: reference key names, round trip (agent.py:26-36,106-107)
     agent.save(str(tmp_path), "model.pth")
     sd = torch.load(str(tmp_path / "model.pth"), map_location="cpu")
-    assert list(sd.keys())[:8] == ["convs.0.weight", "convs.0.bias", "convs.2.weight", "convs.2.bias", "convs.4.weight",
-                                   "convs.4.bias", "fc_h_v.weight_mu", "fc_h_v.weight_sigma"]
+    assert list(sd.keys())[:12] == ["convs.0.weight", "convs.0.bias", "convs.2.weight", "convs.2.bias", "convs.4.weight",
+                                    "convs.4.bias", "fc_h_v.weight_mu", "fc_h_v.weight_sigma", "fc_h_v.bias_mu",
+                                    "fc_h_v.bias_sigma", "fc_h_v.weight_epsilon", "fc_h_v.bias_epsilon"]
     assert tuple(sd["fc_h_v.weight_epsilon"].shape) == (hidden, 3136) and tuple(sd["fc_z_a.bias_epsilon"].shape) == (A * 51,)
     args2 = _args(model=str(tmp_path / "model.pth"), hidden_size=hidden, batch_size=B)
     agent2 = Agent(args2, env)
@@ -343,3 +344,133 @@ def test_device_rng_noise_statistics(hip):
 def cabi_noise_layout(lib, cfg):
     from cabi_adapter import query_layout
     return query_layout(lib, cfg, lib.rb_learner_noise_layout)
+
+
+def test_reference_written_checkpoint_interchange(hip, tmp_path):
+    """tests/golden/ref_model_dataeff.pth was written by the REFERENCE's Agent.save (tests/golden/make_golden_model.py).
+    Loading it through args.model (agent.py:26-36) must reproduce the reference's own act / evaluate_q on the same
+    states in train mode (i.e. with the checkpoint's epsilon buffers: no resample after load) and eval mode; saving it
+    back must give a file the reference layout-checks as identical: same keys, same order, bit-identical tensors."""
+    import os
+    from helpers import GOLDEN_DIR
+    from rainbow_amd.agent import Agent
+    path = os.path.join(GOLDEN_DIR, "ref_model_dataeff.pth")
+    want = load_golden("ref_model_dataeff.npz")
+    args = _args(architecture="data-efficient", hidden_size=32, batch_size=4, model=path)
+    env = types.SimpleNamespace(action_space=lambda: 4)
+    agent = Agent(args, env)
+    states = torch.from_numpy(want["states_u8"].astype(np.float32) / np.float32(255)).cuda()
+    agent.train()
+    assert [agent.act(s) for s in states] == list(want["act_train"])
+    np.testing.assert_allclose([agent.evaluate_q(s) for s in states], want["q_train"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(agent.evaluate_q_batch(states), want["q_train"], rtol=2e-5, atol=1e-6)
+    assert list(agent.act_batch(states)) == list(want["act_train"])
+    agent.eval()
+    assert [agent.act(s) for s in states] == list(want["act_eval"])
+    np.testing.assert_allclose(agent.evaluate_q_batch(states), want["q_eval"], rtol=2e-5, atol=1e-6)
+    agent.train()
+    ref_sd = torch.load(path, map_location="cpu")
+    agent.save(str(tmp_path), "back.pth")
+    back = torch.load(str(tmp_path / "back.pth"), map_location="cpu")
+    assert list(back.keys()) == list(ref_sd.keys())
+    for k in ref_sd:
+        assert back[k].dtype == ref_sd[k].dtype and torch.equal(back[k], ref_sd[k]), k
+    # strictness of the reference's load_state_dict (agent.py:33)
+    broken = dict(ref_sd)
+    broken.pop("fc_z_a.bias_epsilon")
+    with pytest.raises(RuntimeError):
+        agent.load_state_dict(broken)
+    broken = dict(ref_sd, extra_key=torch.zeros(1))
+    with pytest.raises(RuntimeError):
+        agent.load_state_dict(broken)
+
+
+def test_batched_evaluation_of_validation_memory(hip):
+    """SURVEY 8f row 4 (test.py:38-39): Q over a 500-state validation memory as a handful of launches.  states_at(indices)
+    must equal the per-index iterator (memory.py:162-178) and evaluate_q_memory must equal 500 single evaluate_q calls and
+    the oracle's act on a sample of the states."""
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+    args = _args(hidden_size=64, batch_size=8)
+    A, cap = 6, 500
+    env = types.SimpleNamespace(action_space=lambda: A)
+    torch.manual_seed(9)
+    agent = Agent(args, env)
+    val = ReplayMemory(args, cap, seed=1)
+    rs = np.random.RandomState(2)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    frames = torch.randint(0, 256, (cap, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    val.append_batch(frames, np.full(cap, -1), np.zeros(cap), rs.random_sample(cap) < 0.05)     # main.py:134: action -1
+    assert val.transitions.full and val.transitions.index == 0
+    per_index = torch.stack([s for s in val])                       # the reference's iterator protocol, 500 launches
+    batched = val.states_at(torch.arange(cap))
+    assert torch.equal(per_index, batched)
+    agent.eval()                                                    # test.py evaluates with online_net.eval()
+    qs = agent.evaluate_q_memory(val)
+    single = np.array([agent.evaluate_q(s) for s in per_index[:40]], dtype=np.float32)
+    np.testing.assert_allclose(qs[:40], single, rtol=2e-5, atol=1e-6)
+    cfg = O.Config(batch=8, atoms=51, actions=A, history=4, hidden=64, architecture="canonical", multi_step=3)
+    online = {k: v.cpu().numpy() for k, v in agent.state_dict().items() if "epsilon" not in k}
+    acts = agent.act_batch(batched[:32])
+    for i in (0, 1, 17, 31, 499):
+        a_want, q_want = O.act(cfg, online, None, per_index[i].cpu().numpy())
+        np.testing.assert_allclose(qs[i], q_want, rtol=2e-5, atol=1e-6)
+        if i < 32:
+            assert acts[i] == a_want
+    assert qs.shape == (cap,) and np.all(np.isfinite(qs))
+
+
+def test_checkpoint_restore_resumes_bit_exactly(hip, tmp_path):
+    """SURVEY 8f row 3 'exact resume': run 6 steps, checkpoint agent + replay after step 3, restore both into FRESH
+    objects and run steps 4-6 again: parameters, Adam moments, noise, per-sample losses and the sum-tree must come out
+    bit-identical (device Philox streams of the noise generator and the sampler included)."""
+    import io
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+    args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
+    env = types.SimpleNamespace(action_space=lambda: 4)
+
+    def fresh():
+        torch.manual_seed(77)
+        np.random.seed(77)
+        agent = Agent(args, env)
+        mem = ReplayMemory(args, 2048, seed=5)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        rs = np.random.RandomState(3)
+        for _ in range(2):
+            mem.append_batch(torch.randint(0, 256, (1500, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
+                             rs.randint(0, 4, 1500), rs.choice([-1.0, 0.0, 1.0], size=1500), rs.random_sample(1500) < 0.01)
+        return agent, mem
+
+    def run(agent, mem, steps):
+        losses = []
+        for k in steps:
+            mem.priority_weight = min(1.0, 0.4 + 0.05 * k)
+            agent.reset_noise()
+            agent.learn(mem)
+            losses.append(agent._loss.clone())
+            if k == 4:
+                agent.update_target_net()
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu().numpy()
+
+    a1, m1 = fresh()
+    run(a1, m1, range(3))
+    ck = a1.checkpoint(str(tmp_path / "agent.ck"))
+    buf = io.BytesIO()
+    m1.save_to(buf, chunk_bytes=1 << 20)
+    tail1 = run(a1, m1, range(3, 6))
+    a2, _unused = fresh()
+    a2.restore(str(tmp_path / "agent.ck"))
+    buf.seek(0)
+    m2 = ReplayMemory.load_from(buf, torch.device("cuda:0"), chunk_bytes=1 << 20)
+    tail2 = run(a2, m2, range(3, 6))
+    assert np.array_equal(tail1, tail2)
+    assert torch.equal(a1.params.detach(), a2.params.detach()) and torch.equal(a1.target_params, a2.target_params)
+    assert torch.equal(a1.noise, a2.noise) and torch.equal(a1.target_noise, a2.target_noise)
+    s1, s2 = a1.optimiser.state[a1.params], a2.optimiser.state[a2.params]
+    assert torch.equal(s1["exp_avg"], s2["exp_avg"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
+    assert float(s1["step"]) == float(s2["step"]) == 6.0
+    assert np.array_equal(m1._grab("tree"), m2._grab("tree"))
+    assert bytes(m1._header()) == bytes(m2._header())
+    assert isinstance(ck, dict) and ck["adam_step"] == 3.0
