@@ -236,6 +236,7 @@ def main():
                     help="profiling tag of the kernel the roofline object reports (default: the dominant one, measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
+    ap.add_argument("--extra-tags", default="", help="comma-separated extra profiling tags to time (bytes unknown: time only)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the learn step as one captured hipGraph (no per-kernel HIP-event timing then; measured "
                          "within 2%% of eager on MI355X, profiles/round1_launch_ab.txt)")
@@ -342,6 +343,11 @@ def main():
             t, n = bracketed(other, min(200, opt.steps))
             if t is not None:
                 others[other] = (t, n)
+    extra = {}
+    for tag in [t for t in opt.extra_tags.split(",") if t]:
+        t, n = bracketed(tag, min(200, opt.steps))
+        if t is not None:
+            extra[tag] = t * 1e6
     ev_ms = C.c_double(0)
     lib.rb_profile_overhead(torch.cuda.current_stream(dev).cuda_stream, 256, C.byref(ev_ms))
     ev_us = ev_ms.value * 1e3          # what an EMPTY event pair reads: reported, not subtracted (rocprof's duration of
@@ -405,6 +411,8 @@ def main():
                                 {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": t_mfma / sec})
         out["roofline_step"].update(algorithmic_flops=flops, algorithmic_bytes=nbytes)
+        if extra:
+            out["extra_kernel_us"] = extra
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(cfg)
         print(json.dumps(out))

@@ -277,6 +277,19 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg_dev, fl
                          double lr, double beta1, double beta2, double eps, int64_t step,
                          float* norm_dev, rb_stream_t stream);
 
+/* Learner options.
+ * RB_LEARNER_FUSE_FC_H_DW: the hidden layer's weight gradient (93 % of all gradient bytes) is a rank-B product of two
+ *   L2-resident matrices.  With this flag (and batch <= 32) rb_learner_learn* computes it for the global norm only and
+ *   does NOT store it; rb_learner_clip_adam then recomputes each 16 x 64 tile on the MFMA units while it streams that
+ *   tile's parameters and moments — 2 x 25.7 MB less HBM traffic per step at the canonical shape.  Contract: the next
+ *   call on the handle after rb_learner_learn* must be rb_learner_clip_adam (clip_grad / grads_modified refuse), and
+ *   grads_dev does not hold the hidden layer's weight gradient afterwards ...
+ * RB_LEARNER_WRITE_FUSED_GRADS: ... unless this flag is set as well: the fused pass then also stores the tiles it
+ *   computed (as clip_grad_norm_ leaves them), which is how the parity tests read the product path's gradient.        */
+#define RB_LEARNER_FUSE_FC_H_DW 1
+#define RB_LEARNER_WRITE_FUSED_GRADS 2
+int rb_learner_set_flags(rb_learner_t* l, int32_t flags);
+
 /* Fused priority write-back (agent.py:100 -> memory.py:157-159).  With a sink set, rb_learner_learn*
  * itself applies  sum_tree[tree_idx] = loss^w  (+ ancestor sums, max) to `replay` as one extra
  * workgroup of its backward launch, i.e. off the step's critical path.  tree_idx_dev must be the

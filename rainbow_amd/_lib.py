@@ -90,6 +90,7 @@ SIGNATURES = {
     "rb_learner_clip_grad": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rb_learner_clip_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                      c_int64, c_void_p, c_void_p]),
+    "rb_learner_set_flags": (c_int, [c_void_p, c_int32]),
     "rb_learner_set_priority_sink": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rb_learner_priority_written": (c_int, [c_void_p]),
     "rb_learner_grads_modified": (c_int, [c_void_p]),
@@ -118,6 +119,9 @@ def declare(lib, strict=True):
     if missing and strict:
         raise ImportError("librainbow: missing C-ABI symbols: %s" % ", ".join(missing))
     return lib
+
+
+LEARNER_FUSE_FC_H_DW, LEARNER_WRITE_FUSED_GRADS = 1, 2
 
 
 class RainbowError(RuntimeError):

@@ -164,6 +164,9 @@ struct rb_learner {
   int64_t fact_stride;
   hipEvent_t ev_fact;       // recorded when fact_local is complete (the all-gather may start under the rest of the backward)
   int exch_pending;         // a learn call left its FC weight gradients to rb_learner_finish_grads
+  int flags;                // RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS (rb_learner_set_flags)
+  int dw_deferred;          // the last learn call computed the hidden layer's weight gradient for its norm only: the
+                            // optimiser pass (rb_learner_clip_adam) recomputes the tiles while it streams the parameters
   float gamma_n;        // float32(discount ** n)        agent.py:79
   float delta_z;        // float32((Vmax - Vmin)/(Z-1))   agent.py:19,82
 };
@@ -580,6 +583,9 @@ struct ClipAdamArgs {
   const float* part; int nparts;
   float max_norm; float* norm_out;
   float w1, b2, w2, neg_step_size, bc2_sqrt, eps;
+  // FUSED: elements [skip_lo, skip_lo + skip_len) (the hidden layer's mu | sigma weight arrays) are not touched by the
+  // elementwise part: the tile part below updates them from gradients it recomputes on the fly
+  int64_t skip_lo4, skip_len4;        // in float4 units
 };
 // (IEEE sqrt and divisions, as torch computes them: hardware rcp / approximate sqrt measured 1.5 us faster per launch
 // and stay far inside the test tolerance, but the update would no longer be the reference's formula rounding for rounding)
@@ -590,17 +596,125 @@ __device__ __forceinline__ void rb_adam_elem(float& p, float& g, float& m, float
   const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
   p = p + a.neg_step_size * (m / denom);
 }
-template <int RB_ADAM_UNROLL, bool WT>   // float4 quadruples (p, g, m, v) in flight per thread; WT: write-through stores
-__global__ __launch_bounds__(256) void k_clip_adam(ClipAdamArgs a) {
-  __shared__ float s_red[16];
-  const int64_t n4 = a.n >> 2;
-  const int64_t base = (int64_t)blockIdx.x * (256 * RB_ADAM_UNROLL) + threadIdx.x;
-  float4 P[RB_ADAM_UNROLL], G[RB_ADAM_UNROLL], M[RB_ADAM_UNROLL], V[RB_ADAM_UNROLL];
+__device__ __forceinline__ void rb_adam_quad(float4& P, float4& G, float4& M, float4& V, float coef, const ClipAdamArgs& a) {
+  rb_adam_elem(P.x, G.x, M.x, V.x, coef, a);
+  rb_adam_elem(P.y, G.y, M.y, V.y, coef, a);
+  rb_adam_elem(P.z, G.z, M.z, V.z, coef, a);
+  rb_adam_elem(P.w, G.w, M.w, V.w, coef, a);
+}
+// Tile part of the fused optimiser pass (batch <= 32).  The hidden layer's weight gradient is a rank-B product,
+// g_mu = dY^T X  (dY [B][2H], X [B][F], both L2-resident: 0.5 MB), g_sigma = g_mu * (eps_out x eps_in).  Writing it in the
+// backward and reading it back here costs 2 x 25.7 MB of HBM traffic per step; instead a wave recomputes its 16 x 64
+// tile with 32 MFMAs (same operand order as rb_nl_dw_body_pipe, so the bits equal those of the backward's norm-only
+// pass) while its p / m / v loads are in flight, and applies clip + Adam to mu and sigma right there: 6 array passes
+// over the 6.4 M weights instead of 9.
+struct FusedDwAdamArgs {
+  NlDwArgs dw;                 // operands of the weight gradient (g_* unused)
+  int64_t mu_off, sigma_off;   // offsets of the [2H][F] mu / sigma arrays inside p, m, v (and g)
+  int dw_x, n_tile_blocks;     // 256-column block columns; 256-thread tile blocks = dw_x * (2H / 16)
+  int write_grads;             // tests: also store the (unclipped... as clip_grad_norm_ leaves it: clipped) gradient tile
+};
+// Each tile is taken by TWO workgroup slots: slot 0 updates mu, slot 1 sigma (both recompute the same 32 MFMAs — 0.4 GFLOP
+// extra per step against 24 fewer live registers per lane: 4 waves per SIMD instead of 2, no spills; the single-slot
+// version measured 36.5 us per launch against 35.0 for the plain streaming pass, i.e. slower despite 13 % fewer bytes).
+template <bool WT>
+__device__ __forceinline__ void rb_fused_dw_adam_tile(const ClipAdamArgs& a, const FusedDwAdamArgs& f, int b2, float coef) {
+  const NlDwArgs& d = f.dw;
+  const int lane = rb_lane(), wave = rb_wave();
+  const int which = b2 & 1, b = b2 >> 1;                 // 0: mu, 1: sigma
+  const int bx = b % f.dw_x, by = b / f.dw_x;
+  const int kt = bx * 256 + wave * 64;
+  if (kt >= d.K) return;                                  // wave-uniform
+  const int g = (d.n_prob > 1 && by >= d.prob[1].tile_begin) ? 1 : 0;
+  const NlDwProblem pr = d.prob[g];
+  const int row0 = pr.row_begin + (by - pr.tile_begin) * 16;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  const int c = lane & 15, q = lane >> 4;
+  int col4 = kt + 4 * c;
+  const bool cv = col4 < d.K;
+  if (!cv) col4 = d.K - 4;
+  int arow = row0 + c;
+  const bool av_ok = arow < row_end;
+  if (!av_ok) arow = row_end - 1;
+  const int64_t arr = which ? f.sigma_off : f.mu_off;
+  // operands of the gradient tile first (they gate the MFMAs), then the 12 parameter / moment quads (they gate the update)
+  float avs[8];
+  float4 xs[8];
 #pragma unroll
-  for (int u = 0; u < RB_ADAM_UNROLL; ++u) {
-    int64_t i = base + u * 256;
-    if (i >= n4) i = n4 > 0 ? n4 - 1 : 0;          // clamped load (always legal), masked store
-    P[u] = rb_ld4(a.p + 4 * i); G[u] = rb_ld4(a.g + 4 * i); M[u] = rb_ld4(a.m + 4 * i); V[u] = rb_ld4(a.v + 4 * i);
+  for (int st = 0; st < 8; ++st) {
+    const int m = 4 * st + q;
+    const bool mv = m < d.M;
+    const int mcl = mv ? m : d.M - 1;
+    avs[st] = (mv && av_ok) ? d.dy[(int64_t)mcl * d.ldy + arow] : 0.0f;
+    xs[st] = rb_ld4(d.x + (int64_t)mcl * d.ldx + pr.x_off + col4);
+    if (!mv) { xs[st].x = 0.0f; xs[st].y = 0.0f; xs[st].z = 0.0f; xs[st].w = 0.0f; }
+  }
+  const float4 e4 = rb_ld4(d.ein + pr.ein_off + col4);
+  float eo4[4];
+  int64_t off[4];
+  float4 P[4], M[4], V[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int n = row0 + 4 * q + e;
+    if (n > row_end - 1) n = row_end - 1;                 // clamped rows are loaded (legal) and never stored
+    eo4[e] = d.eout[n];
+    off[e] = arr + (int64_t)n * d.K + col4;
+    P[e] = rb_ld4(a.p + off[e]); M[e] = rb_ld4(a.m + off[e]); V[e] = rb_ld4(a.v + off[e]);
+  }
+  rb_f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    if (4 * st < d.M) {                                   // uniform
+      acc[0] = rb_mfma16(avs[st], xs[st].x, acc[0]);
+      acc[1] = rb_mfma16(avs[st], xs[st].y, acc[1]);
+      acc[2] = rb_mfma16(avs[st], xs[st].z, acc[2]);
+      acc[3] = rb_mfma16(avs[st], xs[st].w, acc[3]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    if (n < row_end && cv) {
+      float4 gr;
+      gr.x = acc[0][e]; gr.y = acc[1][e]; gr.z = acc[2][e]; gr.w = acc[3][e];
+      if (which) {                                        // block-uniform: g_sigma = g_mu * (eps_out * eps_in), model.py:39,44
+        const float eo = eo4[e];
+        gr.x = gr.x * (eo * e4.x); gr.y = gr.y * (eo * e4.y); gr.z = gr.z * (eo * e4.z); gr.w = gr.w * (eo * e4.w);
+      }
+      rb_adam_quad(P[e], gr, M[e], V[e], coef, a);
+      if (WT) {
+        const unsigned o = (unsigned)(4 * off[e]);
+        rb_st4_wt(a.p, o, P[e]); rb_st4_wt(a.m, o, M[e]); rb_st4_wt(a.v, o, V[e]);
+      } else {
+        rb_st4(a.p + off[e], P[e]); rb_st4(a.m + off[e], M[e]); rb_st4(a.v + off[e], V[e]);
+      }
+      if (f.write_grads) rb_st4(a.g + off[e], gr);         // as clip_grad_norm_ leaves .grad: scaled when the clip bites
+    }
+  }
+}
+#ifndef RB_ADAM_MINWAVES
+#define RB_ADAM_MINWAVES 1
+#endif
+template <int RB_ADAM_UNROLL, bool WT, bool FUSED>   // float4 quadruples (p, g, m, v) in flight per thread; WT: write-through stores
+__global__ __launch_bounds__(256, RB_ADAM_MINWAVES) void k_clip_adam(ClipAdamArgs a, FusedDwAdamArgs f) {
+  __shared__ float s_red[16];
+  const bool tile_block = FUSED && (int)blockIdx.x < f.n_tile_blocks;
+  const int64_t n4 = (a.n >> 2) - (FUSED ? a.skip_len4 : 0);
+  const int eb = FUSED ? (int)blockIdx.x - f.n_tile_blocks : (int)blockIdx.x;
+  const int64_t base = (int64_t)eb * (256 * RB_ADAM_UNROLL) + threadIdx.x;
+  float4 P[RB_ADAM_UNROLL], G[RB_ADAM_UNROLL], M[RB_ADAM_UNROLL], V[RB_ADAM_UNROLL];
+  int64_t idx[RB_ADAM_UNROLL];
+  if (!tile_block) {
+#pragma unroll
+    for (int u = 0; u < RB_ADAM_UNROLL; ++u) {
+      int64_t i = base + u * 256;
+      if (i >= n4) i = n4 > 0 ? n4 - 1 : 0;          // clamped load (always legal), masked store
+      if (FUSED && i >= a.skip_lo4) i += a.skip_len4;
+      idx[u] = i;
+      P[u] = rb_ld4(a.p + 4 * i); G[u] = rb_ld4(a.g + 4 * i); M[u] = rb_ld4(a.m + 4 * i); V[u] = rb_ld4(a.v + 4 * i);
+    }
   }
   float acc = 0.0f;
   for (int i = (int)threadIdx.x; i < a.nparts; i += 256) acc += a.part[i];
@@ -609,14 +723,15 @@ __global__ __launch_bounds__(256) void k_clip_adam(ClipAdamArgs a) {
   float coef = a.max_norm / (total + 1e-6f);
   if (coef > 1.0f) coef = 1.0f;                                    // clamp(max=1.0)
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) *a.norm_out = total;
+  if (tile_block) {
+    rb_fused_dw_adam_tile<WT>(a, f, (int)blockIdx.x, coef);
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < RB_ADAM_UNROLL; ++u) {
-    const int64_t i = base + u * 256;
-    if (i >= n4) continue;
-    rb_adam_elem(P[u].x, G[u].x, M[u].x, V[u].x, coef, a);
-    rb_adam_elem(P[u].y, G[u].y, M[u].y, V[u].y, coef, a);
-    rb_adam_elem(P[u].z, G[u].z, M[u].z, V[u].z, coef, a);
-    rb_adam_elem(P[u].w, G[u].w, M[u].w, V[u].w, coef, a);
+    if (base + u * 256 >= n4) continue;
+    const int64_t i = idx[u];
+    rb_adam_quad(P[u], G[u], M[u], V[u], coef, a);
     if (WT) {
       const unsigned off = (unsigned)(16 * i);
       rb_st4_wt(a.p, off, P[u]); rb_st4_wt(a.m, off, M[u]); rb_st4_wt(a.v, off, V[u]);
@@ -627,7 +742,7 @@ __global__ __launch_bounds__(256) void k_clip_adam(ClipAdamArgs a) {
   }
   // tail (n % 4 elements): last block's first threads
   if (blockIdx.x == gridDim.x - 1) {
-    const int64_t t = (n4 << 2) + threadIdx.x;
+    const int64_t t = ((a.n >> 2) << 2) + threadIdx.x;
     if (t < a.n) {
       float p = a.p[t], g = a.g[t], m = a.m[t], v = a.v[t];
       rb_adam_elem(p, g, m, v, coef, a);
@@ -1298,7 +1413,7 @@ static FcDwPlan fc_dw_plan(rb_learner* l, const NetPtrs& on, int which, const fl
   NlDwArgs& w = p.a;
   memset(&w, 0, sizeof(w));
   w.dy = dy; w.x = x; w.M = M; w.n_prob = 2; w.ct = ct; w.rpb = 0; w.bstride = 0; w.scale = 1.0f; w.sq_part = nullptr;
-  w.noise_blocks = nullptr; w.eout_noff = 0; w.ein_noff = 0;
+  w.noise_blocks = nullptr; w.eout_noff = 0; w.ein_noff = 0; w.norm_only = 0;
   if (which == 0) {
     const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
     w.ldy = L.NZ; w.ldx = 2 * L.H; w.K = L.H;
@@ -1382,6 +1497,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   const bool exch = l->world > 1 && l->fact_local != nullptr && l->fast_fc;   // replica exchange: FC weight grads deferred
   if (exch && side) { rb_set_error("rb_learner_learn: RB_SIDE_STREAMS and the replica exchange are mutually exclusive"); return RB_ERR_STATE; }
   l->exch_pending = 0;
+  l->dw_deferred = 0;
   if (l->fast_fc) {
     // ---- output layer: weight/bias grads and (ReLU-masked) input grads in one launch
     // sum-of-squares slots (clip_grad_norm_ without re-reading the gradient): [fc_z dW waves | fc_h dW waves | conv reduce blocks]
@@ -1398,6 +1514,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const bool fuse_norm = !side && !exch && zp.slots + hp.slots + c_slots <= 16384;
     NlDwArgs& zw = zp.a;
     NlDwArgs& hw_ = hp.a;
+    const bool defer_dw = (l->flags & RB_LEARNER_FUSE_FC_H_DW) && pipe && h_ct > 0 && fuse_norm && l->fast_conv;
+    hw_.norm_only = defer_dw ? 1 : 0;
+    l->dw_deferred = defer_dw ? 1 : 0;
     zw.sq_part = fuse_norm ? l->norm_part : nullptr;
     hw_.sq_part = fuse_norm ? l->norm_part + zp.slots : nullptr;
     l->norm_slots = fuse_norm ? zp.slots + hp.slots + c_slots : 0;
@@ -1438,9 +1557,12 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     } else {
       NlPriorityUpdate none;
       memset(&none, 0, sizeof(none));
+      // the priority write-back (a single-workgroup latency chain of ~11 us) rides in the LONGER of the two backward
+      // launches: as a tenant of the output layer's launch (~8 us of real work) it was that launch's long pole
+      static const bool up_in_z = getenv("RB_UPDATE_IN_Z") && getenv("RB_UPDATE_IN_Z")[0] == '1';   // A/B switch
       RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd,
-                  dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z + (up.enabled ? 1 : 0))), dim3(256), stream,
-                  zw, zx, zg, up);
+                  dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z + ((up.enabled && up_in_z) ? 1 : 0))), dim3(256), stream,
+                  zw, zx, zg, up_in_z ? up : none);
       if (exch) {
         // every factor of the FC weight gradients exists now (dlogits, h, dh, feat rows [0, B)): pack them for the
         // all-gather, which the caller starts on a side stream as soon as ev_fact fires — under the rest of the backward
@@ -1455,8 +1577,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         if (l->ev_fact) RB_HIP_TRY(hipEventRecord(l->ev_fact, stream));
         l->exch_pending = 1;
       }
-      RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z)), dim3(256),
-                  stream, hw_, hx, hg, none);
+      RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd,
+                  dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled && !up_in_z) ? 1 : 0))), dim3(256),
+                  stream, hw_, hx, hg, up_in_z ? none : up);
     }
     l->sink_done = (up.enabled && !side) ? 1 : 0;
     RB_LAUNCH_CHECK();
@@ -1543,6 +1666,11 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
 
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_clip_grad: NULL handle");
+  if (l->dw_deferred) {
+    rb_set_error("rb_learner_clip_grad: the last learn call left the hidden layer's weight gradient to the fused optimiser "
+                 "pass (RB_LEARNER_FUSE_FC_H_DW); call rb_learner_clip_adam, or clear the flag before learning");
+    return RB_ERR_STATE;
+  }
   const int64_t n = l->L.n_params;
   int nblocks = (int)rb_div_up(n, 256 * 16);
   if (nblocks > 1024) nblocks = 1024;
@@ -1590,14 +1718,36 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
   // 4 quadruples per thread: measured best of {2, 4, 8} on MI355X (254.3 / 255.6 / 256.6 us per step)
   // write-through stores: same-box A/B 253.7 -> 250.8 us per step (RB_ADAM_WT=0 restores plain stores)
   static const bool plain = getenv("RB_ADAM_WT") && getenv("RB_ADAM_WT")[0] == '0';
-  if (!plain && n * 4 < (int64_t)0x7fffffff) {   // buffer-store offsets are 31-bit
-    RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true>), dim3((unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4)), dim3(256),
-                stream, a);
+  const bool wt = !plain && n * 4 < (int64_t)0x7fffffff;   // buffer-store offsets are 31-bit
+  FusedDwAdamArgs f;
+  memset(&f, 0, sizeof(f));
+  a.skip_lo4 = 0; a.skip_len4 = 0;
+  if (l->dw_deferred) {
+    const Layout& L = l->L;
+    const NetPtrs on = net_ptrs(L, l->p_online, l->n_online);
+    FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, l->act[L.nconv - 1], L.B, 0);
+    f.dw = hp.a;
+    f.mu_off = L.h_mu; f.sigma_off = L.h_sigma;
+    f.dw_x = hp.dw_x; f.n_tile_blocks = 2 * hp.dw_x * hp.dw_y;     // two slots per tile: mu, sigma
+    f.write_grads = (l->flags & RB_LEARNER_WRITE_FUSED_GRADS) ? 1 : 0;
+    a.skip_lo4 = L.h_mu >> 2; a.skip_len4 = (L.h_bmu - L.h_mu) >> 2;
+    const unsigned grid = (unsigned)(f.n_tile_blocks + rb_div_up(n4 - a.skip_len4 > 0 ? n4 - a.skip_len4 : 1, 256 * 4));
+    if (wt) { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, true>), dim3(grid), dim3(256), stream, a, f); }
+    else { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false, true>), dim3(grid), dim3(256), stream, a, f); }
+    l->dw_deferred = 0;
   } else {
-    RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false>), dim3((unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4)), dim3(256),
-                stream, a);
+    const unsigned grid = (unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4);
+    if (wt) { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3(grid), dim3(256), stream, a, f); }
+    else { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false, false>), dim3(grid), dim3(256), stream, a, f); }
   }
   RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_set_flags(rb_learner_t* l, int32_t flags) {
+  RB_REQUIRE(l != nullptr, "rb_learner_set_flags: NULL handle");
+  RB_REQUIRE((flags & ~(RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS)) == 0, "rb_learner_set_flags: unknown flag bits");
+  l->flags = flags;
   return RB_OK;
 }
 
@@ -1701,6 +1851,10 @@ int rb_learner_priority_written(rb_learner_t* l) {
 
 int rb_learner_grads_modified(rb_learner_t* l) {
   RB_REQUIRE(l != nullptr, "rb_learner_grads_modified: NULL handle");
+  if (l->dw_deferred) {
+    rb_set_error("rb_learner_grads_modified: the hidden layer's weight gradient was not materialised (RB_LEARNER_FUSE_FC_H_DW)");
+    return RB_ERR_STATE;
+  }
   l->norm_slots = 0;
   return RB_OK;
 }

@@ -424,6 +424,9 @@ struct NlDwArgs {
   float* sq_part;            // optional: one slot per (block, wave) receiving the sum of squares of what that wave wrote
                              // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
   int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave
+  int norm_only;             // 1: the weight-gradient tiles are computed for their sum of squares only and NOT stored (the
+                             // optimiser pass recomputes each tile while it streams the parameters, k_clip_adam<FUSED>);
+                             // the bias gradients are still written
   // Replica exchange: the reduction rows are the all-gathered factor blocks of `world` ranks — row m lives in
   // block m / rpb at row m % rpb, blocks `bstride` floats apart (rpb == 0: one plain matrix) — and the result is the
   // replica MEAN: scale = 1 / world (a power of two for 2/4/8 replicas, i.e. exact; 1.0f otherwise leaves every bit alone)
@@ -708,8 +711,10 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
           float4 gm, gs;
           gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
           gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
-          rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
-          rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+          if (!a.norm_only) {                            // wave-uniform
+            rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
+            rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+          }
           sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
           sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
         }
@@ -756,16 +761,21 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
   // per CU for the whole launch; 32 KB lets five share a CU)
   constexpr int LDSW = RB_NL_DX_LDS > UpdateLds<512, 256>::WORDS ? RB_NL_DX_LDS : UpdateLds<512, 256>::WORDS;
   __shared__ float lds[LDSW];
-  const int b = (int)blockIdx.x;
+  // the write-back block goes FIRST: it is the launch's longest single-workgroup chain and must not queue behind the tiles
+  int b = (int)blockIdx.x;
+  if (up.enabled) {
+    if (b == 0) {
+      rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // n <= 256
+      return;
+    }
+    b -= 1;
+  }
   const int ndw = g.dw_x * g.dw_y;
-  const int ndx = g.dx_x * g.dx_y * g.dx_z;
   if (b < ndw) {
     if (dw.ct > 0) rb_nl_dw_body_pipe(dw, b % g.dw_x, b / g.dw_x, 4 * b);
     else rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
-  } else if (b < ndw + ndx) {
+  } else {
     const int r = b - ndw;
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
-  } else {
-    rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // the one extra block (n <= 256)
   }
 }

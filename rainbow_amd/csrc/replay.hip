@@ -16,6 +16,7 @@
 #include "noise_body.h"
 #include "replay_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -215,16 +216,18 @@ __global__ __launch_bounds__(256) void k_find(ReplayView v, const double* values
 
 // D levels of the search with ONE batch of loads.  c holds level j (1..D) at [2^j - 2, 2^(j+1) - 2); `sel` is the path
 // taken so far inside the fetched subtree (bit per level).  Register arrays are indexed through select chains only.
+// (node indices are 32-bit here: capacity <= 2^30 keeps tree_len below 2^31, and 62 loads with 64-bit address arithmetic
+// made a trip instruction-bound — ~1.8 us per trip against ~0.5 us of memory latency)
 template <int D>
-__device__ __forceinline__ void rb_descend_levels(const float* tree, int64_t& node, double& value, int64_t last, float& nv) {
+__device__ __forceinline__ void rb_descend_levels(const float* tree, int32_t& node, double& value, int32_t last, float& nv) {
   float c[(2 << D) - 2];
 #pragma unroll
   for (int j = 1; j <= D; ++j) {
-    const int64_t base = ((node + 1) << j) - 1;
+    const uint32_t base = (((uint32_t)node + 1u) << j) - 1u;
 #pragma unroll
     for (int t = 0; t < (1 << j); ++t) {
-      const int64_t q = base + t;
-      c[(1 << j) - 2 + t] = tree[q > last ? last : q];
+      const uint32_t q = base + (uint32_t)t;
+      c[(1 << j) - 2 + t] = tree[q > (uint32_t)last ? (uint32_t)last : q];
     }
   }
   int sel = 0;
@@ -236,8 +239,8 @@ __device__ __forceinline__ void rb_descend_levels(const float* tree, int64_t& no
     const double l = (double)lf;
     const bool r = value > l;
     if (r) value = __dsub_rn(value, l);
-    const int64_t nx = 2 * node + 1 + (r ? 1 : 0);
-    node = nx > last ? last : nx;
+    const uint32_t nx = 2u * (uint32_t)node + 1u + (r ? 1u : 0u);
+    node = (int32_t)(nx > (uint32_t)last ? (uint32_t)last : nx);
     sel = 2 * sel + (r ? 1 : 0);
     if (j == D) {
       nv = c[(1 << j) - 2];
@@ -250,13 +253,13 @@ __device__ __forceinline__ void rb_descend_levels(const float* tree, int64_t& no
 __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const float* s_top, int n_cached,
                                                         int32_t levels, int64_t tree_len, double value,
                                                         float* node_value) {
-  int64_t node = 0;
+  int32_t node = 0;
   int32_t lv = 0;
   float nv = 0.0f;                                  // tree[node] of the node reached (saves the caller a round trip)
   bool have_nv = false;
-  const int64_t last = tree_len - 1;
+  const int32_t last = (int32_t)(tree_len - 1);
   for (; lv < levels; ++lv) {                       // LDS phase
-    int64_t left = 2 * node + 1, right = left + 1;
+    int32_t left = 2 * node + 1, right = left + 1;
     if (left > last) left = last;
     if (right > last) right = last;
     if (right >= n_cached) break;
@@ -282,7 +285,104 @@ __device__ __forceinline__ int64_t rb_tree_descend_fast(const float* tree, const
   // a child index clamped to the last node may not be the entry that was loaded for the unclamped slot: re-read then
   if (!have_nv || node == last) nv = tree[node];   // rare: explicit branch so the common path carries no load
   *node_value = nv;
-  return node;
+  return (int64_t)node;
+}
+
+// The same search WITHOUT the LDS top: every level comes from global memory, up to six levels per round trip, the trips
+// balanced (20 levels = 5+5+5+5, 17 = 6+6+5).  The nodes of the first trips are the same few KB for every sample and every
+// launch (L2-resident, wave-wide broadcast loads); only the last trip reaches rows of the tree that miss.  Measured
+// against the LDS-top variant (stage 16 KB, 11 LDS steps, 2 trips): see DESIGN.md §3 sampler row.
+template <int DMAX>   // most levels per trip: 6 needs 126 registers for the fetched subtree (the <= 256-thread kernel only)
+__device__ __forceinline__ int64_t rb_tree_descend_global(const float* tree, int32_t levels, int64_t tree_len, double value,
+                                                          float* node_value) {
+  int32_t node = 0;
+  int32_t lv = 0;
+  float nv = 0.0f;
+  const int32_t last = (int32_t)(tree_len - 1);
+  while (lv < levels) {
+    const int32_t rem = levels - lv;
+    const int32_t trips = (rem + DMAX - 1) / DMAX;
+    const int32_t d = (rem + trips - 1) / trips;
+    switch (d) {
+      case 6: if (DMAX >= 6) { rb_descend_levels<(DMAX >= 6 ? 6 : 5)>(tree, node, value, last, nv); break; }
+      case 5: rb_descend_levels<5>(tree, node, value, last, nv); break;
+      case 4: rb_descend_levels<4>(tree, node, value, last, nv); break;
+      case 3: rb_descend_levels<3>(tree, node, value, last, nv); break;
+      case 2: rb_descend_levels<2>(tree, node, value, last, nv); break;
+      default: rb_descend_levels<1>(tree, node, value, last, nv); break;
+    }
+    lv += d;
+  }
+  if (levels == 0 || node == last) nv = tree[node];
+  *node_value = nv;
+  return (int64_t)node;
+}
+
+// Window, scalars and importance weight of ONE sample (memory.py:111-121,140-145,151-153) with every load of the window
+// requested in a single batch: NCH chunks of 8 timesteps and 8 rewards (NCH = ceil((h + n) / 8): 1 for n = 3, 3 for the
+// data-efficient n = 20 — whose second and third chunk used to be two more dependent round trips each).
+template <int NCH>
+__device__ __forceinline__ float rb_sample_window(const ReplayView& v, int64_t idx, float prob, float p_total, int32_t full,
+                                                  int64_t w_index, float neg_beta_f32, const float* scaling, int32_t* my_win,
+                                                  int64_t* action_out, float* return_out, float* nonterminal_out) {
+  // ring slots as 32-bit, wrapped with two selects (capacity > window, checked by the host; |offset| < capacity): the
+  // 64-bit while-loop form put control flow between the loads, and every load became its own ~0.35 us round trip
+  // (5.8 us for the 16 loads of n = 3, 16.8 us for the 48 loads of n = 20 — measured with in-kernel timestamps)
+  const int32_t C = (int32_t)v.capacity;
+  const int32_t id = (int32_t)idx;
+  const int h = v.history, n = v.n;
+  const int win_len = h + n;
+  auto wrap = [C](int32_t x) { x += x < 0 ? C : 0; x -= x >= C ? C : 0; return x; };
+  constexpr int NT = 8 * NCH;
+  int ts[NT];
+  float rw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tc = t < win_len ? t : win_len - 1;
+    ts[t] = v.timestep[wrap(id + tc - (h - 1))];
+    const int kc = t < n ? t : n - 1;
+    rw[t] = v.reward[wrap(id + kc)];
+  }
+  const int act_now = v.action[id];                                   // slot h-1 is never blanked
+  const uint8_t nt_last = v.nonterminal[wrap(id + n)];
+  // IS weight while those loads are in flight: probs / p_total ; capacity * probs ; ** -beta (memory.py:151-153).  The
+  // reference evaluates the power in float32 (numpy: ~1 ulp, machine dependent); here exp(-beta * log(x)) in float64
+  // (relative error ~1e-15, then ONE rounding to float32 — correctly rounded except on near-ties) — a third of the
+  // instructions of the general double pow(), which was the longest ALU chain of the kernel.
+  float w;
+  {
+    const float pn = __fdiv_rn(prob, p_total);
+    const float cap = (float)(full ? C : w_index);
+    const float base = __fmul_rn(cap, pn);
+    w = base > 0.0f ? (float)exp((double)neg_beta_f32 * log((double)base)) : (float)pow((double)base, (double)neg_beta_f32);
+  }
+  unsigned long long first_bits = 0ull;  // h+n <= 64
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t < win_len && ts[t] == 0) first_bits |= 1ull << t;
+  unsigned long long blank = 0ull;
+  for (int t = h - 2; t >= 0; --t) {  // memory.py:116-117
+    const bool b = ((blank >> (t + 1)) & 1ull) || ((first_bits >> (t + 1)) & 1ull);
+    if (b) blank |= 1ull << t;
+  }
+  for (int t = h; t < win_len; ++t) {  // memory.py:118-119
+    const bool b = ((blank >> (t - 1)) & 1ull) || ((first_bits >> t) & 1ull);
+    if (b) blank |= 1ull << t;
+  }
+  for (int t = 0; t < win_len; ++t) my_win[t] = ((blank >> t) & 1ull) ? -1 : wrap(id + t - (h - 1));
+  *action_out = (int64_t)act_now;                                     // memory.py:140
+  float R = 0.0f;                                                     // memory.py:142-143, k ascending
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (k < n) {
+      const float rew = ((blank >> (h - 1 + k)) & 1ull) ? 0.0f : rw[k];
+      R = __fadd_rn(R, __fmul_rn(rew, scaling[k]));
+    }
+  }
+  *return_out = R;
+  const int t_last = h + n - 1;                                       // memory.py:145
+  *nonterminal_out = ((blank >> t_last) & 1ull) ? 0.0f : (nt_last ? 1.0f : 0.0f);
+  return w;
 }
 
 // ReplayMemory.sample on device (memory.py:124-155).  ONE workgroup, thread i = sample i
@@ -294,11 +394,15 @@ __device__ long long g_stamp[32];
 #else
 #define RB_STAMP_AT(i) ((void)0)
 #endif
-__global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
+// MAXT = 256 for batches up to 256 (the learn step's shapes): the register budget of a 4-wave workgroup lets a thread hold
+// a six-level subtree; MAXT = 1024 (batches up to 1024) keeps to four levels per trip and 128 registers.  NO variant may
+// spill: a kernel with a scratch segment slowed every kernel of the step on MI355X (214 -> 283 us per step, measured).
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                  float* weights_out, NoiseJob job, int32_t* fail_count) {
+                                                  float* weights_out, NoiseJob job, int32_t* fail_count, int32_t lds_top) {
   if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
     const int nb = (int)blockIdx.x - 1;
     rb_noise_body(job.noise, job.noise2, nullptr, job.map, job.seed, job.ctr, nb % job.nblk, job.nblk, nb / job.nblk, job.nets);
@@ -315,19 +419,22 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
   const float neg_beta_f32 = neg_beta_ptr ? *neg_beta_ptr : neg_beta_arg;
 
   const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
-  for (int t = 4 * i; t < n_cached; t += 4 * (int)blockDim.x) {        // 16-byte loads (the tree buffer is 16-byte aligned)
-    if (t + 3 < n_cached) {
-      *reinterpret_cast<float4*>(&s_top[t]) = *reinterpret_cast<const float4*>(&v.tree[t]);
-    } else {
-      for (int u = t; u < n_cached; ++u) s_top[u] = v.tree[u];
+  if (lds_top) {
+    for (int t = 4 * i; t < n_cached; t += 4 * (int)blockDim.x) {        // 16-byte loads (the tree buffer is 16-byte aligned)
+      if (t + 3 < n_cached) {
+        *reinterpret_cast<float4*>(&s_top[t]) = *reinterpret_cast<const float4*>(&v.tree[t]);
+      } else {
+        for (int u = t; u < n_cached; ++u) s_top[u] = v.tree[u];
+      }
     }
   }
   const int64_t w_index = v.hdr->index;
   const int32_t full = v.hdr->full;
   const uint64_t rng_base = v.hdr->rng_counter;
-  __syncthreads();
+  const float p_total_g = v.tree[0];
+  if (lds_top) __syncthreads();
   RB_STAMP_AT(1);
-  const float p_total = s_top[0];                               // memory.py:149
+  const float p_total = lds_top ? s_top[0] : p_total_g;         // memory.py:149
   // segment_length = p_total / batch_size: float32 / python int -> float32 (NEP 50)
   const float seg_f = __fdiv_rn(p_total, (float)batch);         // memory.py:125
   const double seg = (double)seg_f;
@@ -349,7 +456,8 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     const double sample = __dadd_rn(__dadd_rn(0.0, __dmul_rn(seg, u)), start);
     int valid = 1;
     if (active) {
-      leaf = rb_tree_descend_fast(v.tree, s_top, n_cached, v.levels, v.tree_len, sample, &prob);   // memory.py:130
+      leaf = lds_top ? rb_tree_descend_fast(v.tree, s_top, n_cached, v.levels, v.tree_len, sample, &prob)
+                     : rb_tree_descend_global<(MAXT <= 256 ? 6 : 4)>(v.tree, v.levels, v.tree_len, sample, &prob);   // memory.py:130
       const int64_t idx = leaf - v.tree_start;
       // memory.py:131
       valid = (rb_wrap(w_index, -idx, C) > (int64_t)n) && (rb_wrap(idx, -w_index, C) >= (int64_t)h) &&
@@ -368,87 +476,14 @@ __global__ __launch_bounds__(1024) void k_sample(ReplayView v, int32_t batch, fl
     const int64_t idx = leaf - v.tree_start;
     const int win_len = h + n;
     int32_t* my_win = win + (int64_t)i * win_len;
-    // Everything below depends only on idx: the window's timesteps, the action, the n rewards and the last
-    // nonterminal are fetched in ONE round trip (8 at a time, fully unrolled — a runtime-length loop of
-    // load-then-test made each of the h+n timesteps and n rewards its own dependent trip: 15 -> ~9 us).
-    constexpr int CH = 8;
-    int ts0[CH];
-    float rw0[CH];
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const int tc = t < win_len ? t : win_len - 1;
-      ts0[t] = v.timestep[rb_wrap(idx, (int64_t)(tc - (h - 1)), C)];
-      const int kc = t < n ? t : n - 1;
-      rw0[t] = v.reward[rb_wrap(idx, (int64_t)kc, C)];
-    }
-    const int64_t ring_now = idx;
-    const int act_now = v.action[ring_now];                             // slot h-1 is never blanked
-    const int64_t ring_last = rb_wrap(idx, (int64_t)n, C);
-    const uint8_t nt_last = v.nonterminal[ring_last];
-    // IS weight while those loads are in flight: probs / p_total ; capacity * probs ; ** -beta (memory.py:151-153),
-    // all float32 (the double pow is the longest ALU chain of the kernel)
-    {
-      const float pn = __fdiv_rn(prob, p_total);
-      const float cap = (float)(full ? C : w_index);
-      const float base = __fmul_rn(cap, pn);
-      w = (float)pow((double)base, (double)neg_beta_f32);
-    }
-    // firsts: timestep == 0
-    unsigned long long first_bits = 0ull;  // h+n <= 64
-#pragma unroll
-    for (int t = 0; t < CH; ++t)
-      if (t < win_len && ts0[t] == 0) first_bits |= 1ull << t;
-    for (int t0 = CH; t0 < win_len; t0 += CH) {                         // long windows (n = 20): 8 more per trip
-      int tsx[CH];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const int tc = t0 + t < win_len ? t0 + t : win_len - 1;
-        tsx[t] = v.timestep[rb_wrap(idx, (int64_t)(tc - (h - 1)), C)];
-      }
-#pragma unroll
-      for (int t = 0; t < CH; ++t)
-        if (t0 + t < win_len && tsx[t] == 0) first_bits |= 1ull << (t0 + t);
-    }
-    unsigned long long blank = 0ull;
-    for (int t = h - 2; t >= 0; --t) {  // memory.py:116-117
-      const bool b = ((blank >> (t + 1)) & 1ull) || ((first_bits >> (t + 1)) & 1ull);
-      if (b) blank |= 1ull << t;
-    }
-    for (int t = h; t < win_len; ++t) {  // memory.py:118-119
-      const bool b = ((blank >> (t - 1)) & 1ull) || ((first_bits >> t) & 1ull);
-      if (b) blank |= 1ull << t;
-    }
-    for (int t = 0; t < win_len; ++t) {
-      const int64_t ring = rb_wrap(idx, (int64_t)(t - (h - 1)), C);
-      my_win[t] = ((blank >> t) & 1ull) ? -1 : (int32_t)ring;
-    }
-    actions_out[i] = (int64_t)act_now;                                  // memory.py:140
-    float R = 0.0f;                                                     // memory.py:142-143, k ascending
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      if (k < n) {
-        const float rew = ((blank >> (h - 1 + k)) & 1ull) ? 0.0f : rw0[k];
-        R = __fadd_rn(R, __fmul_rn(rew, scaling[k]));
-      }
-    }
-    for (int k0 = CH; k0 < n; k0 += CH) {
-      float rwx[CH];
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int kc = k0 + k < n ? k0 + k : n - 1;
-        rwx[k] = v.reward[rb_wrap(idx, (int64_t)kc, C)];
-      }
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        if (k0 + k < n) {
-          const float rew = ((blank >> (h - 1 + k0 + k)) & 1ull) ? 0.0f : rwx[k];
-          R = __fadd_rn(R, __fmul_rn(rew, scaling[k0 + k]));
-        }
-      }
-    }
-    returns_out[i] = R;
-    const int t_last = h + n - 1;                                       // memory.py:145
-    nonterminals_out[i] = ((blank >> t_last) & 1ull) ? 0.0f : (nt_last ? 1.0f : 0.0f);
+    float nt_f;
+    const int nch = (win_len + 7) >> 3;                                 // block-uniform
+#define RB_WIN(N) w = rb_sample_window<N>(v, idx, prob, p_total, full, w_index, neg_beta_f32, scaling, my_win, &actions_out[i], &returns_out[i], &nt_f)
+    if (nch <= 1) RB_WIN(1);
+    else if (nch <= 3 || MAXT > 256) RB_WIN(3);      // (the 1024-thread variant has no registers for longer windows in one batch ...
+    else RB_WIN(8);                                  //  ... rb_replay_sample refuses batch > 256 with history + multi_step > 24)
+#undef RB_WIN
+    nonterminals_out[i] = nt_f;
     tree_idx_out[i] = leaf;
   }
   RB_STAMP_AT(4);
@@ -785,6 +820,9 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
              "rb_replay_sample: NULL argument");
   RB_REQUIRE(batch >= 1 && batch <= r->max_batch, "rb_replay_sample: batch must be in [1,%d]", r->max_batch);
   RB_REQUIRE(max_attempts >= 1, "rb_replay_sample: max_attempts must be >= 1");
+  RB_REQUIRE(r->capacity > (int64_t)r->history + r->n,
+             "rb_replay_sample: capacity must exceed history + multi_step (no window can clear the write head otherwise: "
+             "the reference's rejection loop, memory.py:128-132, would never end)");
   const ReplayView v = view_of(r);
   int threads = (int)(rb_div_up(batch, 64) * 64);
   if (threads < 256) threads = 256;   // enough lanes to stage the 16 KB tree top into LDS in one sweep
@@ -798,8 +836,18 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
     RB_REQUIRE(job.noise && job.ctr && job.nblk > 0 && job.nets >= 1, "rb_replay_sample_fused_noise: empty noise job");
     blocks += (unsigned)(job.nblk * job.nets);
   }
-  RB_LAUNCH_T("sample:k_sample", k_sample, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-            r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host);
+  // RB_SAMPLER=global searches without the LDS-staged tree top (A/B switch).  Measured on MI355X, back-to-back launches,
+  // B = 32 / 1M leaves: 11.1 us (LDS top, 11 LDS steps + 2 trips) vs 11.6 (4 trips); n = 20 / 100k: 14.3 vs 16.1;
+  // B = 256: 20.0 vs 24.4 — a trip costs ~1.3 us of ISSUE (62 loads + select chain), more than the staging it replaces.
+  static const int lds_top = (getenv("RB_SAMPLER") && !strcmp(getenv("RB_SAMPLER"), "global")) ? 0 : 1;
+  if (threads <= 256) {
+    RB_LAUNCH_T("sample:k_sample", k_sample<256>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host, lds_top);
+  } else {
+    RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: batch > 256 supports history + multi_step <= 24");
+    RB_LAUNCH_T("sample:k_sample", k_sample<1024>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host, lds_top);
+  }
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
     RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win,
@@ -830,7 +878,8 @@ static int rb_update_impl(rb_replay_t* r, const int64_t* tree_idx_dev, const flo
                           int32_t apply_pow, rb_stream_t stream) {
   RB_REQUIRE(r && tree_idx_dev && values_dev, "rb_replay_update: NULL argument");
   RB_REQUIRE(n >= 1 && n <= 1024, "rb_replay_update: n must be in [1,1024]");
-  const int threads = (int)(rb_div_up(n, 64) * 64);
+  int threads = (int)(rb_div_up(n, 64) * 64);
+  if (threads < 256) threads = 256;     // the dense rebuild of the tree top wants lanes, not just one per leaf
   RB_LAUNCH(k_update, dim3(1), dim3(threads), stream, view_of(r), tree_idx_dev, values_dev, n, apply_pow, r->omega);
   RB_LAUNCH_CHECK();
   return RB_OK;

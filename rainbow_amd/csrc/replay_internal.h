@@ -47,6 +47,12 @@ __device__ __forceinline__ int64_t rb_floor_mod(int64_t a, int64_t m) {
 // O(1) LDS probes per level instead of scanning the batch.  Every parent is still
 // fl32(left + right) of its current children (memory.py:25): same floats as the reference.
 #define RB_MAX_LEVELS 31
+// The top RB_UPD_TOP levels of the tree are not walked path by path: once every path has reached depth RB_UPD_TOP, the
+// whole top (2^RB_UPD_TOP nodes of that depth, staged in LDS at kernel start, updated entries overwritten) is rebuilt
+// densely — plain LDS adds, no hashing, the last six levels inside one wave without block barriers — and written back.
+// Untouched nodes are recomputed to the very value they hold (every node IS fl32(left + right) of its children), so the
+// result is bit-identical to the per-path walk; the hashed rounds drop from L to L - RB_UPD_TOP (20 -> 9 for 1M leaves).
+#define RB_UPD_TOP 11
 
 // the table size follows the batch (power of two >= 4n, <= 2048 slots): a batch of 32 clears and probes 128 slots
 __device__ __forceinline__ int rb_hash_slot(int node, int shift) {
@@ -75,7 +81,8 @@ __device__ __forceinline__ int rb_hash_find(const int* keys, int node, int shift
 // uses <2048, 1024>, the learner's fused launch <512, 256> so that its other workgroups keep their occupancy.
 template <int HS, int NMAX>
 struct UpdateLds {
-  static constexpr int WORDS = 8 * HS + NMAX + 16;
+  static constexpr int HEAP = 2 << RB_UPD_TOP;          // level-order heap of the top RB_UPD_TOP + 1 levels
+  static constexpr int WORDS = 8 * HS + NMAX + 16 + HEAP;
 };
 template <int HS, int NMAX>
 __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
@@ -85,7 +92,15 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
   int* s_pos = reinterpret_cast<int*>(lds + 7 * HS);
   float* s_vi = lds + 8 * HS;
   float* s_red = lds + 8 * HS + NMAX;
+  float* s_heap = lds + 8 * HS + NMAX + 16;
   const int i = (int)threadIdx.x;
+  // dense top: only when the tree is deeper than the top itself (block-uniform)
+  const bool dense = v.levels > RB_UPD_TOP;
+  const int path_levels = dense ? v.levels - RB_UPD_TOP : v.levels;
+  if (dense) {
+    constexpr int BASE = (1 << RB_UPD_TOP) - 1;
+    for (int t = i; t < (1 << RB_UPD_TOP); t += (int)blockDim.x) s_heap[BASE + t] = v.tree[BASE + t];
+  }
   const bool active = i < n;
   int node = active ? (int)tree_idx[i] : -1;
   // sibling prefetch for every level (stale where another updated path passes; fixed up from LDS)
@@ -94,7 +109,7 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
     int q = node;
 #pragma unroll
     for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
-      if (active && lv < v.levels) {
+      if (active && lv < path_levels) {
         const int sb = (q & 1) ? q + 1 : q - 1;
         sib[lv] = v.tree[sb];
         q = (q - 1) >> 1;
@@ -115,7 +130,8 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
   float val = 0.0f;
   if (active) {
     val = values[i];
-    if (apply_pow) val = (float)pow((double)val, omega);
+    // loss ** omega (memory.py:158; numpy evaluates it in float32, ~1 ulp): exp(omega * log(x)) in float64, rounded once
+    if (apply_pow) val = val > 0.0f ? (float)exp(omega * log((double)val)) : (float)pow((double)val, omega);
   }
   s_vi[i] = val;
   const float vmax = rb_block_max(active ? val : -INFINITY, s_red);  // np.max(values), memory.py:47 (+ barrier)
@@ -132,7 +148,7 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
   int prev_slot = -1;
 #pragma unroll
   for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
-    if (lv < v.levels) {                        // block-uniform
+    if (lv < path_levels) {                     // block-uniform
       const int c = lv % 3;
       int my = -1;
       if (active) {
@@ -154,9 +170,38 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
       }
     }
   }
+  if (dense) {
+    constexpr int BASE = (1 << RB_UPD_TOP) - 1;
+    __syncthreads();                            // staged heap level complete; every path stands at depth RB_UPD_TOP
+    if (active) s_heap[node] = val;             // paths on the same node carry the same value
+    __syncthreads();
+#pragma unroll
+    for (int d = RB_UPD_TOP - 1; d >= 6; --d) {
+      const int cnt = 1 << d;
+      for (int j = i; j < cnt; j += (int)blockDim.x) {
+        const int p = cnt - 1 + j;
+        s_heap[p] = __fadd_rn(s_heap[2 * p + 1], s_heap[2 * p + 2]);   // memory.py:25
+      }
+      __syncthreads();
+    }
+    if (i < 64) {                               // wave 0: the last six levels without block barriers
+#pragma unroll
+      for (int d = 5; d >= 0; --d) {
+        const int cnt = 1 << d;
+        if (i < cnt) {
+          const int p = cnt - 1 + i;
+          s_heap[p] = __fadd_rn(s_heap[2 * p + 1], s_heap[2 * p + 2]);
+        }
+        rb_wave_sync();
+      }
+    }
+    __syncthreads();
+    for (int t = i; t < BASE; t += (int)blockDim.x) v.tree[t] = s_heap[t];
+    val = s_heap[0];
+  }
   if (threadIdx.x == 0) {
     v.hdr->max = fmaxf(vmax, v.hdr->max);  // memory.py:48
-    v.hdr->total = val;                    // thread 0 ended at the root
+    v.hdr->total = val;                    // the root
   }
 }
 

@@ -199,6 +199,7 @@ class CAbiLearnAdapter:
     """Drives rb_learner_* exactly like rainbow_amd.agent.Agent does: learn -> fused clip+Adam (default), or
     learn -> clip -> torch Adam (fused_adam = False: the hipGraph path of the Agent and the pre-fusion behaviour)."""
     fused_adam = True
+    learner_flags = 0          # rainbow_amd._lib.LEARNER_* (set on the class or instance BEFORE load())
 
     def __init__(self, lib, mem, name):
         import torch
@@ -242,6 +243,7 @@ class CAbiLearnAdapter:
 
     def load(self, online, target):
         m = self.mem
+        L.check(self.lib, self.lib.rb_learner_set_flags(self.h, int(self.learner_flags) if self.fused_adam else 0))
         if isinstance(self.p_on, np.ndarray):
             self.p_on[:] = self._flat(online)
             self.p_tg[:] = self._flat(target)

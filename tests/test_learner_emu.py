@@ -45,6 +45,25 @@ def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
     ad.close()
 
 
+@pytest.mark.parametrize("name", ["dataeff"])     # (the canonical stack runs the same test on the GPU: 2.5 min on the interpreter)
+def test_fused_weight_gradient_in_optimiser_pass_matches_golden(emu, name):
+    """RB_LEARNER_FUSE_FC_H_DW (what rainbow_amd.agent.Agent runs): the hidden layer's weight gradient is not stored by the
+    backward; the clip + Adam pass recomputes each tile while it streams the parameters.  With WRITE_FUSED_GRADS the pass
+    also stores what it computed, so the whole golden trace (all 22 gradients, norms, post-Adam parameters over three
+    steps) is checked on the product path; without it the parameters must be bit-identical to that run."""
+    from rainbow_amd import _lib as L
+    traces = []
+    for flags in (L.LEARNER_FUSE_FC_H_DW | L.LEARNER_WRITE_FUSED_GRADS, L.LEARNER_FUSE_FC_H_DW):
+        ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+        ad.learner_flags = flags
+        traces.append(scenarios.learn_scenario(ad, name, O))
+        ad.close()
+    assert_learn_trace_matches(traces[0], load_golden("learn_%s.npz" % name), label="emu-fused-dw/" + name)
+    for k in traces[0]:
+        if "_param/" in k or k.endswith("_loss") or k.endswith("grad_norm") or k.startswith(("act_", "q_")):
+            assert np.array_equal(np.asarray(traces[0][k]), np.asarray(traces[1][k])), k
+
+
 def test_unit_conversion_is_exact():
     """rb_unit's multiply + Newton step equals the correctly rounded x/255 for every byte (memory.py:137)."""
     x = np.arange(256, dtype=np.float32)

@@ -20,10 +20,13 @@ def hip():
     return _lib.load()
 
 
+@pytest.mark.parametrize("fused_dw", [False, True], ids=["stored-dw", "fused-dw"])
 @pytest.mark.parametrize("name", sorted(scenarios.LEARN_CONFIGS))
-def test_learn_step_hip_matches_reference_golden(hip, name):
+def test_learn_step_hip_matches_reference_golden(hip, name, fused_dw):
     from cabi_adapter import CAbiLearnAdapter, TorchMem
+    from rainbow_amd import _lib as L
     ad = CAbiLearnAdapter(hip, TorchMem(), name)
+    ad.learner_flags = (L.LEARNER_FUSE_FC_H_DW | L.LEARNER_WRITE_FUSED_GRADS) if fused_dw else 0
     trace = scenarios.learn_scenario(ad, name, O)
     assert_learn_trace_matches(trace, load_golden("learn_%s.npz" % name), label="hip/" + name)
     ad.close()
@@ -245,8 +248,9 @@ BASELINE_SHAPES = {
 }
 
 
+@pytest.mark.parametrize("fused_dw", [False, True], ids=["stored-dw", "fused-dw"])
 @pytest.mark.parametrize("shape", sorted(BASELINE_SHAPES))
-def test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape):
+def test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape, fused_dw):
     """TWO consecutive learn steps through the C ABI at the exact network / batch of each BASELINE config against the CPU
     oracle on the same inputs: per-sample loss, global gradient norm, all 22 (clipped) gradients and the post-Adam
     parameters, with the tolerances of helpers.assert_learn_trace_matches (agent.py:61-100)."""
@@ -256,6 +260,9 @@ def test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape):
     cfg = O.Config(**cfgd)
     hy = scenarios.LEARN_HYPER
     ad = CAbiLearnAdapter(hip, TorchMem(), shape)
+    if fused_dw:   # the Agent's configuration: fc_h weight gradient recomputed inside the clip + Adam pass (batch <= 32);
+        from rainbow_amd import _lib as L      # WRITE_FUSED_GRADS makes that pass store what it computed, for this comparison
+        ad.learner_flags = L.LEARNER_FUSE_FC_H_DW | L.LEARNER_WRITE_FUSED_GRADS
     online, target = O.init_params(cfg, 901), O.init_params(cfg, 902)
     ad.load(online, target)
     adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])

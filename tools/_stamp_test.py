@@ -5,12 +5,12 @@ import bench
 from rainbow_amd import _lib as L
 from rainbow_amd.memory import ReplayMemory
 dev = torch.device("cuda", 0)
-cfg = dict(bench.CONFIGS["pong-canonical-b32"])
+cfg = dict(bench.CONFIGS[os.environ.get("SAMPLE_CONFIG", "pong-canonical-b32")])
 args = bench.make_args(cfg, dev)
 mem = ReplayMemory(args, cfg["capacity"], seed=7)
 bench.fill_replay(mem, cfg["capacity"], cfg["actions"], seed=0)
 lib = L.load()
-B = 32
+B = cfg["batch_size"]
 lib.rb_debug_stamps.argtypes = [C.c_void_p]
 acc = []
 for it in range(60):
