@@ -15,6 +15,14 @@
 #pragma once
 #include "learner_problems.h"
 
+#if defined(RB_STAMP)
+extern __device__ long long g_cstamp[64];
+#define RB_CSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_cstamp[i] = wall_clock64(); } while (0)
+#define RB_CSTAMP_LAST(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) g_cstamp[i] = wall_clock64(); } while (0)
+#else
+#define RB_CSTAMP(i) ((void)0)
+#define RB_CSTAMP_LAST(i) ((void)0)
+#endif
 struct ConvLdsFwdArgs {
   int cin, cout;
   int n_on;                  // images [0,n_on) use net 0, the rest net 1
@@ -25,6 +33,8 @@ struct ConvLdsFwdArgs {
   float* out;                // [img][cout][P]
   float* out_blocked;        // optional second copy of the flattened output in the k-blocked layout of noisy_linear.h
   int rows_total;            //   ... with this many rows (images)
+  int rot;                   // WREG: rotate the wave -> K-slice assignment by the image index (experiment: every workgroup
+                             // otherwise requests the same weight lines at the same moment)
 };
 
 // ---- shared staging helpers ------------------------------------------------------------------
@@ -89,20 +99,31 @@ __device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, i
 #define RB_CONV_WAVES 8
 #define RB_CONV_THREADS (64 * RB_CONV_WAVES)
 // PCH = output positions per workgroup (<= 32 NT; a multiple of the row length keeps the patch at PR rows).
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT>
-__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
-  constexpr int KPAD = (KMAX + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES) * (2 * RB_CONV_WAVES);
+// WREG: the weight operand never touches LDS.  A wave keeps its K-slice of the 32-channel slab in REGISTERS, loaded from
+// global memory straight in the MFMA layout: the reduction index is permuted so that lane (m = l & 31, half = l >> 5) owns
+// the KW/2 CONSECUTIVE weights k = kb + half * KW/2 + j of row m (whole float4 loads; KPAD is a multiple of 64 so every
+// wave's half-slice is a multiple of 4), and MFMA step j multiplies k-pair (kb + j, kb + KW/2 + j) — the same permutation
+// indexes the patch-offset table, a sum does not care.  That removes the transposing LDS stores (4- to 16-way bank
+// conflicts, 34-52 % of the LDS-active cycles of these kernels), one LDS read per MFMA step, and 34-76 KB of LDS per
+// workgroup: two workgroups share a CU and the staging of one runs under the MFMAs of the other.
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false>
+__global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
+  constexpr int KGRAN = WREG ? 8 * RB_CONV_WAVES : 2 * RB_CONV_WAVES;
+  constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
   constexpr int PLANE = PR * G::IH;                 // floats per channel in the patch
   constexpr int CMAX = KMAX / G::KK;
   constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
-  constexpr int OPS = KPAD * 33 + CMAX * PLANE;     // weights then patch, contiguous
+  constexpr int OPS = (WREG ? 0 : KPAD * 33) + CMAX * PLANE;     // [weights then] patch, contiguous
   constexpr int WSZ = OPS > RED ? OPS : RED;
   __shared__ float s_all[WSZ];
   __shared__ int s_koff[KPAD];
   float* s_w = s_all;
-  float* s_patch = s_all + KPAD * 33;
+  float* s_patch = s_all + (WREG ? 0 : KPAD * 33);
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int SB = G::KS == 8 ? 0 : G::KS == 4 ? 8 : 16;    // stamp slots per layer (RB_STAMP builds only)
+  RB_CSTAMP(SB + 0);
+  RB_CSTAMP_LAST(SB + 4);
   const int img = (int)blockIdx.z;
   const int net = img < a.n_on ? 0 : 1;
   const int cout0 = (int)blockIdx.y * 32;
@@ -114,8 +135,30 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
   int rows = G::IH - iy0;
   if (rows > PR) rows = PR;
 
-  // ---- stage: weights (transposed), k -> patch offset table, input patch
-  rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
+  // ---- stage: weights (transposed into LDS, or this wave's slice into registers), k -> patch offset table, input patch
+  constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time: the MFMA loop is fully unrolled
+  constexpr int HW = KW / 2;
+  float areg[WREG ? HW : 1];
+  if constexpr (WREG) {
+    const int ml_ = lane & 31, kh_ = lane >> 5;
+    const int rows_valid = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
+    const float* wrow = a.w[net] + (int64_t)(cout0 + (ml_ < rows_valid ? ml_ : 0)) * K;
+    const int k0 = (a.rot ? ((wave + img) & (RB_CONV_WAVES - 1)) : wave) * KW + kh_ * HW;
+    if ((K & 3) == 0) {
+#pragma unroll
+      for (int j4 = 0; j4 < HW / 4; ++j4) {
+        const int k = k0 + 4 * j4;
+        float4 v4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < K && ml_ < rows_valid) v4 = rb_ld4(wrow + k);            // K % 4 == 0: a quad is inside or outside as a whole
+        areg[4 * j4 + 0] = v4.x; areg[4 * j4 + 1] = v4.y; areg[4 * j4 + 2] = v4.z; areg[4 * j4 + 3] = v4.w;
+      }
+    } else {                                           // odd history lengths
+#pragma unroll
+      for (int j = 0; j < HW; ++j) areg[j] = (k0 + j < K && ml_ < rows_valid) ? wrow[k0 + j] : 0.0f;
+    }
+  } else {
+    rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
+  }
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
     const int c = kc / G::KK, r = kc % G::KK;
@@ -197,10 +240,10 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
     }
   }
   __syncthreads();
+  RB_CSTAMP(SB + 1);
 
-  // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW) of the padded reduction (rows >= K of s_w are zero)
-  constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time: the loop is fully unrolled
-  const int kb = wave * KW;
+  // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW) of the padded reduction (weights beyond K are zero)
+  const int kb = ((WREG && a.rot) ? ((wave + img) & (RB_CONV_WAVES - 1)) : wave) * KW;
   int noff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -214,17 +257,27 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
   const int kh = lane >> 5, ml = lane & 31;
+  float bias_r[(16 * 64) / RB_CONV_THREADS];          // the epilogue's bias terms (its rows do not depend on the tile)
+#pragma unroll
+  for (int it = 0; it < (16 * 64) / RB_CONV_THREADS; ++it) {
+    const int idx = t + it * RB_CONV_THREADS;
+    const int m = cout0 + rb_mfma_row(idx >> 6, idx & 63);
+    bias_r[it] = a.bias[net][m < a.cout ? m : a.cout - 1];
+  }
   // the patch offsets of this wave's k range are read up front: inside the loop they would put an LDS round trip
   // (offset -> operand address) on the critical path of every step (measured 7.1 us of MFMA phase for 5.1 us of MFMAs)
-  int kos[KW / 2];
+  int kos[HW];
 #pragma unroll
-  for (int j = 0; j < KW / 2; ++j) kos[j] = s_koff[kb + 2 * j + kh];
+  for (int j = 0; j < HW; ++j) kos[j] = s_koff[WREG ? kb + kh * HW + j : kb + 2 * j + kh];
 #pragma unroll
-  for (int j = 0; j < KW / 2; ++j) {
-    const float av = s_w[(kb + 2 * j + kh) * 33 + ml];
+  for (int j = 0; j < HW; ++j) {
+    float av;
+    if constexpr (WREG) av = areg[j];
+    else av = s_w[(kb + 2 * j + kh) * 33 + ml];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
+  RB_CSTAMP(SB + 2);
   // cross-wave sum one 32-position tile at a time (32 KB of scratch whatever NT is: the LDS footprint decides how many
   // workgroups share a CU), fixed order w0..w7
 #pragma unroll
@@ -233,7 +286,9 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_all[(wave * 16 + r) * 64 + lane] = acc[nt][r];
     __syncthreads();
-    for (int idx = t; idx < 16 * 64; idx += RB_CONV_THREADS) {
+#pragma unroll
+    for (int it = 0; it < (16 * 64) / RB_CONV_THREADS; ++it) {
+      const int idx = t + it * RB_CONV_THREADS;
       const int l = idx & 63, r = idx >> 6;
       float v = s_all[(0 * 16 + r) * 64 + l];
 #pragma unroll
@@ -241,7 +296,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
       const int m = cout0 + rb_mfma_row(r, l);
       const int p = p0 + nt * 32 + (l & 31);
       if (m < a.cout && p < G::P && p < p0 + PCH) {
-        const float o = fmaxf(v + a.bias[net][m], 0.0f);
+        const float o = fmaxf(v + bias_r[it], 0.0f);      // (bias fetched before the MFMA loop: a global load here sat on
+                                                          //  the critical path of every tile's epilogue)
         a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
         if (a.out_blocked) {
           const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
@@ -250,8 +306,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_lds(ConvLdsFwdArgs
       }
     }
   }
+  RB_CSTAMP(SB + 3);
+  RB_CSTAMP_LAST(SB + 5);
 }
 
+// (RB_STAMP: end-of-kernel stamps are written by the host-visible tail below)
 // ========================================================================= data gradient ==
 // dX[img][c][y][x] = relu'(x_act) * sum_{co,ky,kx} W[co][c][ky][kx] * dY[img][co][(y-ky)/S][(x-kx)/S]
 // decomposed by phase (y % S, x % S) so only real taps are visited.  The whole dY image sits in LDS.

@@ -24,6 +24,10 @@
 
 #include <new>
 
+#if defined(RB_STAMP)
+__device__ long long g_cstamp[64];
+extern "C" int rb_debug_cstamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamp), sizeof(long long) * 64) == hipSuccess ? 0 : -2; }
+#endif
 #define RB_HEAD_MAX_NZ 1408   // 3 logit rows of this many floats live in the head kernel's LDS (18 actions x 51 atoms = 969)
 typedef ConvGeom<8, 4, 84, 20> GeomC1;   // model.py:56
 typedef ConvGeom<4, 2, 20, 9> GeomC2;    // model.py:57
@@ -787,7 +791,7 @@ static int launch_conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const I
   return RB_OK;
 }
 
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT>
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false>
 static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                                const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
@@ -797,8 +801,10 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
+  static const int rot = getenv("RB_CONV_ROT") ? atoi(getenv("RB_CONV_ROT")) : 0;   // A/B switch
+  a.rot = rot;
   static const char* const tags[3] = {"conv1_fwd:k_conv_fwd_lds", "conv2_fwd:k_conv_fwd_lds", "conv3_fwd:k_conv_fwd_lds"};
-  RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH>),
+  RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG>),
               dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
               dim3(RB_CONV_THREADS), stream, a);
   RB_LAUNCH_CHECK();
@@ -808,6 +814,18 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
 static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                     const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
+  // A/B switch: weight operand in registers instead of LDS (conv_lds.h WREG).  Measured SLOWER on MI355X at batch 32
+  // (conv2 17.6 -> 19.0 us, conv3 17.3 -> 18.2 bracketed) although it removes the transposing LDS stores and lets two
+  // workgroups share a CU: with 192-480 workgroups there is no second workgroup to overlap with, and 64 lanes fetching
+  // 64 different weight lines per instruction cost more than the LDS round trip they replace.  Off by default.
+  static const bool wreg = getenv("RB_CONV_WREG") && getenv("RB_CONV_WREG")[0] == '1';
+  if (l->fast_conv && wreg) {
+    if (c.ks == 8) return launch_conv_fwd_lds<GeomC1, 3, 20, 256, true, 80, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ks == 4) return launch_conv_fwd_lds<GeomC2, 3, 20, 512, false, 96, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ks == 3) return launch_conv_fwd_lds<GeomC3, 2, 9, 576, false, 64, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    if (c.ih == 84) return launch_conv_fwd_lds<GeomD1, 2, 20, 100, true, 64, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+    return launch_conv_fwd_lds<GeomD2, 1, 16, 800, false, 32, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+  }
   if (l->fast_conv) {
     if (c.ks == 8) {
       // 80 positions (4 output rows) per workgroup: 5 x 96 = 480 workgroups at batch 32, one round at two per CU

@@ -148,7 +148,9 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
   // UNCONDITIONAL (out-of-range blocks re-read the wave's last block and are multiplied by a zero mask): a branch
   // around a load would make the outstanding-load count unknown to the compiler, which then drains the whole queue
   // (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
-  constexpr int RING = 4;
+  // (MT = 4 carries twice the activation registers: a 4-deep ring spilled 20 B per lane there, and a kernel with a scratch
+  // segment slows the whole step on this platform, so the 64-row variant keeps 3 blocks in flight)
+  constexpr int RING = MT >= 4 ? 3 : 4;
   float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][MT];
   const int c_last = wc1 > wc0 ? wc1 - 1 : (nchunks > 0 ? nchunks - 1 : 0);
   auto chunk_of = [&](int sc, int h) { const int cc = wc0 + 2 * sc + h; return cc < wc1 ? cc : c_last; };
