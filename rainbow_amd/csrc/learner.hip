@@ -814,11 +814,13 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
 static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                     const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
-  // A/B switch: weight operand in registers instead of LDS (conv_lds.h WREG).  Measured SLOWER on MI355X at batch 32
-  // (conv2 17.6 -> 19.0 us, conv3 17.3 -> 18.2 bracketed) although it removes the transposing LDS stores and lets two
-  // workgroups share a CU: with 192-480 workgroups there is no second workgroup to overlap with, and 64 lanes fetching
-  // 64 different weight lines per instruction cost more than the LDS round trip they replace.  Off by default.
-  static const bool wreg = getenv("RB_CONV_WREG") && getenv("RB_CONV_WREG")[0] == '1';
+  // Weight operand in registers instead of LDS (conv_lds.h WREG): two workgroups share a CU, no transposing LDS stores.
+  // Pays once there are at least two workgroups per CU to overlap — batch 256 (768 images): conv forward 93 / 81 / 79 ->
+  // 78 / 72 / 65 us, step 733 -> 691 us — and LOSES at batch 32 (96 images, 192-480 workgroups: nothing to overlap with,
+  // and 64 lanes fetching 64 different weight lines per instruction cost more than the LDS round trip: conv2 17.6 ->
+  // 19.0 us).  So: by image count; RB_CONV_WREG=0/1 forces it for A/B runs.
+  static const int wreg_env = getenv("RB_CONV_WREG") ? atoi(getenv("RB_CONV_WREG")) : -1;
+  const bool wreg = wreg_env >= 0 ? wreg_env != 0 : (n_on + n_tg) >= 256;
   if (l->fast_conv && wreg) {
     if (c.ks == 8) return launch_conv_fwd_lds<GeomC1, 3, 20, 256, true, 80, true>(l, layer, n_on, n_tg, src, on, tg, stream);
     if (c.ks == 4) return launch_conv_fwd_lds<GeomC2, 3, 20, 512, false, 96, true>(l, layer, n_on, n_tg, src, on, tg, stream);

@@ -1,6 +1,7 @@
-"""Per-launch HBM bytes of the hot kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+"""Per-launch HBM bytes of the candidate kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 Units/corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950 FETCH_SIZE reports half of
-the bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so the read side is doubled."""
+the bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so the read side is doubled.
+usage: pmc_summary.py <fetch dir> <write dir>  ->  JSON keyed by bench.py's profiling tags."""
 import csv
 import glob
 import json
@@ -15,24 +16,47 @@ def load(d, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            key = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
+            key = (r["Kernel_Name"], int(r["Grid_Size"]))
             out[key].append(float(r["Counter_Value"]))
     return out
+
+
+def tag_of(name, grid, biggest):
+    """bench.py tag of a kernel instance; the hidden layer's launches are the larger grid of k_nl_fwd2 / k_nl_bwd."""
+    if "k_clip_adam" in name:
+        return "clip_adam"
+    if "k_nl_fwd2" in name:
+        return "fc_h_fwd" if grid == biggest["k_nl_fwd2"] else "fc_z_fwd"
+    if "k_nl_bwd" in name:
+        return "fc_h_bwd" if grid == biggest["k_nl_bwd"] else "fc_z_bwd"
+    if "k_conv_dw_all" in name:
+        return "conv_dw_all"
+    if "k_sample" in name:
+        return "sample"
+    for kind, suffix in (("k_conv_fwd_lds", "fwd"), ("k_conv_dx_lds", "dx")):
+        if kind in name:
+            geo = name.split("ConvGeom<")[1].split(">")[0].replace(" ", "")
+            layer = {"8,4,84,20": 1, "4,2,20,9": 2, "3,1,9,7": 3, "5,5,84,16": 1, "5,5,16,3": 2}.get(geo)
+            return "conv%d_%s" % (layer, suffix) if layer else None
+    return None
 
 
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
+    biggest = {}
+    for (name, grid) in fetch:
+        for k in ("k_nl_fwd2", "k_nl_bwd"):
+            if k in name:
+                biggest[k] = max(biggest.get(k, 0), grid)
     res = {}
-    tags = {"k_clip_adam": "clip_adam", "k_nl_fwd2": "fc_h_fwd", "k_nl_bwd": "fc_h_bwd"}
-    for kern, tag in tags.items():
-        keys = [k for k in fetch if kern in k[0]]
-        if not keys:
+    for key in sorted(fetch):
+        tag = tag_of(key[0], key[1], biggest)
+        if tag is None or len(fetch[key]) < 5:
             continue
-        big = max(keys, key=lambda k: k[1])          # the hidden-layer launch is the larger grid of the two
-        f = sum(fetch[big]) / len(fetch[big])
-        w = sum(write.get(big, [0])) / max(1, len(write.get(big, [0])))
-        res[tag] = {"kernel": kern, "grid_size": big[1], "launches": len(fetch[big]), "FETCH_SIZE_KiB": f,
+        f = sum(fetch[key]) / len(fetch[key])
+        w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
+        res[tag] = {"kernel": key[0].split("(")[0][:80], "grid_size": key[1], "launches": len(fetch[key]), "FETCH_SIZE_KiB": f,
                     "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
                     "note": "FETCH_SIZE doubled (gfx950 half-count of wide coalesced reads), WRITE_SIZE uncalibrated"}
     print(json.dumps(res, indent=1))
