@@ -897,10 +897,15 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
       case 3: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<3>, hg, hb, stream, a); break;
       case 4: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<4>, hg, hb, stream, a); break;
       case 7: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<7>, hg, hb, stream, a); break;
-      default:
-        if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), hg, hb, stream, a); }
+      default: {
+        static const bool fwd3 = !(getenv("RB_FWD3") && getenv("RB_FWD3")[0] == '0');   // A/B switch (0 = k_nl_fwd2)
+        if (fwd3) {
+          if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
+          else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a); }
+        } else if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), hg, hb, stream, a); }
         else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<0>, hg, hb, stream, a); }
         break;
+      }
     }
     RB_LAUNCH_CHECK();
     // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
@@ -913,10 +918,15 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
     z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
-    if (wide) {
-      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+    static const bool zfwd3 = !(getenv("RB_FWD3") && getenv("RB_FWD3")[0] == '0');
+    const dim3 zgrid((unsigned)(vt16 + at16), 1, 2 * mch32), zblock(64 * RB_NL_FWD_WAVES);
+    if (zfwd3) {
+      if (wide) { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<4>, zgrid, zblock, stream, z); }
+      else { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<2>, zgrid, zblock, stream, z); }
+    } else if (wide) {
+      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), zgrid, zblock, stream, z);
     } else {
-      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, dim3((unsigned)(vt16 + at16), 1, 2 * mch32), dim3(64 * RB_NL_FWD_WAVES), stream, z);
+      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, zgrid, zblock, stream, z);
     }
     RB_LAUNCH_CHECK();
     return RB_OK;

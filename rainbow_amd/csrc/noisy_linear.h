@@ -258,6 +258,158 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) 
   }
 }
 
+// k_nl_fwd3 — k_nl_fwd2 with the loop overhead taken out (same tiling, same LDS transpose, same results up to the order
+// in which the 8 waves' partial sums were formed — the K ranges of the waves are balanced differently):
+//   * every load is a buffer load: per-lane byte offset fixed before the loop, the running block offset is wave-uniform and
+//     lives in an SGPR — one instruction per load.  k_nl_fwd2 formed `pointer + 64-bit index` per load (5-6 instructions
+//     each, ~50 per 32-wide block: as many issue cycles as the block's 16 MFMAs);
+//   * a wave's K range is a whole number of 32-wide blocks, balanced 12/13 over the 8 waves (fwd2: 13,...,13,7), and the
+//     loop runs floor(n / RING) full ring rounds without any masking plus a tail that only computes — fwd2 padded every
+//     wave to a multiple of RING blocks (16 slots for 12.25 blocks of work: 31 % dead MFMAs and loads, zeroed by a mask
+//     multiply on every weight).
+template <int MT>
+__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) {
+  __shared__ float s_red[RB_NL_FWD_WAVES][4 * MT][64];
+  __shared__ __attribute__((aligned(16))) float s_ein[RB_FWD2_KMAX];
+  __shared__ __attribute__((aligned(16))) float s_wt[RB_NL_FWD_WAVES][16 * RB_FWD2_WT_LD];
+  const int lane = rb_lane(), wave = rb_wave();
+  const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
+  const int M = a.m_cnt[net];
+  const int m0 = mc * (16 * MT);
+  if (m0 >= M) return;                                   // block-uniform
+  const int g = (a.n_groups > 1 && (int)blockIdx.x >= a.grp[1].tile_begin) ? 1 : 0;
+  const NlRowGroup grp = a.grp[g];
+  const int row0 = grp.row_begin + ((int)blockIdx.x - grp.tile_begin) * 16;
+  const int row_end = grp.row_begin + grp.row_cnt;
+  const NlWeights w = a.w[net];
+  const int K = a.K;
+  const int nblk = K / 32;                               // host guarantees K % 32 == 0
+  const int base_n = nblk / RB_NL_FWD_WAVES, extra = nblk % RB_NL_FWD_WAVES;
+  const int nsc = rb_wave_uniform(base_n + (wave < extra ? 1 : 0));                     // 32-wide blocks of this wave
+  const int b0 = rb_wave_uniform(wave * base_n + (wave < extra ? wave : extra));       // its first block
+
+  const int r = lane & 15, q = lane >> 4;
+  const int lr = lane >> 3, lk = lane & 7;               // line-wide weight loads: 8 rows x 128 B per instruction
+  const rb_buf bmu = rb_make_buf(w.mu), bsg = rb_make_buf(w.sigma), bx = rb_make_buf(a.x);
+  unsigned wo[2];
+  float eo2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = row0 + 8 * i + lr;
+    if (row > row_end - 1) row = row_end - 1;
+    wo[i] = (unsigned)(((int64_t)row * K + 4 * lk) * 4);
+    eo2[i] = w.eout[row];
+  }
+  float* wt = &s_wt[wave][0];                             // [16 rows][RB_FWD2_WT_LD]
+  unsigned xo[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = m0 + 16 * mt + r;
+    if (m > M - 1) m = M - 1;
+    xo[mt] = (unsigned)((((int64_t)(grp.x_off >> 4) * a.rows_total + a.m_base[net] + m) * 16 + 4 * q) * 4);
+  }
+  const unsigned xstep = (unsigned)a.rows_total * 64u;     // bytes between consecutive 16-wide k chunks of the activations
+
+  rb_f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[mt][e] = 0.0f;
+
+  constexpr int RING = MT >= 4 ? 3 : 4;
+  float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][MT];
+  const int b_last = b0 + (nsc > 0 ? nsc - 1 : 0);
+  auto blk_of = [&](int sc) { const int b = b0 + sc; return b < b_last ? b : b_last; };   // wave-uniform, clamped
+  {
+    const float* ein_g = w.ein + grp.ein_off;
+    for (int k4 = (int)threadIdx.x; k4 < (K >> 2); k4 += 64 * RB_NL_FWD_WAVES)
+      *reinterpret_cast<float4*>(&s_ein[4 * k4]) = rb_ld4(ein_g + 4 * k4);
+  }
+  auto load_w = [&](int d, int b) {
+    const unsigned so = (unsigned)b * 128u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      r_mu[d][i] = rb_ld4_buf(bmu, wo[i], so);
+      r_sg[d][i] = rb_ld4_buf(bsg, wo[i], so);
+    }
+  };
+  auto load_x = [&](int d, int b) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned so = (unsigned)(2 * b + h) * xstep;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4_buf(bx, xo[mt], so);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < RING; ++d) { load_w(d, blk_of(d)); load_x(d, blk_of(d)); }
+  __syncthreads();                                       // eps_in visible
+  auto compute = [&](int d, int b) {
+    const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[b * 32 + 4 * lk]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(&wt[(8 * i + lr) * RB_FWD2_WT_LD + 4 * lk]) = rb_noisy4(r_mu[d][i], r_sg[d][i], eo2[i], e4);
+  };
+  auto mfmas = [&](int d) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 w4 = *reinterpret_cast<const float4*>(&wt[r * RB_FWD2_WT_LD + 16 * h + 4 * q]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4.x, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4.y, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4.z, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4.w, acc[mt]);
+    }
+  };
+  const int full = nsc / RING * RING;
+  for (int sc0 = 0; sc0 < full; sc0 += RING) {
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+      const int sc = sc0 + d;
+      compute(d, b0 + sc);
+      load_w(d, blk_of(sc + RING));                      // refill the weight half of this ring slot
+      rb_wave_sync();                                    // the tile is private to the wave: LDS executes its ops in order
+      mfmas(d);
+      load_x(d, blk_of(sc + RING));                      // ... and its activation half, once the MFMAs have read it
+      rb_wave_sync();                                    // tile reads done before the next block overwrites it
+      RB_SCHED_FENCE();                                  // keep this slot's refill here, not at the end of the loop
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < RING; ++d) {                       // tail: the blocks the last refills brought in, no more loads
+    if (full + d < nsc) {                                // wave-uniform
+      compute(d, b0 + full + d);
+      rb_wave_sync();
+      mfmas(d);
+      rb_wave_sync();
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_red[wave][mt * 4 + e][lane] = acc[mt][e];
+  __syncthreads();
+  for (int idx = (int)threadIdx.x; idx < 4 * MT * 64; idx += 64 * RB_NL_FWD_WAVES) {
+    const int slot = idx >> 6, l = idx & 63;
+    float v = s_red[0][slot][l];
+#pragma unroll
+    for (int wv = 1; wv < RB_NL_FWD_WAVES; ++wv) v += s_red[wv][slot][l];
+    const int mt = slot >> 2, e = slot & 3;
+    const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
+    const int n = row0 + (l & 15);
+    if (m < M && m < m0 + 16 * MT && n < row_end) {
+      float o = v + (w.bmu[n] + w.bsigma[n] * w.eout[n]);                 // model.py:44
+      if (a.relu) o = fmaxf(o, 0.0f);
+      const int rowi = a.m_base[net] + m;
+      a.out[(int64_t)rowi * a.ld_out + n] = o;
+      if (a.out_blocked) a.out_blocked[((int64_t)(n >> 4) * a.rows_total + rowi) * 16 + (n & 15)] = o;
+    }
+  }
+}
+
 // ====================================================================== input gradient ==
 // dx[m][out_off + k] = sum_{n in rows} dy[m][n] * W[n][k]      (adjoint of the forward)
 struct NlDxProblem {

@@ -85,6 +85,37 @@ __device__ __forceinline__ void rb_st4_wt(float* base, unsigned byte_off, float4
 #endif
 }
 
+// 16-byte load through a buffer descriptor: address = base + per-lane byte offset (VGPR) + wave-uniform byte offset (SGPR).
+// ONE instruction and no address arithmetic in the loop — a streamed kernel whose loads are `pointer + 64-bit index` spends
+// 5-6 VALU/SALU instructions per load on the address alone.  Offsets are 32-bit: buffers up to 2 GB.
+struct rb_buf {
+#if defined(RB_HOST_INTERP)
+  const char* base;
+#else
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ rb_buf rb_make_buf(const void* base) {
+  rb_buf b;
+#if defined(RB_HOST_INTERP)
+  b.base = reinterpret_cast<const char*>(base);
+#else
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00027000);
+#endif
+  return b;
+}
+__device__ __forceinline__ float4 rb_ld4_buf(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
+#if defined(RB_HOST_INTERP)
+  return *reinterpret_cast<const float4*>(b.base + lane_off + uniform_off);
+#else
+  typedef unsigned int rb_v4u __attribute__((ext_vector_type(4)));
+  const rb_v4u t = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)lane_off, (int)uniform_off, 0);
+  float4 v;
+  v.x = __uint_as_float(t.x); v.y = __uint_as_float(t.y); v.z = __uint_as_float(t.z); v.w = __uint_as_float(t.w);
+  return v;
+#endif
+}
+
 __device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int rb_wave() { return (int)(threadIdx.x >> 6); }
 
