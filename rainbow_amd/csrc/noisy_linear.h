@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
 
   constexpr int RING = MT >= 4 ? 3 : 4;
   float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][MT];
-  const int b_last = b0 + (nsc > 0 ? nsc - 1 : 0);
+  const int b_last = nsc > 0 ? b0 + nsc - 1 : nblk - 1;  // (a wave without work still issues the ring's loads: keep them in range)
   auto blk_of = [&](int sc) { const int b = b0 + sc; return b < b_last ? b : b_last; };   // wave-uniform, clamped
   {
     const float* ein_g = w.ein + grp.ein_off;
