@@ -25,6 +25,16 @@
 #include <new>
 
 #if defined(RB_STAMP)
+__device__ long long g_span[64];
+extern "C" int rb_debug_spans(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * 64) != hipSuccess) return -2;
+  if (reset) {
+    long long init[64];
+    for (int i = 0; i < 64; ++i) init[i] = (i & 1) ? 0 : 0x7fffffffffffffffLL;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_span), init, sizeof(init)) != hipSuccess) return -2;
+  }
+  return 0;
+}
 __device__ long long g_cstamp[64];
 extern "C" int rb_debug_cstamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamp), sizeof(long long) * 64) == hipSuccess ? 0 : -2; }
 #endif

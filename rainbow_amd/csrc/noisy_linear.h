@@ -910,6 +910,15 @@ struct NlPriorityUpdate {
   int n;
   double omega;
 };
+#if defined(RB_STAMP)
+extern __device__ long long g_span[64];
+// [2 * slot] = earliest start, [2 * slot + 1] = latest end of the blocks that ran `slot` since the host last reset the array
+#define RB_SPAN_BEGIN(slot) do { if (threadIdx.x == 0) atomicMin((unsigned long long*)&g_span[2 * (slot)], (unsigned long long)wall_clock64()); } while (0)
+#define RB_SPAN_END(slot) do { __syncthreads(); if (threadIdx.x == 0) atomicMax((unsigned long long*)&g_span[2 * (slot) + 1], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define RB_SPAN_BEGIN(slot) ((void)0)
+#define RB_SPAN_END(slot) ((void)0)
+#endif
 __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g, NlPriorityUpdate up) {
   // ONE LDS buffer for whichever body this workgroup runs (separate static arrays would add up: 132 KB, one workgroup
   // per CU for the whole launch; 32 KB lets five share a CU)
@@ -917,19 +926,27 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
   __shared__ float lds[LDSW];
   // the write-back block goes FIRST: it is the launch's longest single-workgroup chain and must not queue behind the tiles
   int b = (int)blockIdx.x;
+  const int sb = dw.K > 1000 ? 3 : 0;                    // RB_STAMP builds: span slots of the hidden / output layer launch
+  (void)sb;
   if (up.enabled) {
     if (b == 0) {
+      RB_SPAN_BEGIN(sb + 0);
       rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // n <= 256
+      RB_SPAN_END(sb + 0);
       return;
     }
     b -= 1;
   }
   const int ndw = g.dw_x * g.dw_y;
   if (b < ndw) {
+    RB_SPAN_BEGIN(sb + 1);
     if (dw.ct > 0) rb_nl_dw_body_pipe(dw, b % g.dw_x, b / g.dw_x, 4 * b);
     else rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
+    RB_SPAN_END(sb + 1);
   } else {
     const int r = b - ndw;
+    RB_SPAN_BEGIN(sb + 2);
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
+    RB_SPAN_END(sb + 2);
   }
 }

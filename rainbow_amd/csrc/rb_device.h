@@ -116,6 +116,14 @@ __device__ __forceinline__ float4 rb_ld4_buf(const rb_buf& b, unsigned lane_off,
 #endif
 }
 
+__device__ __forceinline__ float rb_ld1_buf(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
+#if defined(RB_HOST_INTERP)
+  return *reinterpret_cast<const float*>(b.base + lane_off + uniform_off);
+#else
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, (int)lane_off, (int)uniform_off, 0));
+#endif
+}
+
 __device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int rb_wave() { return (int)(threadIdx.x >> 6); }
 
