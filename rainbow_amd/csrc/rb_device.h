@@ -91,6 +91,7 @@ __device__ __forceinline__ void rb_st4_wt(float* base, unsigned byte_off, float4
 struct rb_buf {
 #if defined(RB_HOST_INTERP)
   const char* base;
+  size_t nbytes;
 #else
   __amdgpu_buffer_rsrc_t r;
 #endif
@@ -99,13 +100,27 @@ __device__ __forceinline__ rb_buf rb_make_buf(const void* base) {
   rb_buf b;
 #if defined(RB_HOST_INTERP)
   b.base = reinterpret_cast<const char*>(base);
+  b.nbytes = (size_t)0x7fffffff;
 #else
   b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00027000);
 #endif
   return b;
 }
+// ... with hardware range checking: a load whose byte range leaves [0, nbytes) returns zeros instead of faulting, so clamped
+// "tail" addresses need no per-lane min() (the host interpreter checks the same bound).
+__device__ __forceinline__ rb_buf rb_make_buf_n(const void* base, size_t nbytes) {
+  rb_buf b;
+#if defined(RB_HOST_INTERP)
+  b.base = reinterpret_cast<const char*>(base);
+  b.nbytes = nbytes;
+#else
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(nbytes > 0x7fffffffu ? 0x7fffffffu : nbytes), 0x00027000);
+#endif
+  return b;
+}
 __device__ __forceinline__ float4 rb_ld4_buf(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
 #if defined(RB_HOST_INTERP)
+  if ((size_t)lane_off + uniform_off + 16 > b.nbytes) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   return *reinterpret_cast<const float4*>(b.base + lane_off + uniform_off);
 #else
   typedef unsigned int rb_v4u __attribute__((ext_vector_type(4)));
@@ -118,6 +133,7 @@ __device__ __forceinline__ float4 rb_ld4_buf(const rb_buf& b, unsigned lane_off,
 
 __device__ __forceinline__ float rb_ld1_buf(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
 #if defined(RB_HOST_INTERP)
+  if ((size_t)lane_off + uniform_off + 4 > b.nbytes) return 0.0f;
   return *reinterpret_cast<const float*>(b.base + lane_off + uniform_off);
 #else
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, (int)lane_off, (int)uniform_off, 0));
