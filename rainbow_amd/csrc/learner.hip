@@ -224,9 +224,16 @@ __global__ __launch_bounds__(256) void k_block_copy(const float* x, int rows, in
 __global__ __launch_bounds__(256) void k_dfeat_finish(const float* part, int splits, int64_t total, const float* feat,
                                                        float* dfeat) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float fv = feat[i];
     float acc = 0.0f;
-    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * total + i];
-    dfeat[i] = feat[i] > 0.0f ? acc : 0.0f;
+    for (int s0 = 0; s0 < splits; s0 += 8) {             // 8 partial loads in flight (a runtime-length loop of load-then-add
+      float v[8];                                        // made every split its own dependent round trip)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(s0 + u < splits ? s0 + u : splits - 1) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (s0 + u < splits) ? v[u] : 0.0f;
+    }
+    dfeat[i] = fv > 0.0f ? acc : 0.0f;
   }
 }
 
@@ -267,9 +274,24 @@ __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const ReduceLayer L = a.layer[li];
   const int64_t j = i - L.begin;
   const int64_t per = (int64_t)L.cout * (L.K + 1);
+  // fixed add order, but 32 slice loads in flight at a time: with `#pragma unroll 8` the compiler waited for each group of
+  // 8 before it requested the next, i.e. 12 dependent round trips for the first layer's 96 slices (the kernel's 6.6 us)
   float acc = 0.0f;
-#pragma unroll 8
-  for (int s = 0; s < L.slices; ++s) acc += L.part[(int64_t)s * per + j];   // independent loads, fixed add order
+  int s = 0;
+  for (; s + 32 <= L.slices; s += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = L.part[(int64_t)(s + u) * per + j];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc += v[u];
+  }
+  {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = L.part[(int64_t)(s + u < L.slices ? s + u : L.slices - 1) * per + j];   // clamped: always legal
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc += (s + u < L.slices) ? v[u] : 0.0f;
+  }
   const int co = (int)(j / (L.K + 1)), col = (int)(j % (L.K + 1));
   if (col < L.K) L.gw[(int64_t)co * L.K + col] = acc;
   else L.gb[co] = acc;
