@@ -290,6 +290,12 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg_dev, fl
 #define RB_LEARNER_WRITE_FUSED_GRADS 2
 int rb_learner_set_flags(rb_learner_t* l, int32_t flags);
 
+/* hipGraph replay with the fused optimiser pass: a captured launch cannot take a new `step` by value.  With a counter set
+ * (caller-owned i64 on the device), every rb_learner_learn* increments it on the device, and rb_learner_clip_adam called
+ * with step = 0 reads the step number from it and forms the bias corrections 1 - beta^t in the kernel (double, one thread
+ * per block).  NULL clears.                                                                                           */
+int rb_learner_set_step_counter(rb_learner_t* l, int64_t* step_dev);
+
 /* Fused priority write-back (agent.py:100 -> memory.py:157-159).  With a sink set, rb_learner_learn*
  * itself applies  sum_tree[tree_idx] = loss^w  (+ ancestor sums, max) to `replay` as one extra
  * workgroup of its backward launch, i.e. off the step's critical path.  tree_idx_dev must be the

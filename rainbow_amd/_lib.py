@@ -91,6 +91,7 @@ SIGNATURES = {
     "rb_learner_clip_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                      c_int64, c_void_p, c_void_p]),
     "rb_learner_set_flags": (c_int, [c_void_p, c_int32]),
+    "rb_learner_set_step_counter": (c_int, [c_void_p, c_void_p]),
     "rb_learner_set_priority_sink": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rb_learner_priority_written": (c_int, [c_void_p]),
     "rb_learner_grads_modified": (c_int, [c_void_p]),

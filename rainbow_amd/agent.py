@@ -69,9 +69,12 @@ class _FlatAdam(torch.optim.Adam):
         st = self.state[g["params"][0]]
         st["step"] += 1
         b1, b2 = g["betas"]
+        # device-resident step counter (hipGraph replay): step = 0 tells the kernel to read it and form the bias
+        # corrections itself; the host copy above only mirrors it (Agent._sync_step refreshes it after replays)
+        step = 0 if ag._step_dev is not None else int(st["step"].item())
         L.check(ag._lib, ag._lib.rb_learner_clip_adam(
             ag._h, float(max_norm), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1),
-            float(b2), float(g["eps"]), int(st["step"].item()),
+            float(b2), float(g["eps"]), step,
             ag._norm.data_ptr() if math.isfinite(max_norm) else None, ag._stream()))
         return loss
 
@@ -131,18 +134,23 @@ class Agent:
 
         self.params.requires_grad_(True)
         self.params.grad = self.grads
-        # hipGraph replay of the whole step is opt-in (RAINBOW_AMD_GRAPH=1): measured within 2 % of eager on MI355X
-        # (the step is GPU-bound, profiles/round1_launch_ab.txt) while capturable Adam costs one extra kernel per step.
+        # hipGraph replay of the whole step is opt-in (RAINBOW_AMD_GRAPH=1).  The captured step runs the library's own
+        # one-pass clip + Adam too: the optimiser's step number is then a device-resident counter the learn call increments
+        # and the kernel reads (rb_learner_set_step_counter), since a by-value argument would freeze at capture time.
         self._use_graph = os.environ.get("RAINBOW_AMD_GRAPH", "0") == "1"
+        self._step_dev = None
         kw = dict(lr=args.learning_rate, eps=args.adam_eps)
-        if self._use_graph:
-            kw["capturable"] = True    # the step counter must live on the device to be replayable
-        if self._use_graph or os.environ.get("RAINBOW_AMD_FUSED_ADAM", "1") != "1":
+        if os.environ.get("RAINBOW_AMD_FUSED_ADAM", "1") != "1":     # A/B: k_clip_scale + PyTorch's fused Adam
+            if self._use_graph:
+                kw["capturable"] = True
             try:
                 self.optimiser = torch.optim.Adam([self.params], fused=True, **kw)
             except (TypeError, RuntimeError):
                 self.optimiser = torch.optim.Adam([self.params], **kw)
         else:
+            if self._use_graph:
+                self._step_dev = torch.zeros(1, dtype=torch.int64, device=d)
+                L.check(self._lib, self._lib.rb_learner_set_step_counter(self._h, self._step_dev.data_ptr()))
             self.optimiser = _FlatAdam(self, **kw)                   # agent.py:46
         self._graph = None
         self._graph_mem = None
@@ -345,6 +353,11 @@ class Agent:
                 return
             self._eager_steps += 1
         self._learn_eager(mem, _target_raw_normals, _unit_uniforms)
+
+    def _sync_step(self):
+        """Host mirror of the optimiser's step number after graph replays (state_dict / checkpoint read it)."""
+        if self._step_dev is not None and isinstance(self.optimiser, _FlatAdam):
+            self.optimiser.state[self.params]["step"].fill_(float(self._step_dev.item()))
 
     def _capture(self, mem):
         dev = self.device
@@ -554,6 +567,7 @@ class Agent:
         (main.py has no such thing: it restarts the optimiser).  Returns the dict; writes it with torch.save if `path`."""
         if not isinstance(self.optimiser, _FlatAdam):
             raise NotImplementedError("checkpoint() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1, no graph)")
+        self._sync_step()
         seed, epoch = C.c_uint64(0), C.c_uint64(0)
         L.check(self._lib, self._lib.rb_learner_get_rng(self._h, C.byref(seed), C.byref(epoch), self._stream()))
         st = self.optimiser.state[self.params]
@@ -580,6 +594,8 @@ class Agent:
             st["exp_avg"].copy_(ck["exp_avg"])
             st["exp_avg_sq"].copy_(ck["exp_avg_sq"])
             st["step"].fill_(ck["adam_step"])
+            if self._step_dev is not None:
+                self._step_dev.fill_(int(ck["adam_step"]))
         L.check(self._lib, self._lib.rb_learner_set_rng(self._h, int(ck["rng_seed"]), int(ck["rng_epoch"]), self._stream()))
         self._noise_pending = bool(ck["noise_pending"])
         self.training = bool(ck["training"])

@@ -178,6 +178,7 @@ struct rb_learner {
   int64_t fact_stride;
   hipEvent_t ev_fact;       // recorded when fact_local is complete (the all-gather may start under the rest of the backward)
   int exch_pending;         // a learn call left its FC weight gradients to rb_learner_finish_grads
+  long long* step_ctr;      // optional device-resident optimiser step counter (rb_learner_set_step_counter)
   int flags;                // RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS (rb_learner_set_flags)
   int dw_deferred;          // the last learn call computed the hidden layer's weight gradient for its norm only: the
                             // optimiser pass (rb_learner_clip_adam) recomputes the tiles while it streams the parameters
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
                                                const float* returns, const float* nonterminals, const float* weights,
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
-                                               int32_t* a_star_out, float* loss_out, float* dlogits) {
+                                               int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr) {
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
   __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
       if (s_ev[a] > best) { best = s_ev[a]; a_star = a; }         // argmax, first maximum
   }
   if (t == 0) a_star_out[b] = a_star;
+  if (step_ctr && b == 0 && t == 0) *step_ctr = *step_ctr + 1;      // this learn call's optimiser step number (1-based)
 
   if (wave == 0) {
     // ---------------- target(next_states)[a*] probabilities      agent.py:75-76, projection inputs agent.py:79-86
@@ -619,6 +621,11 @@ struct ClipAdamArgs {
   const float* part; int nparts;
   float max_norm; float* norm_out;
   float w1, b2, w2, neg_step_size, bc2_sqrt, eps;
+  // hipGraph replay: the step number lives on the device (rb_learner_set_step_counter; incremented by the head kernel of
+  // every learn call), and the bias corrections 1 - beta^t are formed here, in double like the host path, by one thread
+  // per block — by-value scalars would freeze at capture time
+  const long long* step_dev;
+  double lr, beta1, beta2;
   // FUSED: elements [skip_lo, skip_lo + skip_len) (the hidden layer's mu | sigma weight arrays) are not touched by the
   // elementwise part: the tile part below updates them from gradients it recomputes on the fly
   int64_t skip_lo4, skip_len4;        // in float4 units
@@ -759,6 +766,17 @@ __global__ __launch_bounds__(256, RB_ADAM_MINWAVES) void k_clip_adam(ClipAdamArg
   float coef = a.max_norm / (total + 1e-6f);
   if (coef > 1.0f) coef = 1.0f;                                    // clamp(max=1.0)
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) *a.norm_out = total;
+  if (a.step_dev) {                                                // block-uniform
+    if (threadIdx.x == 0) {
+      const double t = (double)*a.step_dev;
+      const double bc1 = 1.0 - pow(a.beta1, t), bc2 = 1.0 - pow(a.beta2, t);
+      s_red[0] = (float)(-(a.lr / bc1));
+      s_red[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    a.neg_step_size = s_red[0];
+    a.bc2_sqrt = s_red[1];
+  }
   if (tile_block) {
     rb_fused_dw_adam_tile<WT>(a, f, (int)blockIdx.x, coef);
     return;
@@ -1538,7 +1556,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head, dim3((unsigned)B), dim3(RB_HEAD_THREADS), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits);
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
@@ -1757,7 +1775,8 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
                          double beta2, double eps, int64_t step, float* norm_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_clip_adam: NULL handle");
   RB_REQUIRE(exp_avg != nullptr && exp_avg_sq != nullptr, "rb_learner_clip_adam: NULL moment buffer");
-  RB_REQUIRE(step >= 1, "rb_learner_clip_adam: step is 1-based");
+  RB_REQUIRE(step >= 1 || (step == 0 && l->step_ctr), "rb_learner_clip_adam: step is 1-based (0 = take it from the device counter set "
+             "with rb_learner_set_step_counter)");
   const int64_t n = l->L.n_params;
   int nparts = l->norm_slots;
   if (!(max_norm < INFINITY) && norm_dev == nullptr) {
@@ -1776,6 +1795,7 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
   a.neg_step_size = (float)(-(lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)eps;
+  a.step_dev = step == 0 ? l->step_ctr : nullptr; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
   const int64_t n4 = n >> 2;
   // 4 quadruples per thread: measured best of {2, 4, 8} on MI355X (254.3 / 255.6 / 256.6 us per step)
   // write-through stores: same-box A/B 253.7 -> 250.8 us per step (RB_ADAM_WT=0 restores plain stores)
@@ -1803,6 +1823,12 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
     else { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false, false>), dim3(grid), dim3(256), stream, a, f); }
   }
   RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_learner_set_step_counter(rb_learner_t* l, int64_t* step_dev) {
+  RB_REQUIRE(l != nullptr, "rb_learner_set_step_counter: NULL handle");
+  l->step_ctr = reinterpret_cast<long long*>(step_dev);
   return RB_OK;
 }
 

@@ -199,6 +199,7 @@ class CAbiLearnAdapter:
     """Drives rb_learner_* exactly like rainbow_amd.agent.Agent does: learn -> fused clip+Adam (default), or
     learn -> clip -> torch Adam (fused_adam = False: the hipGraph path of the Agent and the pre-fusion behaviour)."""
     fused_adam = True
+    step_from_device = False   # pass step = 0: the kernel reads the step number from rb_learner_set_step_counter's counter
     learner_flags = 0          # rainbow_amd._lib.LEARNER_* (set on the class or instance BEFORE load())
 
     def __init__(self, lib, mem, name):
@@ -294,7 +295,8 @@ class CAbiLearnAdapter:
             self.adam_t += 1
             L.check(self.lib, self.lib.rb_learner_clip_adam(self.h, self.hy["norm_clip"], m.ptr(self.adam_m),
                                                             m.ptr(self.adam_v), self.hy["lr"], 0.9, 0.999,
-                                                            self.hy["adam_eps"], self.adam_t, m.ptr(norm), m.stream))
+                                                            self.hy["adam_eps"], 0 if self.step_from_device else self.adam_t,
+                                                            m.ptr(norm), m.stream))
             m.sync()
             grads = self._unflat(m.download(self.grads))
         else:

@@ -64,6 +64,27 @@ def test_fused_weight_gradient_in_optimiser_pass_matches_golden(emu, name):
             assert np.array_equal(np.asarray(traces[0][k]), np.asarray(traces[1][k])), k
 
 
+def test_device_step_counter_equals_host_step(emu):
+    """rb_learner_clip_adam with step = 0 (step number read from the device counter the learn call increments, bias
+    corrections formed in the kernel — the hipGraph path) against the by-value step: bit-identical parameters."""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    name = "atoms21"
+    runs = []
+    for device_step in (False, True):
+        ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+        if device_step:
+            ctr = np.zeros(1, dtype=np.int64)
+            L.check(emu, emu.rb_learner_set_step_counter(ad.h, ctr.ctypes.data))
+            ad.step_from_device = True
+        runs.append(scenarios.learn_scenario(ad, name, O))
+        if device_step:
+            assert int(ctr[0]) == scenarios.LEARN_STEPS
+        ad.close()
+    for k in runs[0]:
+        assert np.array_equal(np.asarray(runs[0][k]), np.asarray(runs[1][k])), k
+
+
 def test_unit_conversion_is_exact():
     """rb_unit's multiply + Newton step equals the correctly rounded x/255 for every byte (memory.py:137)."""
     x = np.arange(256, dtype=np.float32)
