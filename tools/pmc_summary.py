@@ -25,8 +25,8 @@ def tag_of(name, grid, biggest):
     """bench.py tag of a kernel instance; the hidden layer's launches are the larger grid of k_nl_fwd2 / k_nl_bwd."""
     if "k_clip_adam" in name:
         return "clip_adam"
-    if "k_nl_fwd2" in name:
-        return "fc_h_fwd" if grid == biggest["k_nl_fwd2"] else "fc_z_fwd"
+    if "k_nl_fwd" in name:
+        return "fc_h_fwd" if grid == biggest["k_nl_fwd"] else "fc_z_fwd"
     if "k_nl_bwd" in name:
         return "fc_h_bwd" if grid == biggest["k_nl_bwd"] else "fc_z_bwd"
     if "k_conv_dw_all" in name:
@@ -46,7 +46,7 @@ def main():
     write = load(sys.argv[2], "WRITE_SIZE")
     biggest = {}
     for (name, grid) in fetch:
-        for k in ("k_nl_fwd2", "k_nl_bwd"):
+        for k in ("k_nl_fwd", "k_nl_bwd"):
             if k in name:
                 biggest[k] = max(biggest.get(k, 0), grid)
     res = {}
