@@ -474,7 +474,7 @@ struct ConvDwLdsSize {
   static constexpr int PR = (RC - 1) * G::S + G::KS;  // input rows per chunk
   static constexpr int PLANE = PR * G::IH;
   static constexpr int CMAX = KMAX / G::KK;
-  static constexpr int FLOATS = PCP * 33 + CMAX * PLANE + PCP;   // dY^T, patch, position offsets
+  static constexpr int FLOATS = PCP * 33 + CMAX * PLANE + PCP + 32;   // dY^T, patch, position offsets, per-image bias sums
 };
 
 // body with explicit block coordinates and caller-provided LDS, so several layers can share one launch.
@@ -490,6 +490,7 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
   float* s_a = smem;                                  // dY^T: [pos][co]
   float* s_patch = smem + PCP * 33;
   int* s_poff = reinterpret_cast<int*>(smem + PCP * 33 + SZ::CMAX * PLANE);
+  float* s_bias = smem + PCP * 33 + SZ::CMAX * PLANE + PCP;
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int co0 = cotile * 32;
@@ -572,11 +573,18 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
     }
     __syncthreads();
 
-    // bias column: sum over the chunk's positions, fixed order (then over the images, ascending)
-    if (t < 32 && co0 + t < a.cout) {
+    // bias column: sum over the chunk's positions in a fixed order (then over the images, ascending).  Eight lanes per
+    // channel take every eighth position and meet through shuffles (lane = 8 * channel-in-wave + part): one thread per
+    // channel walking up to 140 dependent LDS reads (~3.7 us) made wave 0 the last wave of every workgroup to finish.
+    {
+      const int part = lane & 7, ch = (wave << 3) + (lane >> 3);          // 8 waves x 8 channels = 64 slots >= 32 channels
       float sum = 0.0f;
-      for (int p = 0; p < npos; ++p) sum += s_a[p * 33 + t];
-      bias_acc += sum;
+      if (ch < 32)
+        for (int p = part; p < npos; p += 8) sum += s_a[p * 33 + ch];
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      if (part == 0 && ch < 32 && co0 + ch < a.cout) s_bias[ch] = sum;
     }
     int pofs[PCP / 2];                                  // position offsets of the whole chunk, read once (not per step)
 #pragma unroll
@@ -594,6 +602,8 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
           acc[j] = rb_mfma32(s_a[(2 * jj + kh) * 33 + nl], s_patch[koff + pofs[jj]], acc[j]);
       }
     }
+    __syncthreads();                                    // s_bias of this image is complete (and its operands are done with)
+    if (t < 32 && co0 + t < a.cout) bias_acc += s_bias[t];
   }
 
   float* out = a.part + (((int64_t)grp * nchunks + chunk) * a.cout) * (K + 1);
