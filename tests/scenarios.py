@@ -191,7 +191,7 @@ def summarize(a):
     return a[::stride].copy()
 
 
-def learn_scenario(backend, name, oracle_mod):
+def learn_scenario(backend, name, oracle_mod, steps=None):
     """backend protocol:
          load(online_params, target_params)            # {state-dict name: f32 array}
          reset_noise_online(raw_normals f32[D])
@@ -208,7 +208,7 @@ def learn_scenario(backend, name, oracle_mod):
     draws = oracle_mod.noise_draw_count(cfg)
     trace = {}
     full = LEARN_FULL_RECORD.get(name)
-    for k in range(LEARN_STEPS_BY.get(name, LEARN_STEPS)):
+    for k in range(steps if steps is not None else LEARN_STEPS_BY.get(name, LEARN_STEPS)):
         rs = np.random.RandomState(seed0 + 10 + k)
         backend.reset_noise_online(rs.randn(draws).astype(np.float32))
         batch = make_batch(c, seed0 + 20 + k)
@@ -222,6 +222,8 @@ def learn_scenario(backend, name, oracle_mod):
             trace["s%d_gradnorm/%s" % (k, pname)] = np.float32(np.sqrt(np.sum(np.asarray(g, dtype=np.float64) ** 2)))
         for pname, p in backend.params().items():
             trace["s%d_param/%s" % (k, pname)] = summarize(p)
+    if steps is not None:          # shortened run (a test that only needs the first steps): no acting epilogue
+        return trace
     st = synth_state(np.random.RandomState(seed0 + 99), c["history"], 0)
     a_noisy, q_noisy = backend.act(st, True)
     a_eval, q_eval = backend.act(st, False)
