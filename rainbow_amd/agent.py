@@ -312,6 +312,10 @@ class Agent:
         n = int(st.shape[0])
         out = np.empty(n, dtype=np.float32)
         chunk = max(1, min(int(chunk), 4096))
+        if min(n, chunk) > 3 * self.batch_size and self._graph is not None:
+            # the library regrows its forward buffers for more than 3*batch rows: a captured learn step holds the old
+            # addresses, so it is dropped and re-captured after the next warm-up
+            self._graph, self._graph_mem, self._eager_steps = None, None, 0
         if self._q_pin.numel() < min(n, chunk):
             self._act_pin = torch.zeros(min(n, chunk), dtype=torch.int32).pin_memory()
             self._q_pin = torch.zeros(min(n, chunk), dtype=torch.float32).pin_memory()
