@@ -33,8 +33,6 @@ struct ConvLdsFwdArgs {
   float* out;                // [img][cout][P]
   float* out_blocked;        // optional second copy of the flattened output in the k-blocked layout of noisy_linear.h
   int rows_total;            //   ... with this many rows (images)
-  int rot;                   // WREG: rotate the wave -> K-slice assignment by the image index (experiment: every workgroup
-                             // otherwise requests the same weight lines at the same moment)
 };
 
 // ---- shared staging helpers ------------------------------------------------------------------
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
     const int ml_ = lane & 31, kh_ = lane >> 5;
     const int rows_valid = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
     const float* wrow = a.w[net] + (int64_t)(cout0 + (ml_ < rows_valid ? ml_ : 0)) * K;
-    const int k0 = (a.rot ? ((wave + img) & (RB_CONV_WAVES - 1)) : wave) * KW + kh_ * HW;
+    const int k0 = wave * KW + kh_ * HW;
     if ((K & 3) == 0) {
 #pragma unroll
       for (int j4 = 0; j4 < HW / 4; ++j4) {
@@ -243,7 +241,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   RB_CSTAMP(SB + 1);
 
   // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW) of the padded reduction (weights beyond K are zero)
-  const int kb = ((WREG && a.rot) ? ((wave + img) & (RB_CONV_WAVES - 1)) : wave) * KW;
+  const int kb = wave * KW;
   int noff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {

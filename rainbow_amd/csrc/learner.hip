@@ -851,8 +851,6 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
-  static const int rot = getenv("RB_CONV_ROT") ? atoi(getenv("RB_CONV_ROT")) : 0;   // A/B switch
-  a.rot = rot;
   static const char* const tags[3] = {"conv1_fwd:k_conv_fwd_lds", "conv2_fwd:k_conv_fwd_lds", "conv3_fwd:k_conv_fwd_lds"};
   RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG>),
               dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
