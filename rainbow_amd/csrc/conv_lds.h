@@ -491,6 +491,12 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
   float* s_bias = smem + PCP * 33 + SZ::CMAX * PLANE + PCP;
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int SBW = 24 + (G::KS == 8 || (G::KS == 5 && G::IH == 84) ? 0 : G::KS == 4 || G::KS == 5 ? 8 : 16);   // RB_STAMP slots
+  const bool stamp_me = chunk == 0 && cotile == 0 && grp == 0 && t == 0;
+  (void)stamp_me;
+#if defined(RB_STAMP)
+  if (stamp_me) g_cstamp[SBW + 0] = wall_clock64();
+#endif
   const int co0 = cotile * 32;
   const int cin = a.cin, K = cin * G::KK;
   const int oy0 = chunk * RC;
@@ -570,6 +576,9 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
       }
     }
     __syncthreads();
+#if defined(RB_STAMP)
+    if (stamp_me && ii == 0) g_cstamp[SBW + 1] = wall_clock64();
+#endif
 
     // bias column: sum over the chunk's positions in a fixed order (then over the images, ascending).  Eight lanes per
     // channel take every eighth position and meet through shuffles (lane = 8 * channel-in-wave + part): one thread per
@@ -602,6 +611,9 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
     }
     __syncthreads();                                    // s_bias of this image is complete (and its operands are done with)
     if (t < 32 && co0 + t < a.cout) bias_acc += s_bias[t];
+#if defined(RB_STAMP)
+    if (stamp_me && ii == 0) g_cstamp[SBW + 2] = wall_clock64();
+#endif
   }
 
   float* out = a.part + (((int64_t)grp * nchunks + chunk) * a.cout) * (K + 1);
@@ -618,6 +630,9 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
       }
     }
   }
+#if defined(RB_STAMP)
+  if (stamp_me) g_cstamp[SBW + 3] = wall_clock64();
+#endif
 }
 
 template <class G, int RC, int KMAX, bool FIRST>

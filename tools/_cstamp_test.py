@@ -22,6 +22,9 @@ for it in range(80):
     lib.rb_debug_cstamps(st)
     acc.append(list(st))
 a = np.array(acc[20:], dtype=np.float64) * 0.01
+for name, sb in (("dw conv1", 24), ("dw conv2", 32), ("dw conv3", 40)):
+    m = np.median(a, axis=0)
+    print("%s block0: staged +%.2f  mfma(+bias) +%.2f  store +%.2f" % (name, m[sb+1]-m[sb], m[sb+2]-m[sb+1], m[sb+3]-m[sb+2]))
 for name, sb in (("conv1", 0), ("conv2", 8), ("conv3", 16)):
     m = np.median(a, axis=0)
     print("%s block0: staged +%.2f  mfma +%.2f  epilogue +%.2f | last block starts +%.2f ends +%.2f (us after block 0 start)" % (
