@@ -2,14 +2,17 @@
 // C51 projection, importance-weighted cross-entropy and the full backward, as hand-written
 // HIP over flat float32 parameter / gradient / noise buffers borrowed from the caller.
 //
-// Reference being replaced: model.py (NoisyLinear, DQN) and agent.py:61-97.  The reference
-// issues ~1750 framework ops per learn(); here the step is a fixed chain of launches:
-//   conv fwd x L  ->  fc_h (split-K) -> finish -> fc_z -> head (dueling + softmax + double-Q
-//   + projection + loss + dlogits, one workgroup per sample, atom bins in LDS)
-//   -> fc_z dW/dX -> fc_h dW/dX -> finish -> conv dW/dX x L -> partial reduce -> norm/clip.
-// All contractions run on v_mfma_f32_32x32x2_f32 through gemm_core.h (exact f32: parity with
-// the float32 reference is the contract); everything else is fused into their operand
-// gathers / epilogues (learner_problems.h).
+// Reference being replaced: model.py (NoisyLinear, DQN) and agent.py:61-98.  The reference
+// issues ~1750 framework ops per learn(); here the step is a fixed chain of 14 launches after the sampler
+// (DESIGN.md §3 has the table with what bounds each):
+//   conv fwd x L (conv_lds.h: operands in LDS, 8 waves split K)
+//   -> fc_h, fc_z forward (noisy_linear.h k_nl_fwd3: weights streamed once, whole K per block, no partials)
+//   -> head (dueling + softmaxes + double-Q + projection + loss + dlogits, one workgroup per sample, atom bins in LDS)
+//   -> fc_z backward (dW || dX in one launch) -> fc_h backward (dW || dX || the sum-tree priority write-back)
+//   -> dfeat finish -> conv dX x (L-1) -> every conv dW in one launch -> slice reduction
+//   -> clip + Adam in one pass (norm from per-producer partials; optional fused fc_h weight gradient).
+// All contractions run on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact f32: parity with the float32 reference
+// is the contract).  gemm_core.h + learner_problems.h remain the generic fallback for shapes the fast kernels refuse.
 #include "conv_lds.h"
 #include "noise_body.h"
 #include "learner_problems.h"
