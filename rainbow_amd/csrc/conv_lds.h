@@ -319,9 +319,15 @@ struct ConvLdsDxArgs {
   const float* dy;       // [B][cout][P]
   const float* x_act;    // [NI][cin][IP] (rows [0,B))
   float* dx;             // [B][cin][IP]
+  // LAZY instantiation only (the last conv layer): dY is not materialised — the staging sums the hidden layer's
+  // dy_splits (<= 4) row-split partials [s][B][cout * P] and applies relu'(dy_mask) itself
+  const float* dy_part;
+  const float* dy_mask;  // the layer's own activation, rows [0,B)
+  int64_t dy_stride;     // floats between partials
+  int dy_splits;
 };
 
-template <class G, int NT, int COUT>
+template <class G, int NT, int COUT, bool LAZY = false>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a) {
   constexpr int TMAX = (G::KS + G::S - 1) / G::S;           // taps per dimension of a phase
   constexpr int KMAX = COUT * TMAX * TMAX;
@@ -353,7 +359,42 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   if (n0 >= npos) return;                                            // block-uniform
 
   // ---- stage the (haloed) dY image, the phase's weight slab transposed to [k'][c], the tap table
-  {
+  if constexpr (LAZY) {
+    // interior cells: the mask and every partial of a thread's cells are requested before the first add (one round trip)
+    constexpr int IT = (COUT * G::P + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
+    const int ni = a.cout * G::P;
+    const float* mk = a.dy_mask + (int64_t)img * ni;
+    const float* pp = a.dy_part + (int64_t)img * ni;
+    float mv[IT], pv[IT][4];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = t + i * RB_CONV_THREADS;
+      const int ec = e < ni ? e : ni - 1;
+      mv[i] = mk[ec];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) pv[i][sp] = pp[(int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride + ec];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = t + i * RB_CONV_THREADS;
+      if (e < ni) {
+        const int co = e / G::P, r = e - co * G::P;
+        const int y = r / G::OH, x = r - y * G::OH;
+        float acc = 0.0f;                                                 // k_dfeat_finish's order: ((0 + p0) + p1) + ...
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) acc += sp < a.dy_splits ? pv[i][sp] : 0.0f;
+        s_dy[co * PP + (y + PAD) * PW + x + PAD] = mv[i] > 0.0f ? acc : 0.0f;
+      }
+    }
+    if (PW > G::OH) {
+      const int n = a.cout * PP;
+      for (int e = t; e < n; e += RB_CONV_THREADS) {
+        const int r = e % PP;
+        const int y = r / PW - PAD, x = r % PW - PAD;
+        if (!(y >= 0 && y < G::OH && x >= 0 && x < G::OH)) s_dy[e] = 0.0f;
+      }
+    }
+  } else {
     const float* src = a.dy + (int64_t)img * a.cout * G::P;
     const int n = a.cout * PP;
     for (int e0 = 0; e0 < n; e0 += 16 * RB_CONV_THREADS) {             // 16 loads in flight per thread
@@ -463,6 +504,11 @@ struct ConvLdsDwArgs {
   ImgSrc src;              // FIRST: the state stacks (images [0,B))
   const float* x_f;        // else previous activation [NI][cin][IP], rows [0,B)
   float* part;             // [B * chunks][cout][K+1]
+  // dy_splits > 0 (last conv layer): dY = relu'(dy_mask) * sum of dy_splits (<= 4) partials, formed while staging
+  const float* dy_part;
+  const float* dy_mask;
+  int64_t dy_stride;
+  int dy_splits;
 };
 
 template <class G, int RC, int KMAX>
@@ -524,12 +570,50 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
     const int img = grp * ipb + ii;
     if (img >= batch) break;                          // block-uniform
     if (ii > 0) __syncthreads();                      // the previous image's operands are no longer being read
-    // ---- stage dY^T (zero beyond the chunk) and the input patch of this image
-    for (int e = t; e < 32 * PCP; e += RB_CONV_THREADS) {
-      const int m = e / PCP, p = e - m * PCP;          // p fastest: coalesced along positions
-      float v = 0.0f;
-      if (p < npos && co0 + m < a.cout) v = a.dy[((int64_t)img * a.cout + co0 + m) * G::P + p0 + p];
-      s_a[p * 33 + m] = v;
+    // ---- stage dY^T (zero beyond the chunk) and the input patch of this image.  Every global load of the dY tile is
+    // unconditional (clamped address) and issued before the first LDS store: a loop of test-load-store made each of its
+    // 4-9 iterations a memory round trip.
+    {
+      constexpr int NIT = (32 * PCP + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
+      const int rows_valid = a.cout - co0 < 32 ? a.cout - co0 : 32;
+      float v[NIT];
+      int off[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int e = t + i * RB_CONV_THREADS;
+        int m = e / PCP;
+        int p = e - m * PCP;                              // p fastest: coalesced along positions
+        if (m > rows_valid - 1) m = rows_valid - 1;
+        if (p > npos - 1) p = npos - 1;
+        off[i] = (img * a.cout + co0 + m) * G::P + p0 + p;    // 32-bit: B * cout * P floats < 2^31
+      }
+      bool lazy = false;
+      if constexpr (!FIRST) lazy = a.dy_splits > 0;       // block-uniform
+      if (lazy) {
+        float mv[NIT], pv[NIT][4];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          mv[i] = a.dy_mask[off[i]];
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) pv[i][sp] = a.dy_part[(int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride + off[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          float acc = 0.0f;                               // k_dfeat_finish's order
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) acc += sp < a.dy_splits ? pv[i][sp] : 0.0f;
+          v[i] = mv[i] > 0.0f ? acc : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) v[i] = a.dy[off[i]];
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int e = t + i * RB_CONV_THREADS;
+        const int m = e / PCP, p = e - m * PCP;
+        if (e < 32 * PCP) s_a[p * 33 + m] = (p < npos && m < rows_valid) ? v[i] : 0.0f;
+      }
     }
     if (FIRST) {
       const int per_c = rows * G::IH;
@@ -570,9 +654,26 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
     } else {
       const float* base = a.x_f + (int64_t)img * cin * G::IP;
       const int per_c = rows * G::IH;
-      for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
-        const int c = e / per_c, q = e - c * per_c;
-        s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+      if (PR == G::IH && ((cin * G::IP) & 3) == 0) {
+        // the chunk is the whole image (later layers): the patch is one contiguous copy, all of it in flight at once
+        constexpr int NV = (SZ::CMAX * PLANE / 4 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
+        const int total4 = (cin * G::IP) >> 2;
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int e = t + i * RB_CONV_THREADS;
+          v[i] = rb_ld4(base + 4 * (e < total4 ? e : total4 - 1));
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int e = t + i * RB_CONV_THREADS;
+          if (e < total4) { float* d = s_patch + 4 * e; d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w; }
+        }
+      } else {
+        for (int e = t; e < cin * per_c; e += RB_CONV_THREADS) {
+          const int c = e / per_c, q = e - c * per_c;
+          s_patch[c * PLANE + q] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+        }
       }
     }
     __syncthreads();

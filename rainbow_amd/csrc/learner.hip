@@ -147,6 +147,8 @@ struct rb_learner {
   float* dlogits;       // [B][NZ]
   float* dh;            // [B][2H]
   float* dfeat_part;    // [xs][B][F]
+  int lazy_dfeat;       // this step: the last conv layer's backward kernels sum the partials themselves (no k_dfeat_finish)
+  int lazy_splits;
   float* dw_part[3];    // [ws_l][cout][K+1]
   float* log_ps_a;      // [B][Z]
   float* pns_a;         // [B][Z]
@@ -1025,6 +1027,7 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     constexpr int CHUNKS = (G::OH + RC - 1) / RC;
     ConvLdsDwArgs a;
     a.cin = c.cin; a.cout = c.cout; a.dy = l->dact[0]; a.src = l->cur_src; a.x_f = nullptr; a.part = l->dw_part[0];
+    a.dy_part = nullptr; a.dy_mask = nullptr; a.dy_stride = 0; a.dy_splits = 0;
     RB_LAUNCH((k_conv_dw_lds<G, RC, KMAXW, true>), dim3((unsigned)CHUNKS, (unsigned)rb_div_up(c.cout, 32), (unsigned)L.B),
               dim3(RB_CONV_THREADS), stream, a);
     lds_slices = L.B * CHUNKS;
@@ -1053,14 +1056,17 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     ConvLdsDxArgs a;
     a.cin = c.cin; a.cout = c.cout;
     a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
+    const bool lazy = l->lazy_dfeat && layer == L.nconv - 1;
+    a.dy_part = l->dfeat_part; a.dy_mask = l->act[layer]; a.dy_stride = (int64_t)L.B * L.F; a.dy_splits = lazy ? l->lazy_splits : 0;
     constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
     constexpr int NT_ALL = (NPOS + 31) / 32;
     // few images at batch 32: spread each phase's positions over several workgroups (weights are re-staged from L2)
     constexpr int NT = NT_ALL >= 4 ? 2 : 1;
     const unsigned groups = (unsigned)rb_div_up(NT_ALL, NT);
     static const char* const tags[3] = {"conv1_dx:k_conv_dx_lds", "conv2_dx:k_conv_dx_lds", "conv3_dx:k_conv_dx_lds"};
-    RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64>), dim3((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B),
-                dim3(RB_CONV_THREADS), stream, a);
+    const dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B);
+    if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
+    else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64>), grid, dim3(RB_CONV_THREADS), stream, a); }
     RB_LAUNCH_CHECK();
   } else if (layer > 0) {
     ConvDxProb<G> p;
@@ -1094,6 +1100,8 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
     ConvLdsDwArgs& d = a.layer[i];
     d.cin = c.cin; d.cout = c.cout; d.dy = l->dact[i]; d.part = l->dw_part[i];
     d.src = l->cur_src; d.x_f = i > 0 ? l->act[i - 1] : nullptr;
+    d.dy_part = l->dfeat_part; d.dy_mask = l->act[i]; d.dy_stride = (int64_t)L.B * L.F;
+    d.dy_splits = (l->lazy_dfeat && i == L.nconv - 1 && i > 0) ? l->lazy_splits : 0;
     // first layer: 7-row chunks (3 per image) so that all layers together are 96 + 64 + 64 = 224 workgroups at batch 32,
     // ONE round over the 256 CUs (5-row chunks gave 288 workgroups at one per CU: a second round for 32 of them)
     const int rc = i == 0 ? (c.ks == 8 ? 7 : 4) : c.oh;                 // later layers: the whole image is one chunk
@@ -1664,13 +1672,19 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     }
     l->sink_done = (up.enabled && !side) ? 1 : 0;
     RB_LAUNCH_CHECK();
-    {
+    // d(conv output) = relu' * sum of the row-split partials: formed by its two consumers (the last conv layer's dX and
+    // dW kernels) while they stage it, instead of a ~5 us launch of its own between two dependent kernels
+    static const bool lazy_off = getenv("RB_LAZY_DFEAT") && getenv("RB_LAZY_DFEAT")[0] == '0';   // A/B switch
+    l->lazy_dfeat = (!lazy_off && !side && l->fast_conv && L.nconv >= 2 && hsplits <= 4) ? 1 : 0;
+    l->lazy_splits = hsplits;
+    if (!l->lazy_dfeat) {
       const int64_t total = (int64_t)B * L.F;
       RB_LAUNCH(k_dfeat_finish, dim3((unsigned)rb_div_up(total, 256)), dim3(256), stream, (const float*)l->dfeat_part,
                 hsplits, total, feat, l->dact[L.nconv - 1]);
       RB_LAUNCH_CHECK();
     }
   } else {
+  l->lazy_dfeat = 0;
   l->norm_slots = 0;
   l->sink_done = 0;
   FcGradOut gz;
