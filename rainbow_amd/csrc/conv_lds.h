@@ -155,7 +155,20 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
       for (int j = 0; j < HW; ++j) areg[j] = (k0 + j < K && ml_ < rows_valid) ? wrow[k0 + j] : 0.0f;
     }
   } else {
+#if defined(RB_EXP_STRAIGHT)
+    {  // TIMING EXPERIMENT ONLY (wrong numerics): the slab copied straight, as if global memory held it as [k][32]
+      const float* wsrc = a.w[net] + (int64_t)cout0 * K;
+      const int total4 = (32 * K) >> 2;
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int e = t + i * RB_CONV_THREADS; v[i] = rb_ld4(wsrc + 4 * (e < total4 ? e : total4 - 1)); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int e = t + i * RB_CONV_THREADS; if (e < total4) *reinterpret_cast<float4*>(s_w + 4 * e) = v[i]; }
+      for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[K * 32 + e] = 0.0f;
+    }
+#else
     rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
+#endif
   }
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
@@ -271,7 +284,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   for (int j = 0; j < HW; ++j) {
     float av;
     if constexpr (WREG) av = areg[j];
+#if defined(RB_EXP_STRAIGHT)
+    else av = s_w[(kb + 2 * j + kh) * 32 + ml];
+#else
     else av = s_w[(kb + 2 * j + kh) * 33 + ml];
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
@@ -325,9 +342,13 @@ struct ConvLdsDxArgs {
   const float* dy_mask;  // the layer's own activation, rows [0,B)
   int64_t dy_stride;     // floats between partials
   int dy_splits;
+  int ipb, batch;        // MULTI instantiation: images per workgroup (grid z = ceil(batch / ipb)), image count
 };
 
-template <class G, int NT, int COUT, bool LAZY = false>
+// MULTI (batches of 64 and more): a workgroup keeps its weight slab and walks a.ipb images — per image only the dY tile
+// is staged (31 KB against 76 KB of transposed weights for the third layer); the reduction scratch then has a region of
+// its own instead of overlaying the operands.
+template <class G, int NT, int COUT, bool LAZY = false, bool MULTI = false>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a) {
   constexpr int TMAX = (G::KS + G::S - 1) / G::S;           // taps per dimension of a phase
   constexpr int KMAX = COUT * TMAX * TMAX;
@@ -339,14 +360,16 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   constexpr int PAD = TMAX - 1, PADH = (G::IH + G::S - 1) / G::S - G::OH, PW = G::OH + PAD + PADH, PP = PW * PW;
   constexpr int RED = RB_CONV_WAVES * NT * 16 * 64;
   constexpr int OPS = KPAD * 33 + COUT * PP;
-  constexpr int WSZ = OPS > RED ? OPS : RED;
+  constexpr int WSZ = MULTI ? OPS + RED : (OPS > RED ? OPS : RED);
   __shared__ float s_all[WSZ];
   float* s_w = s_all;
   float* s_dy = s_all + KPAD * 33;
+  float* s_red = MULTI ? s_all + OPS : s_all;
   __shared__ int s_koff[KPAD];      // co*PP - ty*PW - tx
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int img = (int)blockIdx.z;
+  const int ipb = MULTI ? a.ipb : 1;
+  const int img0 = (int)blockIdx.z * ipb;
   const int c0 = (int)blockIdx.y * 32;
   const int phase = (int)blockIdx.x % (G::S * G::S);
   const int n0 = ((int)blockIdx.x / (G::S * G::S)) * (32 * NT);     // first position of this block inside the phase
@@ -358,66 +381,14 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   const int npos = nyy * nxx;
   if (n0 >= npos) return;                                            // block-uniform
 
-  // ---- stage the (haloed) dY image, the phase's weight slab transposed to [k'][c], the tap table
-  if constexpr (LAZY) {
-    // interior cells: the mask and every partial of a thread's cells are requested before the first add (one round trip)
-    constexpr int IT = (COUT * G::P + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
-    const int ni = a.cout * G::P;
-    const float* mk = a.dy_mask + (int64_t)img * ni;
-    const float* pp = a.dy_part + (int64_t)img * ni;
-    float mv[IT], pv[IT][4];
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int e = t + i * RB_CONV_THREADS;
-      const int ec = e < ni ? e : ni - 1;
-      mv[i] = mk[ec];
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) pv[i][sp] = pp[(int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride + ec];
-    }
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int e = t + i * RB_CONV_THREADS;
-      if (e < ni) {
-        const int co = e / G::P, r = e - co * G::P;
-        const int y = r / G::OH, x = r - y * G::OH;
-        float acc = 0.0f;                                                 // k_dfeat_finish's order: ((0 + p0) + p1) + ...
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) acc += sp < a.dy_splits ? pv[i][sp] : 0.0f;
-        s_dy[co * PP + (y + PAD) * PW + x + PAD] = mv[i] > 0.0f ? acc : 0.0f;
-      }
-    }
-    if (PW > G::OH) {
-      const int n = a.cout * PP;
-      for (int e = t; e < n; e += RB_CONV_THREADS) {
-        const int r = e % PP;
-        const int y = r / PW - PAD, x = r % PW - PAD;
-        if (!(y >= 0 && y < G::OH && x >= 0 && x < G::OH)) s_dy[e] = 0.0f;
-      }
-    }
-  } else {
-    const float* src = a.dy + (int64_t)img * a.cout * G::P;
-    const int n = a.cout * PP;
-    for (int e0 = 0; e0 < n; e0 += 16 * RB_CONV_THREADS) {             // 16 loads in flight per thread
-      float v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = e0 + i * RB_CONV_THREADS + t;
-        const int co = e / PP, r = e - co * PP;
-        const int y = r / PW - PAD, x = r % PW - PAD;
-        v[i] = 0.0f;
-        if (e < n && y >= 0 && y < G::OH && x >= 0 && x < G::OH) v[i] = src[co * G::P + y * G::OH + x];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const int e = e0 + i * RB_CONV_THREADS + t; if (e < n) s_dy[e] = v[i]; }
-    }
-  }
+  // ---- once per workgroup: the tap table and the phase's weight slab transposed to [k'][c]
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
     const int co = kc / taps, r = kc - co * taps;
     const int ty = r / ntx, tx = r - ty * ntx;
     s_koff[k] = co * PP - ty * PW - tx;
   }
-  {   // phase slab of the weights, transposed to [k' = (co,ty,tx)][c]; thread = (c, co mod 16), no divisions
+  {   // thread = (c, co mod 16), no divisions
     const int m = t & 31;
     const bool cv = c0 + m < a.cin;
     constexpr int TAPS_MAX = TMAX * TMAX, CO_STEP = RB_CONV_THREADS / 32, CO_IT = (COUT + CO_STEP - 1) / CO_STEP;
@@ -443,7 +414,6 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
     }
     for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
   }
-  __syncthreads();
 
   constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time (rows >= K of s_w are zero): full unroll
   const int kb = wave * KW;
@@ -455,38 +425,122 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
     const int yy = n / nxx, xx = n - yy * nxx;
     noff[nt] = (yy + PAD) * PW + xx + PAD;
   }
-  rb_f32x16 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
   const int kh = lane >> 5, ml = lane & 31;
-  int kos[KW / 2];                                    // tap offsets of this wave's k range, off the per-step critical path
+  // the epilogue's cells (they do not depend on the image): offset inside the image, -1 = nothing to store
+  constexpr int EIT = (NT * 16 * 64) / RB_CONV_THREADS;
+  int eoff[EIT];
 #pragma unroll
-  for (int j = 0; j < KW / 2; ++j) kos[j] = s_koff[kb + 2 * j + kh];
-#pragma unroll
-  for (int j = 0; j < KW / 2; ++j) {
-    const float av = s_w[(kb + 2 * j + kh) * 33 + ml];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_dy[kos[j] + noff[nt]], acc[nt]);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_all[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
-  __syncthreads();
-  for (int idx = t; idx < NT * 16 * 64; idx += RB_CONV_THREADS) {
+  for (int it = 0; it < EIT; ++it) {
+    const int idx = t + it * RB_CONV_THREADS;
     const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
-    float v = s_all[((0 * NT + nt) * 16 + r) * 64 + l];
-#pragma unroll
-    for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[((wv * NT + nt) * 16 + r) * 64 + l];
     const int c = c0 + rb_mfma_row(r, l);
     const int n = n0 + nt * 32 + (l & 31);
-    if (c < a.cin && n < npos) {
-      const int yy = n / nxx, xx = n - yy * nxx;
-      const int64_t o = ((int64_t)img * a.cin + c) * G::IP + (yy * G::S + py) * G::IH + xx * G::S + px;
-      a.dx[o] = a.x_act[o] > 0.0f ? v : 0.0f;
+    const int yy = n / nxx, xx = n - yy * nxx;
+    eoff[it] = (c < a.cin && n < npos) ? c * G::IP + (yy * G::S + py) * G::IH + xx * G::S + px : -1;
+  }
+  int kos[KW / 2];                                    // tap offsets of this wave's k range, off the per-step critical path
+
+  // dY of an image: global loads into registers (issue), LDS stores later (commit) — with MULTI the next image's loads
+  // are in flight under this image's MFMA loop and reduction
+  constexpr int LIT = (COUT * G::P + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
+  static_assert(COUT * PP <= 16 * RB_CONV_THREADS, "one 16-deep batch covers the haloed dY image");
+  float pre_m[LAZY ? LIT : 1], pre_p[LAZY ? LIT : 1][4], pre_v[LAZY ? 1 : 16];
+  const int ni = a.cout * G::P, nh = a.cout * PP;
+  auto issue = [&](int img) {
+    if constexpr (LAZY) {
+      // interior cells: the mask and every partial of a thread's cells are requested before the first add (one round trip)
+      const float* mk = a.dy_mask + (int64_t)img * ni;
+      const float* pp = a.dy_part + (int64_t)img * ni;
+#pragma unroll
+      for (int i = 0; i < LIT; ++i) {
+        const int e = t + i * RB_CONV_THREADS;
+        const int ec = e < ni ? e : ni - 1;
+        pre_m[i] = mk[ec];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) pre_p[i][sp] = pp[(int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride + ec];
+      }
+    } else {
+      const float* src = a.dy + (int64_t)img * ni;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        const int co = e / PP, r = e - co * PP;
+        const int y = r / PW - PAD, x = r % PW - PAD;
+        pre_v[i] = 0.0f;
+        if (e < nh && y >= 0 && y < G::OH && x >= 0 && x < G::OH) pre_v[i] = src[co * G::P + y * G::OH + x];
+      }
+    }
+  };
+  auto commit = [&](bool first) {
+    if constexpr (LAZY) {
+#pragma unroll
+      for (int i = 0; i < LIT; ++i) {
+        const int e = t + i * RB_CONV_THREADS;
+        if (e < ni) {
+          const int co = e / G::P, r = e - co * G::P;
+          const int y = r / G::OH, x = r - y * G::OH;
+          float acc = 0.0f;                                                 // k_dfeat_finish's order: ((0 + p0) + p1) + ...
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) acc += sp < a.dy_splits ? pre_p[i][sp] : 0.0f;
+          s_dy[co * PP + (y + PAD) * PW + x + PAD] = pre_m[i] > 0.0f ? acc : 0.0f;
+        }
+      }
+      if (PW > G::OH && first) {                      // the halo stays zero from image to image
+        for (int e = t; e < nh; e += RB_CONV_THREADS) {
+          const int r = e % PP;
+          const int y = r / PW - PAD, x = r % PW - PAD;
+          if (!(y >= 0 && y < G::OH && x >= 0 && x < G::OH)) s_dy[e] = 0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int e = i * RB_CONV_THREADS + t; if (e < nh) s_dy[e] = pre_v[i]; }
+    }
+  };
+
+  issue(img0);
+  for (int ii = 0; ii < ipb; ++ii) {
+    const int img = img0 + ii;
+    if (MULTI && img >= a.batch) break;               // block-uniform
+    commit(ii == 0);
+    // the ReLU mask of this image's output cells: requested now, consumed after the MFMA loop (in the epilogue the load
+    // sat on the critical path of every store)
+    const float* xa = a.x_act + (int64_t)img * a.cin * G::IP;
+    float mask[EIT];
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) mask[it] = xa[eoff[it] >= 0 ? eoff[it] : 0];
+    __syncthreads();            // operands complete (and, MULTI, the previous image's reduction scratch has been consumed)
+    if (MULTI && ii + 1 < ipb && img + 1 < a.batch) issue(img + 1);
+    if (ii == 0) {
+#pragma unroll
+      for (int j = 0; j < KW / 2; ++j) kos[j] = s_koff[kb + 2 * j + kh];
+    }
+    rb_f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KW / 2; ++j) {
+      const float av = s_w[(kb + 2 * j + kh) * 33 + ml];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_dy[kos[j] + noff[nt]], acc[nt]);
+    }
+    if (!MULTI) __syncthreads();                      // the scratch overlays the operands
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_red[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
+    __syncthreads();                                  // (MULTI: every wave is also done reading this image's dY)
+    float* dxi = a.dx + (int64_t)img * a.cin * G::IP;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int idx = t + it * RB_CONV_THREADS;
+      const int l = idx & 63, r = (idx >> 6) & 15, nt = idx >> 10;
+      float v = s_red[((0 * NT + nt) * 16 + r) * 64 + l];
+#pragma unroll
+      for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_red[((wv * NT + nt) * 16 + r) * 64 + l];
+      if (eoff[it] >= 0) dxi[eoff[it]] = mask[it] > 0.0f ? v : 0.0f;
     }
   }
 }

@@ -1064,9 +1064,23 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     constexpr int NT = NT_ALL >= 4 ? 2 : 1;
     const unsigned groups = (unsigned)rb_div_up(NT_ALL, NT);
     static const char* const tags[3] = {"conv1_dx:k_conv_dx_lds", "conv2_dx:k_conv_dx_lds", "conv3_dx:k_conv_dx_lds"};
-    const dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)L.B);
-    if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
-    else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64>), grid, dim3(RB_CONV_THREADS), stream, a); }
+    // batches of 64 and more: about one round of workgroups over the chip, each keeping its weight slab for ipb images
+    const char* ipb_s = getenv("RB_DX_IPB");                                      // A/B / test switch (1 = one image each)
+    const int ipb_env = ipb_s ? atoi(ipb_s) : 0;
+    const int per_img = (G::S * G::S) * (int)groups * (int)rb_div_up(c.cin, 32);
+    int ipb = 1;
+    if (ipb_env > 0) ipb = ipb_env;
+    else if (L.B >= 64)                               // ONE round of workgroups (their LDS footprint allows one per CU)
+      while (per_img * (int)rb_div_up(L.B, ipb) > 256) ++ipb;
+    a.ipb = ipb; a.batch = L.B;
+    const dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
+    if (ipb > 1) {
+      if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
+      else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, false, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
+    } else {
+      if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
+      else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64>), grid, dim3(RB_CONV_THREADS), stream, a); }
+    }
     RB_LAUNCH_CHECK();
   } else if (layer > 0) {
     ConvDxProb<G> p;

@@ -47,6 +47,20 @@ def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
     ad.close()
 
 
+@pytest.mark.parametrize("name,steps", [("dataeff", None), ("canon", 1)])
+def test_multi_image_conv_input_gradient_matches_golden(emu, monkeypatch, name, steps):
+    """Batches of 64 and more run the conv data-gradient kernels with one weight slab per workgroup and a loop over
+    images (k_conv_dx_lds<..., MULTI>); RB_DX_IPB=3 forces that path (ragged: 3 does not divide the batch) on the small
+    fixtures, with the last layer's dY formed from the row-split partials inside the loop."""
+    monkeypatch.setenv("RB_DX_IPB", "3")
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    trace = scenarios.learn_scenario(ad, name, O, steps=steps)
+    golden = load_golden("learn_%s.npz" % name)
+    assert_learn_trace_matches(trace, {k: v for k, v in golden.items() if k in trace}, label="emu-dx-multi/" + name)
+    assert any("_grad/convs.0" in k for k in trace)
+    ad.close()
+
+
 @pytest.mark.parametrize("name", ["dataeff"])     # (the canonical stack runs the same test on the GPU: 2.5 min on the interpreter)
 def test_fused_weight_gradient_in_optimiser_pass_matches_golden(emu, name):
     """RB_LEARNER_FUSE_FC_H_DW (what rainbow_amd.agent.Agent runs): the hidden layer's weight gradient is not stored by the
