@@ -17,6 +17,9 @@
 
 #if defined(RB_STAMP)
 extern __device__ long long g_cstamp[64];
+#ifndef RB_MSTAMP_KS
+#define RB_MSTAMP_KS 4
+#endif
 #define RB_CSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_cstamp[i] = wall_clock64(); } while (0)
 #define RB_CSTAMP_LAST(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) g_cstamp[i] = wall_clock64(); } while (0)
 #else
@@ -33,6 +36,7 @@ struct ConvLdsFwdArgs {
   float* out;                // [img][cout][P]
   float* out_blocked;        // optional second copy of the flattened output in the k-blocked layout of noisy_linear.h
   int rows_total;            //   ... with this many rows (images)
+  int ipb;                   // k_conv_fwd_multi: images per workgroup
 };
 
 // ---- shared staging helpers ------------------------------------------------------------------
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
   constexpr int OPS = (WREG ? 0 : KPAD * 33) + CMAX * PLANE;     // [weights then] patch, contiguous
   constexpr int WSZ = OPS > RED ? OPS : RED;
-  __shared__ float s_all[WSZ];
+  __shared__ __attribute__((aligned(16))) float s_all[WSZ];
   __shared__ int s_koff[KPAD];
   float* s_w = s_all;
   float* s_patch = s_all + (WREG ? 0 : KPAD * 33);
@@ -325,6 +329,396 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   RB_CSTAMP_LAST(SB + 5);
 }
 
+// ---- large batches: one weight slab per workgroup, a loop over images -----------------------------------------
+// At 768 images the one-image workgroup above stages 34-76 KB of transposed weights for 2.6-5.3 us of MFMAs, 6-15 times
+// per CU.  Here a workgroup owns (position chunk, 32-channel slab) and walks a.ipb images: the slab, the tap table and
+// the epilogue's bias terms are set up once (again where the image range crosses from the online to the target net);
+// per image only the patch is staged, and the NEXT image's patch is already in flight (registers) under this image's
+// MFMA loop and reductions.  The reduction scratch has a
+// region of its own (it cannot overlay operands that live across images).
+// grid = (position chunks, cout / 32, image groups); block = 512.
+template <class G, int PR, int KMAX>
+struct ConvFwdMultiLds {
+  static constexpr int KPAD = (KMAX + 2 * RB_CONV_WAVES - 1) / (2 * RB_CONV_WAVES) * (2 * RB_CONV_WAVES);
+  static constexpr int FLOATS = KPAD * 33 + (KMAX / G::KK) * PR * G::IH + RB_CONV_WAVES * 16 * 64;
+  static constexpr bool FITS = FLOATS * 4 + KPAD * 4 <= 160 * 1024;
+};
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_multi(ConvLdsFwdArgs a) {
+  constexpr int KGRAN = 2 * RB_CONV_WAVES;
+  constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
+  constexpr int PLANE = PR * G::IH;                 // floats per channel in the patch
+  constexpr int CMAX = KMAX / G::KK;
+  constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch for ONE 32-position tile
+  constexpr int OPS = KPAD * 33 + CMAX * PLANE;
+  __shared__ __attribute__((aligned(16))) float s_all[OPS + RED];
+  __shared__ int s_koff[KPAD];
+  float* s_w = s_all;
+  float* s_patch = s_all + KPAD * 33;
+  float* s_red = s_all + OPS;
+
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+#if defined(RB_STAMP)
+  const bool mst = G::KS == RB_MSTAMP_KS && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+#define RB_MSTAMP(i) do { if (mst) g_cstamp[i] = wall_clock64(); } while (0)
+#else
+#define RB_MSTAMP(i) ((void)0)
+#endif
+  RB_MSTAMP(48);
+  // images [z * ipb, (z + 1) * ipb) of the whole list (net 0's first); a range that straddles the nets re-stages its slab
+  const int img0 = (int)blockIdx.z * a.ipb;
+  const int img_end = img0 + a.ipb < a.rows_total ? img0 + a.ipb : a.rows_total;
+  const int cout0 = (int)blockIdx.y * 32;
+  const int p0 = (int)blockIdx.x * PCH;
+  const int cin = a.cin;
+  const int K = cin * G::KK;
+  const int oy0 = p0 / G::OH;
+  const int iy0 = oy0 * G::S;
+  int rows = G::IH - iy0;
+  if (rows > PR) rows = PR;
+  const int per_c = rows * G::IH;
+
+  // ---- once: tap table (the weight slab: at the first image and where the net changes)
+  for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
+    const int kc = k < K ? k : K - 1;
+    const int c = kc / G::KK, r = kc % G::KK;
+    s_koff[k] = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
+  }
+
+  // ---- the patch of one image: loads into registers (issue), LDS stores later (commit)
+  constexpr bool VEC = !FIRST && (G::IH % 4 == 0);          // per_c, iy0 * IH and IP are then multiples of 4
+  constexpr int NU = FIRST ? 2 : 1, NV = (!FIRST && VEC) ? 8 : 1, NS = (!FIRST && !VEC) ? 12 : 1;
+  static_assert(!FIRST || CMAX * PLANE <= 16 * NU * RB_CONV_THREADS, "u8 patch fits one batch of loads");
+  static_assert(FIRST || !VEC || CMAX * PLANE <= 4 * NV * RB_CONV_THREADS, "f32 patch fits one batch of float4 loads");
+  static_assert(FIRST || VEC || CMAX * PLANE <= NS * RB_CONV_THREADS, "f32 patch fits one batch of scalar loads");
+  uint4 pu[NU];
+  float4 pv[NV];
+  float ps[NS];
+  auto issue = [&](int img) {
+    if constexpr (FIRST) {
+      const int v16 = per_c >> 4, total16 = cin * v16;       // 84-wide frames: 16-byte multiples
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        pu[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+          if (fp) pu[i] = *reinterpret_cast<const uint4*>(fp + iy0 * G::IH + q * 16);
+        }
+      }
+    } else if constexpr (VEC) {
+      const float* base = a.in_f + (int64_t)img * cin * G::IP;
+      const int v4 = per_c >> 2, total = cin * v4;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        const int ec = e < total ? e : total - 1;
+        const int c = ec / v4, q = ec - c * v4;
+        pv[i] = rb_ld4(base + c * G::IP + iy0 * G::IH + q * 4);
+      }
+    } else {
+      const float* base = a.in_f + (int64_t)img * cin * G::IP;
+      const int total = cin * per_c;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        const int ec = e < total ? e : total - 1;
+        const int c = ec / per_c, q = ec - c * per_c;
+        ps[i] = base[c * G::IP + iy0 * G::IH + q];
+      }
+    }
+  };
+  auto commit = [&]() {
+    if constexpr (FIRST) {
+      const int v16 = per_c >> 4, total16 = cin * v16;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          float* d = s_patch + c * PLANE + q * 16;
+          const unsigned wds[4] = {pu[i].x, pu[i].y, pu[i].z, pu[i].w};
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+        }
+      }
+    } else if constexpr (VEC) {
+      const int v4 = per_c >> 2, total = cin * v4;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        if (e < total) {
+          const int c = e / v4, q = e - c * v4;
+          float* d = s_patch + c * PLANE + q * 4;
+          d[0] = pv[i].x; d[1] = pv[i].y; d[2] = pv[i].z; d[3] = pv[i].w;
+        }
+      }
+    } else {
+      const int total = cin * per_c;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        if (e < total) { const int c = e / per_c, q = e - c * per_c; s_patch[c * PLANE + q] = ps[i]; }
+      }
+    }
+  };
+
+  constexpr int KW = KPAD / RB_CONV_WAVES, HW = KW / 2;
+  const int kb = wave * KW;
+  int noff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int p = p0 + nt * 32 + (lane & 31);
+    if (p > G::P - 1) p = G::P - 1;                  // clamped lanes are never stored
+    noff[nt] = (p / G::OH - oy0) * G::S * G::IH + (p % G::OH) * G::S;
+  }
+  const int kh = lane >> 5, ml = lane & 31;
+  constexpr int EIT = (16 * 64) / RB_CONV_THREADS;
+  float bias_r[EIT];
+  int kos[HW];
+
+  issue(img0);
+  for (int img = img0; img < img_end; ++img) {
+    if (img == img0 || img == a.n_on) {               // block-uniform (every wave is past the previous image's MFMA loop)
+      const int net = img < a.n_on ? 0 : 1;
+      rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
+#pragma unroll
+      for (int it = 0; it < EIT; ++it) {
+        const int idx = t + it * RB_CONV_THREADS;
+        const int m = cout0 + rb_mfma_row(idx >> 6, idx & 63);
+        bias_r[it] = a.bias[net][m < a.cout ? m : a.cout - 1];
+      }
+    }
+    commit();
+    __syncthreads();            // patch (and slab) complete; the previous image's last reduction has been consumed
+    RB_MSTAMP(img == img0 ? 49 : img == img0 + 1 ? 53 : 57);
+    if (img + 1 < img_end) issue(img + 1);
+    if (img == img0) {
+#pragma unroll
+      for (int j = 0; j < HW; ++j) kos[j] = s_koff[kb + 2 * j + kh];
+    }
+    rb_f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < HW; ++j) {
+      const float av = s_w[(kb + 2 * j + kh) * 33 + ml];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
+    }
+    RB_MSTAMP(img == img0 ? 50 : img == img0 + 1 ? 54 : 58);
+    // cross-wave sum one 32-position tile at a time, fixed order w0..w7 (as the one-image kernel)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt > 0) __syncthreads();                    // the previous tile's sums are no longer read
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[nt][r];
+      __syncthreads();                                // (nt == NT - 1: every wave is also done with this image's patch)
+#pragma unroll
+      for (int it = 0; it < EIT; ++it) {
+        const int idx = t + it * RB_CONV_THREADS;
+        const int l = idx & 63, r = idx >> 6;
+        float v = s_red[(0 * 16 + r) * 64 + l];
+#pragma unroll
+        for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_red[(wv * 16 + r) * 64 + l];
+        const int m = cout0 + rb_mfma_row(r, l);
+        const int p = p0 + nt * 32 + (l & 31);
+        if (m < a.cout && p < G::P && p < p0 + PCH) {
+          const float o = fmaxf(v + bias_r[it], 0.0f);
+          a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+          if (a.out_blocked) {
+            const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+            a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+          }
+        }
+      }
+      if (nt == 0) RB_MSTAMP(img == img0 ? 51 : img == img0 + 1 ? 55 : 59);
+    }
+    RB_MSTAMP(img == img0 ? 52 : img == img0 + 1 ? 56 : 60);
+  }
+  RB_MSTAMP(61);
+}
+
+// ---- large batches, FIRST layer: whole image per workgroup, no split of the reduction ---------------------------
+// The first layer's reduction is short (K = 256): splitting it over 8 waves leaves 16 MFMA steps per wave and tile, and
+// the cross-wave sum + barriers cost as much as the MFMAs (measured 2.7 us of 5.6 per 80-position chunk).  Here the whole
+// image (cin planes, decoded to f32) and the 32-channel slab sit in LDS (113 + 34 KB), every wave owns whole 32-position
+// tiles (wave w: tiles w and w + 8) and runs the full reduction for them: no partial sums, no scratch, the epilogue
+// goes from the accumulators to memory.  A workgroup walks a.ipb images of one net; the next image's frames are in
+// flight under the MFMA loop.
+// grid = (1, 1, image groups); block = 512.  Requires cout <= 32, cin * KK == KMAX, u8 frames.
+template <class G>
+__device__ __forceinline__ constexpr int rb_patch_off(int k) {           // reduction index (c, ky, kx) -> offset in the image planes
+  return (k / G::KK) * G::IP + ((k % G::KK) / G::KS) * G::IH + (k % G::KK) % G::KS;
+}
+template <class G, int KMAX>
+struct ConvFwdFullLds {
+  static constexpr int KPAD = (KMAX + 1) / 2 * 2;
+  static constexpr int CMAX = KMAX / G::KK;
+  static constexpr int FLOATS = KPAD * 33 + CMAX * G::IP;
+  static constexpr int NTILES = (G::P + 31) / 32;
+  static constexpr bool FITS = FLOATS * 4 <= 160 * 1024 && NTILES <= 2 * RB_CONV_WAVES && (G::IP % 16) == 0;
+};
+template <class G, int KMAX>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArgs a) {
+  typedef ConvFwdFullLds<G, KMAX> SZ;
+  constexpr int KPAD = SZ::KPAD, CMAX = SZ::CMAX, NTILES = SZ::NTILES;
+  __shared__ __attribute__((aligned(16))) float s_all[SZ::FLOATS];
+  float* s_w = s_all;
+  float* s_patch = s_all + KPAD * 33;
+
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+#if defined(RB_STAMP)
+  const bool fst = G::KS == 8 && t == 0 && blockIdx.z == 0;
+#define RB_FSTAMP(i) do { if (fst) g_cstamp[i] = wall_clock64(); } while (0)
+#else
+#define RB_FSTAMP(i) ((void)0)
+#endif
+  RB_FSTAMP(48);
+  // images [z * ipb, (z + 1) * ipb) of the whole list (net 0's images first): a workgroup whose range straddles the two
+  // nets re-stages the weight slab once — uniform groups keep 768 images at exactly 3 per workgroup on 256 CUs
+  const int img0 = (int)blockIdx.z * a.ipb;
+  const int img_end = img0 + a.ipb < a.rows_total ? img0 + a.ipb : a.rows_total;
+  const int cin = a.cin;
+  const int K = cin * G::KK;
+
+  // frames of one image: 16-byte loads into registers (issue), decoded to exact x/255 into LDS later (commit)
+  constexpr int V16 = G::IP / 16;
+  constexpr int NU = (CMAX * V16 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
+  uint4 pu[NU];
+  const int total16 = cin * V16;
+  auto issue = [&](int img) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      pu[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (e < total16) {
+        const int c = e / V16, q = e - c * V16;
+        const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
+        if (fp) pu[i] = *reinterpret_cast<const uint4*>(fp + q * 16);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      if (e < total16) {
+        float* d = s_patch + e * 16;                   // planes are contiguous: c * IP + q * 16
+        const unsigned wds[4] = {pu[i].x, pu[i].y, pu[i].z, pu[i].w};
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+      }
+    }
+  };
+
+  const int kh = lane >> 5, ml = lane & 31;
+  const bool two = wave + RB_CONV_WAVES < NTILES;                       // wave-uniform: a second tile
+  int noff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    int p = (wave + u * RB_CONV_WAVES) * 32 + ml;
+    if (p > G::P - 1) p = G::P - 1;                  // clamped lanes are never stored
+    noff[u] = (p / G::OH) * G::S * G::IH + (p % G::OH) * G::S;
+  }
+  float bias_r[16];
+
+  issue(img0);
+  for (int img = img0; img < img_end; ++img) {
+    if (img == img0 || img == a.n_on) {               // block-uniform: (re)stage the slab and bias of this image's net
+      const int net = img < a.n_on ? 0 : 1;           // (every wave has passed the end-of-image barrier: s_w is idle)
+      rb_stage_weights_t(s_w, a.w[net], 0, a.cout < 32 ? a.cout : 32, K, KPAD);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = rb_mfma_row(r, lane);
+        bias_r[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+      }
+    }
+    RB_FSTAMP(img == img0 ? 57 : 58);
+    commit();
+    RB_FSTAMP(img == img0 ? 59 : 60);
+    __syncthreads();            // image complete (first image: weights and tap table as well)
+    RB_FSTAMP(img == img0 ? 49 : img == img0 + 1 ? 53 : 61);
+    if (img + 1 < img_end) issue(img + 1);
+    rb_f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    // tap offsets are compile-time functions of the step (no table: a table read per step put two dependent LDS round
+    // trips in front of every MFMA — measured 38 us per image for 13 us of MFMAs); K == KMAX (host-checked): straight-line
+    // code the compiler can pipeline
+    if constexpr (G::KS % 2 == 0) {
+      // even kernel sizes: the two taps of a step are neighbours (kx, kx + 1) — the lane's half goes into the base
+      // pointers, a step's offsets are immediates, and the channel loop only advances the bases (a fully unrolled
+      // 128-step body needed a base register per 1 KB window of ds_read2: 255 VGPRs and a scratch segment)
+      const float* pb0 = s_patch + noff[0] + kh;
+      const float* pb1 = s_patch + noff[1] + kh;
+      const float* wp = s_w + kh * 33 + ml;
+      if (two) {
+#pragma unroll 1
+        for (int c = 0; c < CMAX; ++c) {
+#pragma unroll
+          for (int jj = 0; jj < G::KK / 2; ++jj) {
+            const float av = wp[2 * jj * 33];
+            acc0 = rb_mfma32(av, pb0[rb_patch_off<G>(2 * jj)], acc0);
+            acc1 = rb_mfma32(av, pb1[rb_patch_off<G>(2 * jj)], acc1);
+          }
+          pb0 += G::IP; pb1 += G::IP; wp += G::KK * 33;
+        }
+      } else {
+#pragma unroll 1
+        for (int c = 0; c < CMAX; ++c) {
+#pragma unroll
+          for (int jj = 0; jj < G::KK / 2; ++jj) {
+            const float av = wp[2 * jj * 33];
+            acc0 = rb_mfma32(av, pb0[rb_patch_off<G>(2 * jj)], acc0);
+          }
+          pb0 += G::IP; wp += G::KK * 33;
+        }
+      }
+    } else {
+      // odd sizes: a step's two taps can sit in different rows or planes — select between two constants
+      if (two) {
+#pragma unroll
+        for (int j = 0; j < KPAD / 2; ++j) {
+          const int o = kh ? rb_patch_off<G>(2 * j + 1) : rb_patch_off<G>(2 * j);
+          const float av = s_w[(2 * j + kh) * 33 + ml];
+          acc0 = rb_mfma32(av, s_patch[noff[0] + o], acc0);
+          acc1 = rb_mfma32(av, s_patch[noff[1] + o], acc1);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPAD / 2; ++j) {
+          const int o = kh ? rb_patch_off<G>(2 * j + 1) : rb_patch_off<G>(2 * j);
+          const float av = s_w[(2 * j + kh) * 33 + ml];
+          acc0 = rb_mfma32(av, s_patch[noff[0] + o], acc0);
+        }
+      }
+    }
+    RB_FSTAMP(img == img0 ? 50 : 54);
+    // epilogue straight from the accumulators: row r of the tile is output channel rb_mfma_row(r, lane), 32 consecutive
+    // positions per half-wave (contiguous in the NCHW activation)
+    float* outi = a.out + (int64_t)img * a.cout * G::P;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = rb_mfma_row(r, lane);
+      const int p0 = wave * 32 + ml;
+      if (m < a.cout && p0 < G::P) outi[m * G::P + p0] = fmaxf(acc0[r] + bias_r[r], 0.0f);
+      const int p1 = (wave + RB_CONV_WAVES) * 32 + ml;
+      if (two && m < a.cout && p1 < G::P) outi[m * G::P + p1] = fmaxf(acc1[r] + bias_r[r], 0.0f);
+    }
+    RB_FSTAMP(img == img0 ? 51 : 55);
+    __syncthreads();            // every wave is done reading this image before the next one is committed
+    RB_FSTAMP(img == img0 ? 52 : 56);
+  }
+}
+
 // (RB_STAMP: end-of-kernel stamps are written by the host-visible tail below)
 // ========================================================================= data gradient ==
 // dX[img][c][y][x] = relu'(x_act) * sum_{co,ky,kx} W[co][c][ky][kx] * dY[img][co][(y-ky)/S][(x-kx)/S]
@@ -361,7 +755,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   constexpr int RED = RB_CONV_WAVES * NT * 16 * 64;
   constexpr int OPS = KPAD * 33 + COUT * PP;
   constexpr int WSZ = MULTI ? OPS + RED : (OPS > RED ? OPS : RED);
-  __shared__ float s_all[WSZ];
+  __shared__ __attribute__((aligned(16))) float s_all[WSZ];
   float* s_w = s_all;
   float* s_dy = s_all + KPAD * 33;
   float* s_red = MULTI ? s_all + OPS : s_all;
@@ -792,7 +1186,7 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 
 template <class G, int RC, int KMAX, bool FIRST>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a) {
-  __shared__ float smem[ConvDwLdsSize<G, RC, KMAX>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[ConvDwLdsSize<G, RC, KMAX>::FLOATS];
   rb_conv_dw_body<G, RC, KMAX, FIRST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, 1, (int)gridDim.z, smem);
 }
 
@@ -813,7 +1207,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a
   typedef ConvDwLdsSize<G2, RC2, K2> S2;
   constexpr int M01 = S0::FLOATS > S1::FLOATS ? S0::FLOATS : S1::FLOATS;
   constexpr int MAXF = (NL > 2 && S2::FLOATS > M01) ? S2::FLOATS : M01;
-  __shared__ float smem[MAXF];
+  __shared__ __attribute__((aligned(16))) float smem[MAXF];
   int b = (int)blockIdx.x;
   if (b < a.nblocks[0]) {                              // decode: chunk fastest, then cout tile, then image
     constexpr int CH = (G0::OH + RC0 - 1) / RC0;

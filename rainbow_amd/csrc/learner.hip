@@ -856,7 +856,40 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.src = src; a.in_f = layer > 0 ? l->act[layer - 1] : nullptr; a.out = l->act[layer];
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
+  a.ipb = 1;
   static const char* const tags[3] = {"conv1_fwd:k_conv_fwd_lds", "conv2_fwd:k_conv_fwd_lds", "conv3_fwd:k_conv_fwd_lds"};
+  // large batches: one round of workgroups, each keeping its weight slab for ipb images of one net (conv_lds.h)
+  const char* multi_s = getenv("RB_CONV_MULTI");                         // A/B / test switch: images per workgroup (0 = off)
+  int ipb = 0;
+  if (multi_s) ipb = atoi(multi_s);
+  else if (n_on + n_tg >= 256) {
+    const int per_img = (int)(rb_div_up(G::P, PCH) * rb_div_up(c.cout, 32));
+    ipb = (int)rb_div_up((int64_t)(n_on + n_tg) * per_img, 256);
+  }
+  if constexpr (FIRST && ConvFwdFullLds<G, KMAX>::FITS) {
+    // first layer: whole image per workgroup, whole reduction per wave (RB_CONV_FULL=0: the chunked kernel below)
+    const char* full_s = getenv("RB_CONV_FULL");
+    const bool full_off = full_s && full_s[0] == '0';
+    if (ipb > 0 && !src.f32 && c.cout <= 32 && !a.out_blocked && !full_off && c.cin * G::KK == KMAX && (KMAX & 1) == 0) {
+      int fi = ipb;
+      if (!multi_s) fi = (int)rb_div_up(n_on + n_tg, 256);              // one round of workgroups
+      a.ipb = fi;
+      RB_LAUNCH_T(tags[layer], (k_conv_fwd_full<G, KMAX>), dim3(1, 1, (unsigned)rb_div_up(n_on + n_tg, fi)),
+                  dim3(RB_CONV_THREADS), stream, a);
+      RB_LAUNCH_CHECK();
+      return RB_OK;
+    }
+  }
+  if constexpr (ConvFwdMultiLds<G, PR, KMAX>::FITS) {
+    if (ipb > 0 && !(FIRST && src.f32)) {
+      a.ipb = ipb;
+      RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi<G, NT, PR, KMAX, FIRST, PCH>),
+                  dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(n_on + n_tg, ipb)),
+                  dim3(RB_CONV_THREADS), stream, a);
+      RB_LAUNCH_CHECK();
+      return RB_OK;
+    }
+  }
   RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG>),
               dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
               dim3(RB_CONV_THREADS), stream, a);

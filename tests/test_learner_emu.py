@@ -47,12 +47,14 @@ def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
     ad.close()
 
 
-@pytest.mark.parametrize("name,steps", [("dataeff", None), ("canon", 1)])
-def test_multi_image_conv_input_gradient_matches_golden(emu, monkeypatch, name, steps):
-    """Batches of 64 and more run the conv data-gradient kernels with one weight slab per workgroup and a loop over
-    images (k_conv_dx_lds<..., MULTI>); RB_DX_IPB=3 forces that path (ragged: 3 does not divide the batch) on the small
-    fixtures, with the last layer's dY formed from the row-split partials inside the loop."""
+@pytest.mark.parametrize("name,steps,full", [("dataeff", None, "1"), ("canon", 1, "1"), ("canon", 1, "0")])
+def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, full):
+    """Large batches run the conv forward and data-gradient kernels with one weight slab per workgroup and a loop over
+    images (k_conv_fwd_multi, k_conv_dx_lds<..., MULTI>); RB_CONV_MULTI / RB_DX_IPB force those paths (ragged: neither
+    divides the batch) on the small fixtures, with the last layer's dY formed from the row-split partials in the loop."""
     monkeypatch.setenv("RB_DX_IPB", "3")
+    monkeypatch.setenv("RB_CONV_MULTI", "5")         # and the forward's multi-image kernels, ragged as well
+    monkeypatch.setenv("RB_CONV_FULL", full)         # first layer: whole-image kernel (k_conv_fwd_full) / chunked k_conv_fwd_multi
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=steps)
     golden = load_golden("learn_%s.npz" % name)
