@@ -159,20 +159,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
       for (int j = 0; j < HW; ++j) areg[j] = (k0 + j < K && ml_ < rows_valid) ? wrow[k0 + j] : 0.0f;
     }
   } else {
-#if defined(RB_EXP_STRAIGHT)
-    {  // TIMING EXPERIMENT ONLY (wrong numerics): the slab copied straight, as if global memory held it as [k][32]
-      const float* wsrc = a.w[net] + (int64_t)cout0 * K;
-      const int total4 = (32 * K) >> 2;
-      float4 v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const int e = t + i * RB_CONV_THREADS; v[i] = rb_ld4(wsrc + 4 * (e < total4 ? e : total4 - 1)); }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const int e = t + i * RB_CONV_THREADS; if (e < total4) *reinterpret_cast<float4*>(s_w + 4 * e) = v[i]; }
-      for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[K * 32 + e] = 0.0f;
-    }
-#else
     rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
-#endif
   }
   for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
     const int kc = k < K ? k : K - 1;
@@ -288,11 +275,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   for (int j = 0; j < HW; ++j) {
     float av;
     if constexpr (WREG) av = areg[j];
-#if defined(RB_EXP_STRAIGHT)
-    else av = s_w[(kb + 2 * j + kh) * 32 + ml];
-#else
     else av = s_w[(kb + 2 * j + kh) * 33 + ml];
-#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
