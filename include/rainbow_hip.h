@@ -277,6 +277,35 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg_dev, fl
                          double lr, double beta1, double beta2, double eps, int64_t step,
                          float* norm_dev, rb_stream_t stream);
 
+/* One whole training step of Agent.learn (agent.py:63-100) in ONE call: rb_replay_sample_fused_noise (zero-copy: no stack
+ * gather), rb_learner_learn_windows on the frames/windows of `replay`, rb_learner_clip_adam — the same three entry points
+ * with the same arguments, back to back.  Why it exists: the HIP runtime lets the launching thread run only about one
+ * kernel ahead of the GPU, so host work BETWEEN launches (a Python interpreter between three ctypes calls: ~10 us twice
+ * per step) shows up as idle GPU time (measured 2 x 6 us of a 194 us step); inside one call the launches are 3 us apart.
+ * The priority write-back needs rb_learner_set_priority_sink(l, replay, tree_idx_dev) set beforehand.               */
+typedef struct {
+  rb_replay_t* replay;
+  int32_t batch, max_attempts, window_len, reserved;
+  double priority_weight;
+  int64_t* tree_idx_dev;            /* sampler outputs (device, [batch]) */
+  int64_t* actions_dev;
+  float* returns_dev;
+  float* nonterminals_dev;
+  float* weights_dev;
+  const rb_noise_job_t* noise_job;  /* from rb_learner_noise_job */
+  const uint8_t* frames_dev;        /* rb_replay_buffers: frame ring and the sampler's window table */
+  const int32_t* windows_dev;
+  float* loss_dev;                  /* f32[batch]: per-sample loss (agent.py:94) */
+  float* exp_avg_dev;               /* rb_learner_clip_adam arguments */
+  float* exp_avg_sq_dev;
+  float* norm_dev;
+  double lr, beta1, beta2, eps;
+  int64_t step;
+  float max_norm;
+  float reserved2;
+} rb_train_step_t;
+int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t stream);
+
 /* Learner options.
  * RB_LEARNER_FUSE_FC_H_DW: the hidden layer's weight gradient (93 % of all gradient bytes) is a rank-B product of two
  *   L2-resident matrices.  With this flag (and batch <= 32) rb_learner_learn* computes it for the global norm only and

@@ -38,6 +38,16 @@ class NoiseJob(C.Structure):
     _fields_ = [("opaque", c_uint64 * 32)]
 
 
+class TrainStep(C.Structure):
+    """rb_train_step_t (include/rainbow_hip.h)."""
+    _fields_ = [("replay", c_void_p), ("batch", c_int32), ("max_attempts", c_int32), ("window_len", c_int32), ("reserved", c_int32),
+                ("priority_weight", c_double), ("tree_idx_dev", c_void_p), ("actions_dev", c_void_p), ("returns_dev", c_void_p),
+                ("nonterminals_dev", c_void_p), ("weights_dev", c_void_p), ("noise_job", c_void_p), ("frames_dev", c_void_p),
+                ("windows_dev", c_void_p), ("loss_dev", c_void_p), ("exp_avg_dev", c_void_p), ("exp_avg_sq_dev", c_void_p),
+                ("norm_dev", c_void_p), ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("step", c_int64), ("max_norm", c_float), ("reserved2", c_float)]
+
+
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("offset", c_int64), ("ndim", c_int32), ("shape", c_int32 * 4)]
 
@@ -90,6 +100,7 @@ SIGNATURES = {
     "rb_learner_clip_grad": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rb_learner_clip_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                      c_int64, c_void_p, c_void_p]),
+    "rb_learner_train_step": (c_int, [c_void_p, C.POINTER(TrainStep), c_void_p]),
     "rb_learner_set_flags": (c_int, [c_void_p, c_int32]),
     "rb_learner_set_step_counter": (c_int, [c_void_p, c_void_p]),
     "rb_learner_set_priority_sink": (c_int, [c_void_p, c_void_p, c_void_p]),

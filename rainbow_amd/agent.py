@@ -60,6 +60,12 @@ class _FlatAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.step_direct(max_norm)
+        return loss
+
+    def step_direct(self, max_norm=float("inf"), stream=None):
+        """What step() does, callable without torch.optim's step wrapper (profiler record + hook dispatch: ~20 us per call,
+        a tenth of a batch-32 learn step's host time).  Agent.learn uses this; step() stays for API compatibility."""
         ag = self._agent()
         if ag is None:
             raise RuntimeError("the Agent that owns this optimiser is gone")
@@ -72,11 +78,12 @@ class _FlatAdam(torch.optim.Adam):
         # device-resident step counter (hipGraph replay): step = 0 tells the kernel to read it and form the bias
         # corrections itself; the host copy above only mirrors it (Agent._sync_step refreshes it after replays)
         step = 0 if ag._step_dev is not None else int(st["step"].item())
-        L.check(ag._lib, ag._lib.rb_learner_clip_adam(
+        rc = ag._lib.rb_learner_clip_adam(
             ag._h, float(max_norm), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1),
             float(b2), float(g["eps"]), step,
-            ag._norm.data_ptr() if math.isfinite(max_norm) else None, ag._stream()))
-        return loss
+            ag._norm.data_ptr() if math.isfinite(max_norm) else None, ag._stream() if stream is None else stream)
+        if rc != 0:
+            L.check(ag._lib, rc)
 
 
 class Agent:
@@ -156,6 +163,10 @@ class Agent:
         self._graph_mem = None
         self._eager_steps = 0
         self._noise_jobs = {}
+        self._zero_copy_ok = None
+        # the whole step as ONE C call (rb_learner_train_step) when nothing needs the interpreter in between
+        self._one_call = os.environ.get("RAINBOW_AMD_ONE_CALL", "1") == "1"
+        self._ts = self._ts_mem = self._ts_out = None
         # priority write-back beside clip + Adam on a second stream (one fork/join per step)
         self._overlap_update = os.environ.get("RAINBOW_AMD_UPDATE_OVERLAP", "0") == "1"
         # priority write-back as one extra workgroup of the learner's backward launch (see rb_learner_set_priority_sink)
@@ -376,15 +387,66 @@ class Agent:
         torch.cuda.synchronize(dev)     # the capture itself does not execute the step
         self._graph.replay()
 
+    def _learn_one_call(self, mem, stream):
+        """The whole step through rb_learner_train_step (one C call): same entry points, same arguments, same order as
+        _learn_eager's three calls — without the interpreter between the launches (include/rainbow_hip.h says why)."""
+        B = self.batch_size
+        ts = self._ts
+        if ts is None or self._ts_mem is not mem or mem._out.get(B) is not self._ts_out:
+            o = mem._buffers(B)
+            frames, windows, wlen = mem.frame_source()
+            if getattr(self, "_sink_mem", None) is not mem or self._sink_idx is not o["tree_idxs"]:
+                L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, mem._h, o["tree_idxs"].data_ptr()))
+                self._sink_mem, self._sink_idx = mem, o["tree_idxs"]
+                me = weakref.ref(self)
+                weakref.finalize(mem, lambda: me() is not None and me()._clear_sink())
+            ts = L.TrainStep(replay=mem._h, batch=B, max_attempts=mem.MAX_ATTEMPTS, window_len=wlen,
+                             tree_idx_dev=o["tree_idxs"].data_ptr(), actions_dev=o["actions"].data_ptr(),
+                             returns_dev=o["returns"].data_ptr(), nonterminals_dev=o["nonterminals"].data_ptr(),
+                             weights_dev=o["weights"].data_ptr(), frames_dev=frames, windows_dev=windows,
+                             loss_dev=self._loss.data_ptr(), norm_dev=self._norm.data_ptr())
+            self._ts, self._ts_mem, self._ts_out = ts, mem, o
+        if float(mem.priority_weight) != mem._neg_beta_val:
+            mem._sync_beta()
+        which = 2 if self._noise_pending else 1
+        self._noise_pending = False
+        job = self._noise_jobs.get(which)
+        if job is None:
+            job = L.NoiseJob()
+            L.check(self._lib, self._lib.rb_learner_noise_job(self._h, which, C.byref(job)))
+            self._noise_jobs[which] = job
+        g = self.optimiser.param_groups[0]
+        st = self.optimiser.state[self.params]        # looked up every step: load_state_dict replaces these tensors
+        st["step"] += 1
+        ts.exp_avg_dev, ts.exp_avg_sq_dev = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+        ts.priority_weight = float(mem.priority_weight)
+        ts.noise_job = C.addressof(job)
+        ts.lr, ts.eps, ts.max_norm = float(g["lr"]), float(g["eps"]), float(self.norm_clip)
+        ts.beta1, ts.beta2 = g["betas"]
+        ts.step = 0 if self._step_dev is not None else int(st["step"].item())
+        rc = self._lib.rb_learner_train_step(self._h, C.byref(ts), stream)
+        if rc != 0:
+            L.check(self._lib, rc)
+        if not self._lib.rb_learner_priority_written(self._h):       # (cannot happen with a sink set; keeps agent.py:100)
+            mem.update_priorities(self._ts_out["tree_idxs"], self._loss)
+
     def _learn_eager(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
+        stream = self._stream()                       # ONE lookup per step (torch.cuda.current_stream costs ~4 us a call)
         if device_mem and mem.failed_samples():
             raise RuntimeError("ReplayMemory: %d sampler launch(es) found no valid batch in %d attempts (replay too small "
                                "for batch %d?); those steps ran with zero importance weights"
                                % (mem.failed_samples(), mem.MAX_ATTEMPTS, B))
-        zero_copy = (device_mem and bool(self._lib.rb_learner_zero_copy_ok(self._h)) and mem.history == self._cfg.history
-                     and mem.n == self.n)
+        if self._zero_copy_ok is None:                # a property of the learner's configuration: asked once
+            self._zero_copy_ok = bool(self._lib.rb_learner_zero_copy_ok(self._h))
+        zero_copy = device_mem and self._zero_copy_ok and mem.history == self._cfg.history and mem.n == self.n
+        if (zero_copy and self._one_call and _target_raw_normals is None and _unit_uniforms is None and self._fuse_update
+                and not self._overlap_update and self._exchange is None and not self._dist
+                and isinstance(self.optimiser, _FlatAdam) and math.isfinite(float(self.norm_clip))):
+            g = self.optimiser.param_groups[0]
+            if not (g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"]):
+                return self._learn_one_call(mem, stream)
         noise_job = None
         if device_mem and _target_raw_normals is None:
             # the target-noise draw of this step (agent.py:74) — plus the deferred online draw (main.py:151) when one is
@@ -398,7 +460,7 @@ class Agent:
                 L.check(self._lib, self._lib.rb_learner_noise_job(self._h, which, C.byref(noise_job)))
                 self._noise_jobs[which] = noise_job
         if device_mem:
-            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy, noise_job=noise_job)   # agent.py:63
+            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy, noise_job=noise_job, stream=stream)   # agent.py:63
             idxs, states, next_states = o["tree_idxs"], o["states"], o["next_states"]
             actions, returns, nonterminals, weights = o["actions"], o["returns"], o["nonterminals"], o["weights"]
         else:   # foreign replay with the reference's API: float32 /255 states come back; re-quantise (exact for k/255)
@@ -413,7 +475,7 @@ class Agent:
         if noise_job is None:
             if self._noise_pending and _target_raw_normals is None:
                 self._noise_pending = False      # online (main.py:151) and target (agent.py:74) noise in one launch
-                L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 2, None, self._stream()))
+                L.check(self._lib, self._lib.rb_learner_reset_noise(self._h, 2, None, stream))
             else:
                 self._flush_noise()
                 self._reset_target_noise(_target_raw_normals)                              # agent.py:74
@@ -430,13 +492,15 @@ class Agent:
             self._sink_mem, self._sink_idx = None, None
         if zero_copy:   # conv1 reads the frames straight out of the HBM ring: no stack gather at all
             frames, windows, wlen = mem.frame_source()
-            L.check(self._lib, self._lib.rb_learner_learn_windows(
+            rc = self._lib.rb_learner_learn_windows(
                 self._h, frames, windows, wlen, actions.data_ptr(), returns.data_ptr(), nonterminals.data_ptr(),
-                weights.data_ptr(), self._loss.data_ptr(), self._stream()))
+                weights.data_ptr(), self._loss.data_ptr(), stream)
+            if rc != 0:
+                L.check(self._lib, rc)
         else:
             L.check(self._lib, self._lib.rb_learner_learn(
                 self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
-                nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), self._stream()))   # agent.py:66-96
+                nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), stream))   # agent.py:66-96
         fused_update = device_mem and bool(self._lib.rb_learner_priority_written(self._h))
         overlap = device_mem and self._overlap_update and not fused_update
         if overlap:
@@ -456,10 +520,10 @@ class Agent:
             rdist.average_gradients(self.grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         if isinstance(self.optimiser, _FlatAdam):
-            self.optimiser.step(max_norm=float(self.norm_clip))                            # agent.py:97-98, one pass
+            self.optimiser.step_direct(float(self.norm_clip), stream)                      # agent.py:97-98, one pass
         else:
             L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
-                                                              self._stream()))            # agent.py:97
+                                                              stream))                    # agent.py:97
             self.optimiser.step()                                                          # agent.py:98
         if overlap:
             torch.cuda.current_stream(self.device).wait_event(self._ev_upd)

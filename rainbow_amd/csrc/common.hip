@@ -37,6 +37,38 @@ bool rb_prof_begin(const char* kernel_expr, hipStream_t stream) {
 void rb_prof_end(hipStream_t stream) { (void)hipEventRecord(g_prof_events[g_prof_used++], stream); }
 #endif
 
+#if defined(RB_HOST_TIMING)
+#include <chrono>
+#include <map>
+#include <string>
+static std::map<std::string, std::pair<double, long>> g_host_time;
+double rb_host_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void rb_host_time_add(const char* tag, double us) { auto& e = g_host_time[tag]; e.first += us; e.second += 1; }
+__global__ void k_debug_spin(long long cycles, float* out) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) {}
+  if (out && threadIdx.x == 0 && blockIdx.x == 0) out[0] = 1.0f;
+}
+// N launches of a ~us-long kernel on `stream`: host time per launch and wall time per kernel (is the host throttled?)
+extern "C" int rb_debug_spin_launch(void* stream, int n, int us) {
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(k_debug_spin, dim3(256), dim3(256), 0, s, (long long)us * 100, (float*)nullptr);
+  hipStreamSynchronize(s);
+  const double t0 = rb_host_now_us();
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_debug_spin, dim3(256), dim3(256), 0, s, (long long)us * 100, (float*)nullptr);
+  const double t1 = rb_host_now_us();
+  hipStreamSynchronize(s);
+  const double t2 = rb_host_now_us();
+  printf("spin %d us on stream %p: host %.2f us/launch, wall %.2f us/kernel\n", us, stream, (t1 - t0) / n, (t2 - t0) / n);
+  return 0;
+}
+extern "C" int rb_debug_host_timing(int reset) {
+  if (reset) { g_host_time.clear(); return 0; }
+  for (auto& kv : g_host_time) printf("  host %-40s n %7ld  mean %7.2f us\n", kv.first.c_str(), kv.second.second, kv.second.first / kv.second.second);
+  return 0;
+}
+#endif
+
 void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nbytes);   // replay.hip
 
 extern "C" {

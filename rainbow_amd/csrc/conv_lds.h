@@ -720,6 +720,7 @@ struct ConvLdsDxArgs {
   int64_t dy_stride;     // floats between partials
   int dy_splits;
   int ipb, batch;        // MULTI instantiation: images per workgroup (grid z = ceil(batch / ipb)), image count
+  int wt;                // write-through stores (strided phases: see rb_st1_wt)
 };
 
 // MULTI (batches of 64 and more): a workgroup keeps its weight slab and walks a.ipb images — per image only the dY tile
@@ -917,7 +918,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       float v = s_red[((0 * NT + nt) * 16 + r) * 64 + l];
 #pragma unroll
       for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_red[((wv * NT + nt) * 16 + r) * 64 + l];
-      if (eoff[it] >= 0) dxi[eoff[it]] = mask[it] > 0.0f ? v : 0.0f;
+      if (eoff[it] >= 0) {
+        const float o = mask[it] > 0.0f ? v : 0.0f;
+        if (a.wt) rb_st1_wt(dxi, 4u * (unsigned)eoff[it], o);            // uniform
+        else dxi[eoff[it]] = o;
+      }
     }
   }
 }

@@ -1106,6 +1106,10 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     else if (L.B >= 64)                               // ONE round of workgroups (their LDS footprint allows one per CU)
       while (per_img * (int)rb_div_up(L.B, ipb) > 256) ++ipb;
     a.ipb = ipb; a.batch = L.B;
+    {
+      const char* wt_s = getenv("RB_DX_WT");                               // A/B switch
+      a.wt = wt_s ? atoi(wt_s) : 0;                  // measured slower (batch 256: 45 -> 53 us): off
+    }
     const dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
     if (ipb > 1) {
       if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
@@ -1804,6 +1808,19 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     RB_HIP_TRY(hipStreamWaitEvent(stream, l->ev[7], 0));
   }
   return RB_OK;
+}
+
+int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr && a != nullptr && a->replay != nullptr, "rb_learner_train_step: NULL argument");
+  int rc = rb_replay_sample_fused_noise(a->replay, a->batch, a->priority_weight, nullptr, a->max_attempts, a->tree_idx_dev, nullptr,
+                                        nullptr, a->actions_dev, a->returns_dev, a->nonterminals_dev, a->weights_dev,
+                                        a->noise_job, stream);
+  if (rc != RB_OK) return rc;
+  rc = rb_learner_learn_windows(l, a->frames_dev, a->windows_dev, a->window_len, a->actions_dev, a->returns_dev,
+                                a->nonterminals_dev, a->weights_dev, a->loss_dev, stream);
+  if (rc != RB_OK) return rc;
+  return rb_learner_clip_adam(l, a->max_norm, a->exp_avg_dev, a->exp_avg_sq_dev, a->lr, a->beta1, a->beta2, a->eps, a->step,
+                              a->norm_dev, stream);
 }
 
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream) {

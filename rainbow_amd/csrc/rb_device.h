@@ -21,12 +21,24 @@ bool rb_prof_begin(const char* kernel_expr, hipStream_t stream);
 void rb_prof_end(hipStream_t stream);
 extern int g_rb_prof_on;
 // RB_LAUNCH_T: same, with an explicit profiling tag (a kernel used for several layers gets one tag per layer)
+// RB_HOST_TIMING builds: host time spent inside each launch call, per tag (rb_debug_host_timing, common.hip)
+#if defined(RB_HOST_TIMING)
+void rb_host_time_add(const char* tag, double us);
+double rb_host_now_us();
+#define RB_LAUNCH_T(tag, kern, grid, block, stream, ...)                                        \
+  do {                                                                                          \
+    const double rb_t0_ = rb_host_now_us();                                                     \
+    hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__);           \
+    rb_host_time_add(tag, rb_host_now_us() - rb_t0_);                                           \
+  } while (0)
+#else
 #define RB_LAUNCH_T(tag, kern, grid, block, stream, ...)                                        \
   do {                                                                                          \
     const bool rb_pf_ = g_rb_prof_on && rb_prof_begin(tag, (hipStream_t)(stream));              \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__);           \
     if (rb_pf_) rb_prof_end((hipStream_t)(stream));                                             \
   } while (0)
+#endif
 #define RB_LAUNCH(kern, grid, block, stream, ...) RB_LAUNCH_T(#kern, kern, grid, block, stream, __VA_ARGS__)
 #endif
 
@@ -82,6 +94,18 @@ __device__ __forceinline__ void rb_st4_wt(float* base, unsigned byte_off, float4
   rb_v4u t;
   t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)byte_off, 0, 16);   // aux bit 4 = sc1
+#endif
+}
+
+// 4-byte write-through store (same idea for scattered element stores: a strided writer — the stride-2 phases of a
+// transposed conv — leaves PARTIAL dirty lines in several XCDs' L2s, whose end-of-kernel write-back is slow and is charged
+// to the next kernel's start)
+__device__ __forceinline__ void rb_st1_wt(float* base, unsigned byte_off, float v) {
+#if defined(RB_HOST_INTERP)
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+#else
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00027000);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 16);   // aux bit 4 = sc1
 #endif
 }
 

@@ -80,6 +80,7 @@ class ReplayMemory:
                                                           self.discount, self.priority_exponent, self._seed))
         self.transitions = _TransitionsView(self)
         self._out = {}
+        self._ptr_cache = {}
         self.current_idx = 0
         self._init_beta_source()
 
@@ -114,6 +115,7 @@ class ReplayMemory:
     def _buffers(self, batch):
         key = int(batch)
         if key not in self._out:
+            self._ptr_cache = {k: v for k, v in self._ptr_cache.items() if k[0] != key}
             d, h = self.device, self.history
             self._out[key] = dict(
                 tree_idxs=torch.empty(batch, dtype=torch.int64, device=d),
@@ -167,26 +169,37 @@ class ReplayMemory:
             L.check(self._lib, self._lib.rb_replay_buffers(self._h, C.byref(self._bufs)))
         return self._bufs.frames_dev, self._bufs.window_dev, int(self._bufs.window_len)
 
-    def sample_device(self, batch_size, unit_uniforms=None, gather=True, noise_job=None):
+    def sample_device(self, batch_size, unit_uniforms=None, gather=True, noise_job=None, stream=None):
         """Device-resident batch: dict(tree_idxs i64[B], states u8[B,h,84,84], next_states u8, actions i64[B],
         returns f32[B], nonterminals f32[B], weights f32[B]).  Asynchronous.  unit_uniforms (float64 device
         tensor [attempts,B]) injects the sampler's random numbers for parity tests.  gather=False skips the
         frame-stack copies (states/next_states are then stale): the consumer reads the ring via frame_source().
         noise_job (rainbow_amd._lib.NoiseJob from the learner) lets the launch also carry the noise resample."""
         o = self._buffers(batch_size)
-        if not torch.cuda.is_current_stream_capturing():
+        if float(self.priority_weight) != self._neg_beta_val and not torch.cuda.is_current_stream_capturing():
             self._sync_beta()
         uu_ptr, attempts = None, self.MAX_ATTEMPTS
         if unit_uniforms is not None:
             self._uu = unit_uniforms.to(device=self.device, dtype=torch.float64).contiguous()
             uu_ptr, attempts = self._uu.data_ptr(), int(self._uu.shape[0])
-        args = (self._h, int(batch_size), float(self.priority_weight), uu_ptr, attempts, o["tree_idxs"].data_ptr(),
-                o["states"].data_ptr() if gather else None, o["next_states"].data_ptr() if gather else None,
-                o["actions"].data_ptr(), o["returns"].data_ptr(), o["nonterminals"].data_ptr(), o["weights"].data_ptr())
+        # the output buffers are persistent: their addresses are looked up once per (batch, gather), not per call (the
+        # host side of a learn step is about as long as its GPU side at batch 32 — every microsecond here is on the clock)
+        key = (int(batch_size), bool(gather))
+        ptrs = self._ptr_cache.get(key)
+        if ptrs is None:
+            ptrs = (o["tree_idxs"].data_ptr(), o["states"].data_ptr() if gather else None,
+                    o["next_states"].data_ptr() if gather else None, o["actions"].data_ptr(), o["returns"].data_ptr(),
+                    o["nonterminals"].data_ptr(), o["weights"].data_ptr())
+            self._ptr_cache[key] = ptrs
+        if stream is None:
+            stream = self._stream()
         if noise_job is not None:
-            L.check(self._lib, self._lib.rb_replay_sample_fused_noise(*args, C.byref(noise_job), self._stream()))
+            rc = self._lib.rb_replay_sample_fused_noise(self._h, key[0], float(self.priority_weight), uu_ptr, attempts, *ptrs,
+                                                        C.byref(noise_job), stream)
         else:
-            L.check(self._lib, self._lib.rb_replay_sample(*args, self._stream()))
+            rc = self._lib.rb_replay_sample(self._h, key[0], float(self.priority_weight), uu_ptr, attempts, *ptrs, stream)
+        if rc != 0:
+            L.check(self._lib, rc)
         return o
 
     def sample(self, batch_size):
@@ -369,5 +382,6 @@ class ReplayMemory:
         L.check(self._lib, self._lib.rb_copy_to_device(b.header_dev, hdr.ctypes.data, hdr.nbytes, self._stream()))
         self.transitions = _TransitionsView(self)
         self._out = {}
+        self._ptr_cache = {}
         self._init_beta_source()
         self._header()   # resynchronise the library's host mirror of index/full

@@ -481,3 +481,49 @@ def test_checkpoint_restore_resumes_bit_exactly(hip, tmp_path):
     assert np.array_equal(m1._grab("tree"), m2._grab("tree"))
     assert bytes(m1._header()) == bytes(m2._header())
     assert isinstance(ck, dict) and ck["adam_step"] == 3.0
+
+
+@pytest.mark.gpu
+def test_one_call_step_equals_three_call_step(hip, monkeypatch):
+    """Agent.learn's default path hands the whole step to rb_learner_train_step (one C call: sample + noise, learn, clip +
+    Adam); RAINBOW_AMD_ONE_CALL=0 issues the same three entry points from Python.  Same launches, same arguments: after 8
+    steps with beta annealing, a deferred online-noise draw and a target sync, parameters, moments, per-sample losses and
+    the sum-tree must be bit-identical."""
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+    args = _args(architecture="canonical", hidden_size=64, batch_size=16)
+    env = types.SimpleNamespace(action_space=lambda: 4)
+
+    def run(one_call):
+        monkeypatch.setenv("RAINBOW_AMD_ONE_CALL", one_call)
+        torch.manual_seed(11)
+        np.random.seed(11)
+        agent = Agent(args, env)
+        assert agent._one_call == (one_call == "1")
+        mem = ReplayMemory(args, 4096, seed=9)
+        g = torch.Generator(device="cuda").manual_seed(4)
+        rs = np.random.RandomState(4)
+        for _ in range(3):
+            mem.append_batch(torch.randint(0, 256, (1500, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
+                             rs.randint(0, 4, 1500), rs.choice([-1.0, 0.0, 1.0], size=1500), rs.random_sample(1500) < 0.01)
+        losses = []
+        for k in range(8):
+            mem.priority_weight = min(1.0, 0.4 + 0.05 * k)
+            if k % 2 == 0:
+                agent.reset_noise()
+            agent.learn(mem)
+            losses.append(agent._loss.clone())
+            if k == 4:
+                agent.update_target_net()
+        torch.cuda.synchronize()
+        st = agent.optimiser.state[agent.params]
+        return dict(params=agent.params.detach().cpu().numpy(), m=st["exp_avg"].cpu().numpy(), v=st["exp_avg_sq"].cpu().numpy(),
+                    step=float(st["step"]), losses=torch.stack(losses).cpu().numpy(), total=mem._header().total,
+                    idx=mem._buffers(16)["tree_idxs"].cpu().numpy(), used_one_call=agent._ts is not None)
+
+    a, b = run("1"), run("0")
+    assert a["used_one_call"] and not b["used_one_call"]
+    assert a["step"] == b["step"] == 8.0
+    for k in ("params", "m", "v", "losses", "idx"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["total"] == b["total"]

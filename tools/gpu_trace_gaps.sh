@@ -1,0 +1,27 @@
+# usage: bash tools/gpu_trace_gaps.sh <config>: rocprofv3 kernel trace of a short bench run; per kernel of the learn step the
+# mean duration and the mean idle gap between the previous kernel's end and its start (steady-state steps only)
+CFG=$1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+ROOT=$PWD
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/gaps -o gaps -- python $ROOT/bench.py --config $CFG --steps 60 --warmup 20 --no-cpu-baseline --roofline-kernel clip_adam > $ROOT/gpurun_out/gaps.log 2>&1
+cd $ROOT
+python - <<'PY'
+import csv, glob, collections
+f = glob.glob("gpurun_out/gaps/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+# the timed region: the last 60 k_clip_adam launches delimit steps
+idx = [i for i, r in enumerate(rows) if "k_clip_adam" in r["Kernel_Name"]]
+lo, hi = idx[-41], idx[-1]
+dur = collections.defaultdict(list); gap = collections.defaultdict(list)
+for i in range(lo + 1, hi + 1):
+    r, p = rows[i], rows[i - 1]
+    name = r["Kernel_Name"].split("(")[0][:48] + ("|" + str(r.get("Grid_Size") or r.get("Grid_Size_X")) if "k_nl_" in r["Kernel_Name"] else "")
+    dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    gap[name].append((int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / 1e3)
+tot = 0
+for k in dur:
+    d, g = sum(dur[k]) / len(dur[k]), sum(gap[k]) / len(gap[k])
+    print("%-60s n/step %.1f  dur %7.2f us  gap-before %6.2f us" % (k, len(dur[k]) / 40.0, d, g))
+PY
+rm -rf gpurun_out/gaps
