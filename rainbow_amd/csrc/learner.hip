@@ -160,6 +160,7 @@ struct rb_learner {
   int norm_conv_base;   // first slot of the conv reduction blocks
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
+  NoiseJob* job_dev;               // [3] device copies of the noise jobs (rb_learner_noise_job), uploaded on request
   int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
@@ -1282,6 +1283,7 @@ int rb_learner_destroy(rb_learner_t* l) {
     if (*p) (void)hipFree(*p);
   if (l->a_star) (void)hipFree(l->a_star);
   if (l->noise_ctr) (void)hipFree(l->noise_ctr);
+  if (l->job_dev) (void)hipFree(l->job_dev);
   if (l->ev_fact) (void)hipEventDestroy(l->ev_fact);
   if (l->use_side) {
     for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
@@ -1291,6 +1293,7 @@ int rb_learner_destroy(rb_learner_t* l) {
   return RB_OK;
 }
 
+static int upload_noise_jobs(rb_learner* l);
 int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float* online_params_dev,
                       float* target_params_dev, float* grads_dev, float* online_noise_dev, float* target_noise_dev,
                       uint64_t seed) {
@@ -1393,6 +1396,10 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_HIP_TRY(hipMemcpy(l->support, sup, L.Z * sizeof(float), hipMemcpyHostToDevice));
   RB_HIP_TRY(hipMemset(l->zero_noise, 0, L.n_noise * sizeof(float)));
   RB_HIP_TRY(hipMemset(l->hpart, 0, (size_t)l->hs * NI * 2 * L.H * 4));
+  {
+    const int rc = upload_noise_jobs(l);
+    if (rc != RB_OK) return rc;
+  }
   *out = l;
   return RB_OK;
 }
@@ -1402,20 +1409,36 @@ static NoiseMap noise_map(const Layout& L) {
   const int64_t counts[8] = {L.F, L.H, L.F, L.H, L.H, L.Z, L.H, (int64_t)L.A * L.Z};
   const int64_t dst[8] = {L.h_ein, L.h_eout, L.h_ein + L.F, L.h_eout + L.H, L.z_ein, L.z_eout, L.z_ein + L.H, L.z_eout + L.Z};
   map.seg_begin[0] = 0;
-  for (int i = 0; i < 8; ++i) { map.seg_begin[i + 1] = map.seg_begin[i] + counts[i]; map.dst[i] = dst[i]; }
+  for (int i = 0; i < 8; ++i) { map.seg_begin[i + 1] = map.seg_begin[i] + (int32_t)counts[i]; map.dst[i] = (int32_t)dst[i]; }
   return map;
 }
 
-int rb_learner_noise_job(rb_learner_t* l, int32_t which, rb_noise_job_t* out) {
-  RB_REQUIRE(l && out, "rb_learner_noise_job: NULL argument");
-  RB_REQUIRE(which >= 0 && which <= 2, "rb_learner_noise_job: which must be 0 (online), 1 (target) or 2 (both)");
-  static_assert(sizeof(NoiseJob) <= sizeof(rb_noise_job_t), "rb_noise_job_t too small");
+static NoiseJob make_noise_job(rb_learner* l, int which) {
   NoiseJob j;
   j.noise = which == 1 ? l->n_target : l->n_online;
   j.noise2 = which == 2 ? l->n_target : nullptr;
   j.map = noise_map(l->L);
   j.seed = l->seed; j.ctr = l->noise_ctr;
   j.nblk = (int)rb_div_up(j.map.seg_begin[8], 256); j.nets = which == 2 ? 2 : 1;
+  j.dev = l->job_dev + which;
+  return j;
+}
+// device copies of the three job variants (a hosting kernel reads them through NoiseJob::dev): at creation and whenever the
+// seed changes — never from rb_learner_noise_job, which may be called while a stream is capturing
+static int upload_noise_jobs(rb_learner* l) {
+  if (!l->job_dev) RB_HIP_TRY(hipMalloc((void**)&l->job_dev, 3 * sizeof(NoiseJob)));
+  NoiseJob j[3];
+  for (int which = 0; which < 3; ++which) j[which] = make_noise_job(l, which);
+  RB_HIP_TRY(hipMemcpy(l->job_dev, j, sizeof(j), hipMemcpyHostToDevice));
+  return RB_OK;
+}
+
+int rb_learner_noise_job(rb_learner_t* l, int32_t which, rb_noise_job_t* out) {
+  RB_REQUIRE(l && out, "rb_learner_noise_job: NULL argument");
+  RB_REQUIRE(which >= 0 && which <= 2, "rb_learner_noise_job: which must be 0 (online), 1 (target) or 2 (both)");
+  static_assert(sizeof(NoiseJob) <= sizeof(rb_noise_job_t), "rb_noise_job_t too small");
+  RB_REQUIRE(l->job_dev != nullptr, "rb_learner_noise_job: handle has no device job table");
+  const NoiseJob j = make_noise_job(l, which);
   memset(out, 0, sizeof(*out));
   memcpy(out, &j, sizeof(j));
   return RB_OK;
@@ -1997,7 +2020,7 @@ int rb_learner_set_rng(rb_learner_t* l, uint64_t seed, uint64_t epoch, rb_stream
   const unsigned long long e[2] = {(unsigned long long)epoch, 0ull};
   RB_HIP_TRY(hipMemcpy(l->noise_ctr, e, sizeof(e), hipMemcpyHostToDevice));
   l->seed = seed;
-  return RB_OK;
+  return upload_noise_jobs(l);   // the device copies of the noise jobs carry the seed (callers re-query the host copy)
 }
 
 int rb_learner_set_priority_sink(rb_learner_t* l, rb_replay_t* replay, const int64_t* tree_idx_dev) {

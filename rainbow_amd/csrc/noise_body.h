@@ -5,8 +5,11 @@
 #include "rb_common.h"
 
 struct NoiseMap {
-  int64_t seg_begin[9];   // prefix of draw counts: hv_in, hv_out, ha_in, ha_out, zv_in, zv_out, za_in, za_out
-  int64_t dst[8];         // destination offsets in the noise buffer
+  // 32-bit on purpose: these 17 values live in SGPRs of every kernel that hosts the noise workgroups; as int64 they
+  // pushed k_sample over the SGPR budget (17 spilled -> a private segment -> ~6 us of scratch set-up at BOTH boundaries
+  // of that launch).  Draw counts and noise-buffer offsets are far below 2^31.
+  int32_t seg_begin[9];   // prefix of draw counts: hv_in, hv_out, ha_in, ha_out, zv_in, zv_out, za_in, za_out
+  int32_t dst[8];         // destination offsets in the noise buffer
 };
 
 // f(x) = sign(x) * sqrt(|x|)  (model.py:32-34).  raw == NULL: N(0,1) from Philox + Box-Muller.
@@ -19,8 +22,8 @@ __device__ __forceinline__ void rb_noise_body(float* noise, float* noise2, const
                                               uint64_t seed, unsigned long long* ctr, int blk, int nblk, int net, int nets) {
   const uint64_t epoch = ctr[0] + (uint64_t)net;
   if (net == 1) noise = noise2;
-  const int64_t total = map.seg_begin[8];
-  for (int64_t i = (int64_t)blk * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+  const int total = map.seg_begin[8];
+  for (int i = blk * (int)blockDim.x + (int)threadIdx.x; i < total; i += nblk * (int)blockDim.x) {
     float x;
     if (raw) {
       x = raw[i];
@@ -58,4 +61,6 @@ struct NoiseJob {
   uint64_t seed;
   unsigned long long* ctr;
   int nblk, nets;
+  const NoiseJob* dev;    // device-resident copy of this struct: a hosting kernel takes this pointer (8 bytes of kernel
+                          // arguments instead of 120) and reads the fields inside its noise branch only
 };

@@ -402,10 +402,15 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                  float* weights_out, NoiseJob job, int32_t* fail_count, int32_t lds_top) {
+                                                  float* weights_out, const NoiseJob* job_dev, int32_t* fail_count, int32_t lds_top) {
   if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
-    const int nb = (int)blockIdx.x - 1;
-    rb_noise_body(job.noise, job.noise2, nullptr, job.map, job.seed, job.ctr, nb % job.nblk, job.nblk, nb / job.nblk, job.nets);
+    // the job is read HERE, from device memory: as a by-value kernel argument its 30 SGPRs were live across the sampler
+    // path as well, 17 SGPRs spilled, and the private segment that reserved cost ~6 us of scratch set-up before AND
+    // after this launch (rocprofv3 kernel trace: the only two idle gaps of the step)
+    // (field by field, the map by reference: a local copy of the struct would be a dynamically indexed stack object)
+    const int nb = (int)blockIdx.x - 1, nblk = job_dev->nblk;
+    rb_noise_body(job_dev->noise, job_dev->noise2, nullptr, job_dev->map, job_dev->seed, job_dev->ctr, nb % nblk, nblk, nb / nblk,
+                  job_dev->nets);
     return;
   }
   __shared__ int s_flag[16];
@@ -833,7 +838,7 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   unsigned blocks = 1;
   if (noise_job) {
     memcpy(&job, noise_job, sizeof(job));
-    RB_REQUIRE(job.noise && job.ctr && job.nblk > 0 && job.nets >= 1, "rb_replay_sample_fused_noise: empty noise job");
+    RB_REQUIRE(job.noise && job.ctr && job.nblk > 0 && job.nets >= 1 && job.dev, "rb_replay_sample_fused_noise: empty noise job");
     blocks += (unsigned)(job.nblk * job.nets);
   }
   // RB_SAMPLER=global searches without the LDS-staged tree top (A/B switch).  Measured on MI355X, back-to-back launches,
@@ -842,11 +847,11 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   static const int lds_top = (getenv("RB_SAMPLER") && !strcmp(getenv("RB_SAMPLER"), "global")) ? 0 : 1;
   if (threads <= 256) {
     RB_LAUNCH_T("sample:k_sample", k_sample<256>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host, lds_top);
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, r->fail_host, lds_top);
   } else {
     RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: batch > 256 supports history + multi_step <= 24");
     RB_LAUNCH_T("sample:k_sample", k_sample<1024>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job, r->fail_host, lds_top);
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, r->fail_host, lds_top);
   }
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
