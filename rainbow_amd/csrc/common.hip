@@ -41,9 +41,16 @@ void rb_prof_end(hipStream_t stream) { (void)hipEventRecord(g_prof_events[g_prof
 #include <chrono>
 #include <map>
 #include <string>
-static std::map<std::string, std::pair<double, long>> g_host_time;
+struct HostT { double in_launch = 0, before = 0; long n = 0; };
+static std::map<std::string, HostT> g_host_time;
+static double g_host_last_end = 0;
 double rb_host_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-void rb_host_time_add(const char* tag, double us) { auto& e = g_host_time[tag]; e.first += us; e.second += 1; }
+void rb_host_time_add(const char* tag, double us, double t0) {
+  auto& e = g_host_time[tag];
+  e.in_launch += us; e.n += 1;
+  if (g_host_last_end > 0) e.before += t0 - g_host_last_end;     // host time since the previous launch returned
+  g_host_last_end = t0 + us;
+}
 __global__ void k_debug_spin(long long cycles, float* out) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < cycles) {}
@@ -63,8 +70,10 @@ extern "C" int rb_debug_spin_launch(void* stream, int n, int us) {
   return 0;
 }
 extern "C" int rb_debug_host_timing(int reset) {
-  if (reset) { g_host_time.clear(); return 0; }
-  for (auto& kv : g_host_time) printf("  host %-40s n %7ld  mean %7.2f us\n", kv.first.c_str(), kv.second.second, kv.second.first / kv.second.second);
+  if (reset) { g_host_time.clear(); g_host_last_end = 0; return 0; }
+  for (auto& kv : g_host_time)
+    printf("  host %-34s n %6ld  in launch %7.2f us   since previous launch returned %7.2f us\n", kv.first.c_str(), kv.second.n,
+           kv.second.in_launch / kv.second.n, kv.second.before / kv.second.n);
   return 0;
 }
 #endif

@@ -23,13 +23,13 @@ extern int g_rb_prof_on;
 // RB_LAUNCH_T: same, with an explicit profiling tag (a kernel used for several layers gets one tag per layer)
 // RB_HOST_TIMING builds: host time spent inside each launch call, per tag (rb_debug_host_timing, common.hip)
 #if defined(RB_HOST_TIMING)
-void rb_host_time_add(const char* tag, double us);
+void rb_host_time_add(const char* tag, double us, double t0);
 double rb_host_now_us();
 #define RB_LAUNCH_T(tag, kern, grid, block, stream, ...)                                        \
   do {                                                                                          \
     const double rb_t0_ = rb_host_now_us();                                                     \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__);           \
-    rb_host_time_add(tag, rb_host_now_us() - rb_t0_);                                           \
+    rb_host_time_add(tag, rb_host_now_us() - rb_t0_, rb_t0_);                                   \
   } while (0)
 #else
 #define RB_LAUNCH_T(tag, kern, grid, block, stream, ...)                                        \

@@ -52,6 +52,7 @@ uint64_t* wave_slots(int which);  // 64 x 8-byte exchange slots, which in {0,1}
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
+inline void __threadfence_system() {}
 
 // ---- minimal HIP runtime surface (device memory == host memory) ----------------
 typedef int hipError_t;

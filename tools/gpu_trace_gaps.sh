@@ -19,9 +19,24 @@ for i in range(lo + 1, hi + 1):
     name = r["Kernel_Name"].split("(")[0][:48] + ("|" + str(r.get("Grid_Size") or r.get("Grid_Size_X")) if "k_nl_" in r["Kernel_Name"] else "")
     dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     gap[name].append((int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / 1e3)
+# the PER-only phase of bench.py (k_sample / k_update alternate, no learner): the same statistics
+pidx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_update")]
+if len(pidx) > 100:
+    d2 = collections.defaultdict(list); g2 = collections.defaultdict(list)
+    for i in range(pidx[50], pidx[-50]):
+        r, p = rows[i], rows[i - 1]
+        name = "PER phase: " + r["Kernel_Name"].split("(")[0][:40]
+        d2[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        g2[name].append((int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / 1e3)
+    for k in d2:
+        print("%-60s n %5d  dur %7.2f us  gap-before %6.2f us" % (k, len(d2[k]), sum(d2[k]) / len(d2[k]), sum(g2[k]) / len(g2[k])))
 tot = 0
 for k in dur:
     d, g = sum(dur[k]) / len(dur[k]), sum(gap[k]) / len(gap[k])
     print("%-60s n/step %.1f  dur %7.2f us  gap-before %6.2f us" % (k, len(dur[k]) / 40.0, d, g))
+print("columns:", list(rows[0].keys()))
+for i in range(hi - 15, hi + 1):
+    r = rows[i]
+    print({k: r[k] for k in r if k in ("Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Agent_Id", "Correlation_Id", "Private_Segment_Size", "LDS_Block_Size", "Scratch_Size")}, r["Kernel_Name"][:30])
 PY
 rm -rf gpurun_out/gaps
