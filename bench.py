@@ -102,13 +102,21 @@ def kernel_table(cfg, n_params):
     F = conv[-1][1] * conv[-1][5] ** 2
     wh = 2 * H * F * 4                      # one of mu / sigma of the fused hidden layer, bytes
     fused_dw = os.environ.get("RAINBOW_AMD_FUSED_DW", "0") == "1" and B <= 32   # fc_h weight gradient never stored
+    def binding(nbytes, flops):
+        """The roofline that binds a streamed noisy-linear launch: HBM at batch 32 (weights streamed once for a rank-32
+        product), f32 MFMA at batch 256 (the same bytes carry 8x the FLOPs)."""
+        if nbytes / (HBM_PEAK_GBS * 1e9) >= flops / (F32_MFMA_PEAK_TF * 1e12):
+            return dict(bound="hbm", work=nbytes, unit="GB/s")
+        return dict(bound="mfma", work=flops, unit="TFLOP/s")
+
     t = {
         # clip + Adam over the flat buffers: reads p, g, m, v and writes p, m, v once (fused: no g read for the fc_h weights)
         "clip_adam": dict(bound="hbm", work=7 * 4 * n_params - (2 * wh if fused_dw else 0), unit="GB/s"),
-        # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident
-        "fc_h_fwd": dict(bound="hbm", work=2 * 2 * wh + 3 * B * F * 4 + 3 * B * 2 * H * 4 * 2, unit="GB/s"),
-        # hidden layer backward (one launch): streams mu+sigma of the online net once (dX), writes d_mu + d_sigma once (dW)
-        "fc_h_bwd": dict(bound="hbm", work=2 * wh + (0 if fused_dw else 2 * wh) + B * (F + 2 * H) * 4, unit="GB/s"),
+        # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident; 3B rows x F x 2H MACs
+        "fc_h_fwd": binding(2 * 2 * wh + 3 * B * F * 4 + 3 * B * 2 * H * 4 * 2, 2 * 3 * B * F * 2 * H),
+        # hidden layer backward (one launch): streams mu+sigma of the online net once (dX), writes d_mu + d_sigma once (dW);
+        # dW and dX are B x F x 2H MACs each
+        "fc_h_bwd": binding(2 * wh + (0 if fused_dw else 2 * wh) + B * (F + 2 * H) * 4, 2 * 2 * B * F * 2 * H),
     }
     dw = 0
     for i, (cin, cout, ks, _s, _ih, oh) in enumerate(conv):
