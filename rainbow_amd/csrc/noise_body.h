@@ -5,9 +5,8 @@
 #include "rb_common.h"
 
 struct NoiseMap {
-  // 32-bit on purpose: these 17 values live in SGPRs of every kernel that hosts the noise workgroups; as int64 they
-  // pushed k_sample over the SGPR budget (17 spilled -> a private segment -> ~6 us of scratch set-up at BOTH boundaries
-  // of that launch).  Draw counts and noise-buffer offsets are far below 2^31.
+  // 32-bit on purpose: these 17 values live in SGPRs of every kernel that hosts the noise workgroups (as int64 they
+  // helped push k_sample over the SGPR budget).  Draw counts and noise-buffer offsets are far below 2^31.
   int32_t seg_begin[9];   // prefix of draw counts: hv_in, hv_out, ha_in, ha_out, zv_in, zv_out, za_in, za_out
   int32_t dst[8];         // destination offsets in the noise buffer
 };

@@ -405,8 +405,7 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
                                                   float* weights_out, const NoiseJob* job_dev, int32_t* fail_count, int32_t lds_top) {
   if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
     // the job is read HERE, from device memory: as a by-value kernel argument its 30 SGPRs were live across the sampler
-    // path as well, 17 SGPRs spilled, and the private segment that reserved cost ~6 us of scratch set-up before AND
-    // after this launch (rocprofv3 kernel trace: the only two idle gaps of the step)
+    // path as well, 17 SGPRs spilled and the kernel carried a private segment (no kernel of the step may: DESIGN.md §6)
     // (field by field, the map by reference: a local copy of the struct would be a dynamically indexed stack object)
     const int nb = (int)blockIdx.x - 1, nblk = job_dev->nblk;
     rb_noise_body(job_dev->noise, job_dev->noise2, nullptr, job_dev->map, job_dev->seed, job_dev->ctr, nb % nblk, nblk, nb / nblk,
