@@ -277,3 +277,71 @@ def test_projection_known_answers(emu, monkeypatch):
         want[hi] += b - lo
         np.testing.assert_allclose(m[i], want, rtol=0, atol=2e-6)
     ad.close()
+
+
+def test_train_step_entry_point_equals_its_three_calls(emu):
+    """rb_learner_train_step (what Agent.learn calls: sampler + noise tenant, zero-copy learn, clip + Adam, priority
+    write-back through the sink) against the same three entry points issued one by one on a twin replay / twin learner:
+    three consecutive steps, device RNG for the sampler and the noise, everything bit-identical — batch, loss, parameters,
+    Adam moments, noise buffers and the sum-tree."""
+    import ctypes as C
+    from cabi_adapter import CAbiReplayAdapter
+    from rainbow_amd import _lib as L
+    name = "dataeff"
+    c = scenarios.LEARN_CONFIGS[name]
+    B, h, n = c["batch"], c["history"], c["multi_step"]
+    hy = scenarios.LEARN_HYPER
+
+    def build():
+        mem = NumpyMem()
+        rp = CAbiReplayAdapter(emu, mem, 512, h, n, c["discount"], 0.5)
+        rs = np.random.RandomState(5)
+        for _ in range(600):
+            rp.append(scenarios.synth_state(rs, h, 0), int(rs.randint(0, c["actions"])), float(rs.choice([-1.0, 0.0, 1.0])),
+                      bool(rs.random_sample() < 0.05))
+        ad = CAbiLearnAdapter(emu, mem, name)
+        cfg = O.Config(**c)
+        ad.load(O.init_params(cfg, 1), O.init_params(cfg, 2))
+        ad.reset_noise_online(rs.randn(O.noise_draw_count(cfg)).astype(np.float32))
+        out = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
+                   nonterm=mem.empty((B,), np.float32), weights=mem.empty((B,), np.float32), loss=mem.empty((B,), np.float32),
+                   norm=mem.empty((1,), np.float32))
+        L.check(emu, emu.rb_learner_set_priority_sink(ad.h, rp.h, mem.ptr(out["tree_idx"])))
+        job = L.NoiseJob()
+        L.check(emu, emu.rb_learner_noise_job(ad.h, 1, C.byref(job)))
+        return mem, rp, ad, out, job
+
+    def snapshot(mem, rp, ad, out):
+        return dict(idx=mem.download(out["tree_idx"]).copy(), loss=mem.download(out["loss"]).copy(),
+                    w=mem.download(out["weights"]).copy(), params=mem.download(ad.p_on).copy(),
+                    m=mem.download(ad.adam_m).copy(), v=mem.download(ad.adam_v).copy(), noise=mem.download(ad.z_tg).copy(),
+                    tree=rp.tree().copy(), norm=mem.download(out["norm"]).copy())
+
+    mem1, rp1, ad1, o1, job1 = build()
+    mem2, rp2, ad2, o2, job2 = build()
+    for step in range(1, 4):
+        beta = 0.4 + 0.1 * step
+        ts = L.TrainStep(replay=rp1.h, batch=B, max_attempts=64, window_len=rp1.bufs.window_len, priority_weight=beta,
+                         tree_idx_dev=mem1.ptr(o1["tree_idx"]), actions_dev=mem1.ptr(o1["actions"]), returns_dev=mem1.ptr(o1["returns"]),
+                         nonterminals_dev=mem1.ptr(o1["nonterm"]), weights_dev=mem1.ptr(o1["weights"]),
+                         noise_job=C.addressof(job1), frames_dev=rp1.bufs.frames_dev, windows_dev=rp1.bufs.window_dev,
+                         loss_dev=mem1.ptr(o1["loss"]), exp_avg_dev=mem1.ptr(ad1.adam_m), exp_avg_sq_dev=mem1.ptr(ad1.adam_v),
+                         norm_dev=mem1.ptr(o1["norm"]), lr=hy["lr"], beta1=0.9, beta2=0.999, eps=hy["adam_eps"], step=step,
+                         max_norm=hy["norm_clip"])
+        L.check(emu, emu.rb_learner_train_step(ad1.h, C.byref(ts), None))
+        assert emu.rb_learner_priority_written(ad1.h) == 1
+        # twin: the three entry points, one by one
+        L.check(emu, emu.rb_replay_sample_fused_noise(rp2.h, B, beta, None, 64, mem2.ptr(o2["tree_idx"]), None, None,
+                                                     mem2.ptr(o2["actions"]), mem2.ptr(o2["returns"]), mem2.ptr(o2["nonterm"]),
+                                                     mem2.ptr(o2["weights"]), C.byref(job2), None))
+        L.check(emu, emu.rb_learner_learn_windows(ad2.h, rp2.bufs.frames_dev, rp2.bufs.window_dev, rp2.bufs.window_len,
+                                                  mem2.ptr(o2["actions"]), mem2.ptr(o2["returns"]), mem2.ptr(o2["nonterm"]),
+                                                  mem2.ptr(o2["weights"]), mem2.ptr(o2["loss"]), None))
+        L.check(emu, emu.rb_learner_clip_adam(ad2.h, hy["norm_clip"], mem2.ptr(ad2.adam_m), mem2.ptr(ad2.adam_v), hy["lr"], 0.9,
+                                              0.999, hy["adam_eps"], step, mem2.ptr(o2["norm"]), None))
+        a, b = snapshot(mem1, rp1, ad1, o1), snapshot(mem2, rp2, ad2, o2)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (step, k)
+        assert rp1.raw_header().last_status == 0
+    assert not np.array_equal(a["params"], ad1._flat(O.init_params(O.Config(**c), 1))), "the online net must have moved"
+    ad1.close(); ad2.close(); rp1.close(); rp2.close()
