@@ -78,6 +78,16 @@ __device__ __forceinline__ int rb_mfma_row(int reg, int lane) { return (reg & 3)
 #define RB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// +1 on a word the HOST reads (pinned, device-mapped memory): a system-scope atomic — a global instruction when `p` is a
+// kernel argument (a volatile read-modify-write through it was compiled to FLAT loads/stores)
+__device__ __forceinline__ void rb_atomic_inc_system(int32_t* p) {
+#if defined(RB_HOST_INTERP)
+  *p = *p + 1;
+#else
+  (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
 // 16-byte global/LDS accesses (pointers must be 16-byte aligned)
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -402,14 +402,16 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                  float* weights_out, const NoiseJob* job_dev, int32_t* fail_count, int32_t lds_top) {
+                                                  float* weights_out, const NoiseJob* job_dev, float* job_noise, float* job_noise2,
+                                                  unsigned long long* job_ctr, int32_t* fail_count, int32_t lds_top) {
   if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
-    // the job is read HERE, from device memory: as a by-value kernel argument its 30 SGPRs were live across the sampler
-    // path as well, 17 SGPRs spilled and the kernel carried a private segment (no kernel of the step may: DESIGN.md §6)
+    // the job's SCALARS are read here, from device memory: as a by-value kernel argument its 30 SGPRs were live across the
+    // sampler path as well, 17 SGPRs spilled and the kernel carried a private segment (no kernel of the step may: DESIGN.md
+    // §6).  Its three POINTERS stay kernel arguments: a pointer loaded from memory is a generic pointer and every access
+    // through it a FLAT instruction — this was the only kernel of the library with flat instructions.
     // (field by field, the map by reference: a local copy of the struct would be a dynamically indexed stack object)
     const int nb = (int)blockIdx.x - 1, nblk = job_dev->nblk;
-    rb_noise_body(job_dev->noise, job_dev->noise2, nullptr, job_dev->map, job_dev->seed, job_dev->ctr, nb % nblk, nblk, nb / nblk,
-                  job_dev->nets);
+    rb_noise_body(job_noise, job_noise2, nullptr, job_dev->map, job_dev->seed, job_ctr, nb % nblk, nblk, nb / nblk, job_dev->nets);
     return;
   }
   __shared__ int s_flag[16];
@@ -502,7 +504,9 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
     v.hdr->last_attempts = attempts_used;
     v.hdr->last_status = ok ? 0 : 1;
     if (!unit_uniforms) v.hdr->rng_counter = rng_base + (uint64_t)attempts_used;
-    if (!ok && fail_count) *(volatile int32_t*)fail_count = *(volatile int32_t*)fail_count + 1;
+    // (a system-scope atomic on the kernel-argument pointer: a global instruction; the former volatile read-modify-write was
+    // compiled to flat loads/stores)
+    if (!ok && fail_count) rb_atomic_inc_system(fail_count);
   }
   RB_STAMP_AT(5);
 }
@@ -846,11 +850,11 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   static const int lds_top = (getenv("RB_SAMPLER") && !strcmp(getenv("RB_SAMPLER"), "global")) ? 0 : 1;
   if (threads <= 256) {
     RB_LAUNCH_T("sample:k_sample", k_sample<256>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, r->fail_host, lds_top);
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top);
   } else {
     RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: batch > 256 supports history + multi_step <= 24");
     RB_LAUNCH_T("sample:k_sample", k_sample<1024>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, r->fail_host, lds_top);
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top);
   }
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
