@@ -78,13 +78,15 @@ __device__ __forceinline__ int rb_mfma_row(int reg, int lane) { return (reg & 3)
 #define RB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-// +1 on a word the HOST reads (pinned, device-mapped memory): a system-scope atomic — a global instruction when `p` is a
-// kernel argument (a volatile read-modify-write through it was compiled to FLAT loads/stores)
+// +1 on a word the HOST reads (pinned, device-mapped memory), by its only writer: a system-scope atomic load and store —
+// global instructions when `p` is a kernel argument (a volatile read-modify-write through it was compiled to FLAT
+// loads/stores), and no read-modify-write travels over PCIe
 __device__ __forceinline__ void rb_atomic_inc_system(int32_t* p) {
 #if defined(RB_HOST_INTERP)
   *p = *p + 1;
 #else
-  (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int32_t c = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(p, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
 
