@@ -232,3 +232,39 @@ def learn_scenario(backend, name, oracle_mod, steps=None):
     trace["q_noisy"] = np.float32(q_noisy)
     trace["q_eval"] = np.float32(q_eval)
     return trace
+
+
+def sampler_gives_up_check(lib, mem):
+    """A ring too small for the batch (stratum 0 lies inside the write head's exclusion zone) has NO valid batch; the
+    reference would spin forever (memory.py:128-132).  The bounded device loop must then emit zero importance weights
+    (zero-gradient step, no inf/NaN from a zero-priority leaf), flag the header and count the failure in the pinned host
+    word.  Shared by the emulator test and the GPU test (`mem` = NumpyMem / TorchMem)."""
+    import ctypes as C
+    from cabi_adapter import CAbiReplayAdapter
+    from rainbow_amd import _lib as L
+    ad = CAbiReplayAdapter(lib, mem, 16, 4, 3, 0.99, 0.5)
+    rs = np.random.RandomState(0)
+    for _ in range(16):
+        ad.append(synth_state(rs, 4, 0), 1, 0.0, False)
+    B, attempts = 8, 12
+    uu = mem.upload(rs.random_sample((attempts, B)))
+    outs = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
+                nonterm=mem.empty((B,), np.float32), weights=mem.upload(np.full(B, 7.0, np.float32)))
+    n0 = C.c_int64(-1)
+    L.check(lib, lib.rb_replay_failed_samples(ad.h, C.byref(n0)))
+    assert n0.value == 0
+    for k in range(2):
+        L.check(lib, lib.rb_replay_sample(ad.h, B, 0.5, mem.ptr(uu), attempts, mem.ptr(outs["tree_idx"]), None, None,
+                                          mem.ptr(outs["actions"]), mem.ptr(outs["returns"]), mem.ptr(outs["nonterm"]),
+                                          mem.ptr(outs["weights"]), mem.stream))
+        mem.sync()
+        hdr = ad.raw_header()
+        assert hdr.last_status == 1 and hdr.last_attempts == attempts
+        assert np.array_equal(mem.download(outs["weights"]), np.zeros(B, np.float32))
+        L.check(lib, lib.rb_replay_failed_samples(ad.h, C.byref(n0)))
+        assert n0.value == k + 1
+    # the host mirror of the write position needs no device round trip and follows a raw header restore
+    idx, full = C.c_int64(-1), C.c_int32(-1)
+    L.check(lib, lib.rb_replay_position(ad.h, C.byref(idx), C.byref(full)))
+    assert (idx.value, full.value) == (0, 1)
+    return ad

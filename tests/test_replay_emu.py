@@ -93,36 +93,12 @@ def test_create_rejects_what_the_reference_cannot_run(emu):
 
 
 def test_sampler_gives_up_harmlessly(emu):
-    """A ring too small for the batch (stratum 0 lies inside the write head's exclusion zone) has NO valid batch; the
-    reference would spin forever (memory.py:128-132).  The bounded device loop must then emit zero importance weights
-    (zero-gradient step, no inf/NaN from a zero-priority leaf), flag the header and count the failure on the host."""
+    """scenarios.sampler_gives_up_check on the host interpreter (the same check runs on the GPU in test_replay_gpu.py), plus:
+    the host mirror of the write position follows a raw header restore."""
     import ctypes as C
     from rainbow_amd import _lib as L
-    mem = NumpyMem()
-    ad = CAbiReplayAdapter(emu, mem, 16, 4, 3, 0.99, 0.5)
-    rs = np.random.RandomState(0)
-    for _ in range(16):
-        ad.append(scenarios.synth_state(rs, 4, 0), 1, 0.0, False)
-    B, attempts = 8, 12
-    uu = mem.upload(rs.random_sample((attempts, B)))
-    outs = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
-                nonterm=mem.empty((B,), np.float32), weights=mem.upload(np.full(B, 7.0, np.float32)))
-    n0 = C.c_int64(-1)
-    L.check(emu, emu.rb_replay_failed_samples(ad.h, C.byref(n0)))
-    assert n0.value == 0
-    for k in range(2):
-        L.check(emu, emu.rb_replay_sample(ad.h, B, 0.5, mem.ptr(uu), attempts, mem.ptr(outs["tree_idx"]), None, None,
-                                          mem.ptr(outs["actions"]), mem.ptr(outs["returns"]), mem.ptr(outs["nonterm"]),
-                                          mem.ptr(outs["weights"]), None))
-        hdr = ad.raw_header()
-        assert hdr.last_status == 1 and hdr.last_attempts == attempts
-        assert np.array_equal(outs["weights"], np.zeros(B, np.float32))
-        L.check(emu, emu.rb_replay_failed_samples(ad.h, C.byref(n0)))
-        assert n0.value == k + 1
-    # the host mirror of the write position needs no device round trip and follows a raw header restore
+    ad = scenarios.sampler_gives_up_check(emu, NumpyMem())
     idx, full = C.c_int64(-1), C.c_int32(-1)
-    L.check(emu, emu.rb_replay_position(ad.h, C.byref(idx), C.byref(full)))
-    assert (idx.value, full.value) == (0, 1)
     hdr = ad.raw_header()
     hdr.index = 6
     raw = np.frombuffer(bytes(hdr), dtype=np.uint8).copy()

@@ -31,6 +31,13 @@ def test_replay_hip_matches_reference_golden(hip, name):
     ad.close()
 
 
+def test_sampler_gives_up_harmlessly_on_device(hip):
+    """The bounded rejection loop on a ring that has no valid batch: zero importance weights, header flag, and the failure
+    count in the pinned host word the kernel bumps (system-scope load + store) — the emulator runs the same check."""
+    from cabi_adapter import TorchMem
+    scenarios.sampler_gives_up_check(hip, TorchMem()).close()
+
+
 def _args(**kw):
     base = dict(device=torch.device("cuda:0"), history_length=4, discount=0.99, multi_step=3, priority_weight=0.4,
                 priority_exponent=0.5)
