@@ -149,6 +149,9 @@ struct rb_learner {
   float* dfeat_part;    // [xs][B][F]
   int lazy_dfeat;       // this step: the last conv layer's backward kernels sum the partials themselves (no k_dfeat_finish)
   int lazy_splits;
+  // A/B and test switches read ONCE, when the handle is created (not per launch): RB_CONV_MULTI (-1 = by image count),
+  // RB_CONV_FULL, RB_DX_IPB (0 = by batch), RB_DX_WT
+  int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_dx_wt;
   float* dw_part[3];    // [ws_l][cout][K+1]
   float* log_ps_a;      // [B][Z]
   float* pns_a;         // [B][Z]
@@ -860,20 +863,19 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.ipb = 1;
   static const char* const tags[3] = {"conv1_fwd:k_conv_fwd_lds", "conv2_fwd:k_conv_fwd_lds", "conv3_fwd:k_conv_fwd_lds"};
   // large batches: one round of workgroups, each keeping its weight slab for ipb images of one net (conv_lds.h)
-  const char* multi_s = getenv("RB_CONV_MULTI");                         // A/B / test switch: images per workgroup (0 = off)
+  const bool multi_forced = l->opt_conv_multi >= 0;                      // RB_CONV_MULTI: images per workgroup (0 = off)
   int ipb = 0;
-  if (multi_s) ipb = atoi(multi_s);
+  if (multi_forced) ipb = l->opt_conv_multi;
   else if (n_on + n_tg >= 256) {
     const int per_img = (int)(rb_div_up(G::P, PCH) * rb_div_up(c.cout, 32));
     ipb = (int)rb_div_up((int64_t)(n_on + n_tg) * per_img, 256);
   }
   if constexpr (FIRST && ConvFwdFullLds<G, KMAX>::FITS) {
     // first layer: whole image per workgroup, whole reduction per wave (RB_CONV_FULL=0: the chunked kernel below)
-    const char* full_s = getenv("RB_CONV_FULL");
-    const bool full_off = full_s && full_s[0] == '0';
+    const bool full_off = !l->opt_conv_full;
     if (ipb > 0 && !src.f32 && c.cout <= 32 && !a.out_blocked && !full_off && c.cin * G::KK == KMAX && (KMAX & 1) == 0) {
       int fi = ipb;
-      if (!multi_s) fi = (int)rb_div_up(n_on + n_tg, 256);              // one round of workgroups
+      if (!multi_forced) fi = (int)rb_div_up(n_on + n_tg, 256);         // one round of workgroups
       a.ipb = fi;
       RB_LAUNCH_T(tags[layer], (k_conv_fwd_full<G, KMAX>), dim3(1, 1, (unsigned)rb_div_up(n_on + n_tg, fi)),
                   dim3(RB_CONV_THREADS), stream, a);
@@ -1099,18 +1101,14 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     const unsigned groups = (unsigned)rb_div_up(NT_ALL, NT);
     static const char* const tags[3] = {"conv1_dx:k_conv_dx_lds", "conv2_dx:k_conv_dx_lds", "conv3_dx:k_conv_dx_lds"};
     // batches of 64 and more: about one round of workgroups over the chip, each keeping its weight slab for ipb images
-    const char* ipb_s = getenv("RB_DX_IPB");                                      // A/B / test switch (1 = one image each)
-    const int ipb_env = ipb_s ? atoi(ipb_s) : 0;
+    const int ipb_env = l->opt_dx_ipb;                                            // RB_DX_IPB (1 = one image each)
     const int per_img = (G::S * G::S) * (int)groups * (int)rb_div_up(c.cin, 32);
     int ipb = 1;
     if (ipb_env > 0) ipb = ipb_env;
     else if (L.B >= 64)                               // ONE round of workgroups (their LDS footprint allows one per CU)
       while (per_img * (int)rb_div_up(L.B, ipb) > 256) ++ipb;
     a.ipb = ipb; a.batch = L.B;
-    {
-      const char* wt_s = getenv("RB_DX_WT");                               // A/B switch
-      a.wt = wt_s ? atoi(wt_s) : 0;                  // measured slower (batch 256: 45 -> 53 us): off
-    }
+    a.wt = l->opt_dx_wt;
     const dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
     if (ipb > 1) {
       if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
@@ -1326,6 +1324,11 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   {
     const char* generic_fc = getenv("RB_GENERIC_FC");             // A/B switch: only the noisy-linear layers fall back
     if (generic_fc && generic_fc[0] == '1') l->fast_fc = 0;
+    const char* e;
+    l->opt_conv_multi = (e = getenv("RB_CONV_MULTI")) ? atoi(e) : -1;
+    l->opt_conv_full = (e = getenv("RB_CONV_FULL")) ? (e[0] != '0') : 1;
+    l->opt_dx_ipb = (e = getenv("RB_DX_IPB")) ? atoi(e) : 0;
+    l->opt_dx_wt = (e = getenv("RB_DX_WT")) ? atoi(e) : 0;      // measured slower (batch 256: 45 -> 53 us): off
   }
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
