@@ -244,6 +244,10 @@ def main():
     ap.add_argument("--roofline-kernel", default="auto",
                     help="profiling tag of the kernel the roofline object reports (default: the dominant one, measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="no HIP-event brackets anywhere (no roofline objects): the run a rocprofv3 kernel trace should see — an "
+                         "event record is a system-scope barrier packet and shows as ~6 us of idle GPU on both sides of the "
+                         "bracketed launch (tools/gpu_trace_gaps.sh)")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
     ap.add_argument("--extra-tags", default="", help="comma-separated extra profiling tags to time (bytes unknown: time only)")
     ap.add_argument("--graph", action="store_true",
@@ -313,12 +317,14 @@ def main():
     ktab = kernel_table(cfg, int(agent.params.numel()))
     # the kernel the roofline object reports = the step's DOMINANT kernel by time, found by a short bracketed pass over
     # every candidate before the timed region (or forced with --roofline-kernel)
-    if opt.roofline_kernel in ktab:
+    if opt.no_profile:
+        kname = None
+    elif opt.roofline_kernel in ktab:
         kname = opt.roofline_kernel
     else:
         probe = {k: bracketed(k, 30)[0] for k in ktab}
         kname = max((k for k in probe if probe[k] is not None), key=lambda k: probe[k])
-    lib.rb_profile_select(kname.encode())
+    lib.rb_profile_select(kname.encode() if kname else None)
     lib.rb_profile_stride(PROFILE_STRIDE)       # 1 launch in 8 is bracketed inside the timed region
     if world > 1 or force_dist:
         torch.distributed.barrier()
@@ -348,7 +354,7 @@ def main():
     # every other candidate, each timed the same way in a short pass of its own AFTER the timed region
     others = {}
     for other in ktab:
-        if other != kname:
+        if other != kname and not opt.no_profile:
             t, n = bracketed(other, min(200, opt.steps))
             if t is not None:
                 others[other] = (t, n)

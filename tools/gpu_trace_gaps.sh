@@ -1,10 +1,13 @@
 # usage: bash tools/gpu_trace_gaps.sh <config>: rocprofv3 kernel trace of a short bench run; per kernel of the learn step the
-# mean duration and the mean idle gap between the previous kernel's end and its start (steady-state steps only)
+# mean duration and the mean idle gap between the previous kernel's end and its start (steady-state steps only).
+# bench.py runs with --no-profile: a bracketed launch (HIP event records = system-scope barrier packets) shows ~6 us of idle
+# GPU on both sides, and the LAST steps of a default bench run are its bracketed roofline_others passes (round 2 read those
+# as 'two idle gaps at the sampler launch': the sampler was simply the last tag bracketed)
 CFG=$1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT=$PWD
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/gaps -o gaps -- python $ROOT/bench.py --config $CFG --steps 60 --warmup 20 --no-cpu-baseline --roofline-kernel clip_adam > $ROOT/gpurun_out/gaps.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/gaps -o gaps -- python $ROOT/bench.py --config $CFG --steps 60 --warmup 20 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/gaps.log 2>&1
 cd $ROOT
 python - <<'PY'
 import csv, glob, collections
