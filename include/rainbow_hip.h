@@ -66,6 +66,11 @@ int rb_profile_read(double* total_ms, int64_t* launches);
 /* Cost of an event pair with NOTHING between them on `stream` (mean of n pairs, ms): what the
  * bracketing itself adds to every rb_profile_read sample.  Blocks until the stream drains.     */
 int rb_profile_overhead(rb_stream_t stream, int32_t n, double* mean_ms);
+/* Test hook (no reference counterpart).  With RB_GUARD=1 in the environment when the library is loaded, every device
+ * allocation the library owns (replay ring, sum-tree, learner workspaces) sits between two 4 KiB guard bands; this call
+ * synchronises the device and reports how many blocks are live and how many have a band that a kernel wrote into
+ * (tests/test_guard_gpu.py).  Without RB_GUARD it reports 0 / 0.                                                     */
+int rb_debug_check_guards(int64_t* n_blocks, int64_t* n_bad);
 
 /* ===================================================================== replay ==
  * HBM-resident prioritised replay: SoA ring (frames u8[C][7056], timestep i32[C],

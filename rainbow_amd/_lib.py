@@ -62,6 +62,7 @@ SIGNATURES = {
     "rb_profile_stride": (c_int, [c_int32]),
     "rb_profile_read": (c_int, [C.POINTER(c_double), C.POINTER(c_int64)]),
     "rb_profile_overhead": (c_int, [c_void_p, c_int32, C.POINTER(c_double)]),
+    "rb_debug_check_guards": (c_int, [C.POINTER(c_int64), C.POINTER(c_int64)]),
     "rb_replay_create": (c_int, [C.POINTER(c_void_p), c_int64, c_int32, c_int32, c_double, c_double, c_uint64]),
     "rb_replay_destroy": (c_int, [c_void_p]),
     "rb_replay_buffers": (c_int, [c_void_p, C.POINTER(ReplayBuffers)]),

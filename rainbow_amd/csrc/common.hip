@@ -78,6 +78,44 @@ extern "C" int rb_debug_host_timing(int reset) {
 }
 #endif
 
+// ---- guarded device allocations (rb_common.h) -----------------------------------------
+#include <stdlib.h>
+#include <vector>
+#define RB_GUARD_BYTES 4096
+#define RB_GUARD_FILL 0xC5
+struct GuardedBlock { char* raw; char* user; size_t bytes; };
+static std::vector<GuardedBlock> g_guarded;
+static int guard_on() {
+  static const int on = getenv("RB_GUARD") && getenv("RB_GUARD")[0] == '1';
+  return on;
+}
+hipError_t rb_dev_malloc(void** p, size_t bytes) {
+  if (!guard_on()) return hipMalloc(p, bytes);
+  const size_t padded = (bytes + 255) / 256 * 256;             // keep the user block's end 256-byte aligned like its start
+  char* raw = nullptr;
+  hipError_t e = hipMalloc((void**)&raw, padded + 2 * RB_GUARD_BYTES);
+  if (e != hipSuccess) return e;
+  e = hipMemset(raw, RB_GUARD_FILL, padded + 2 * RB_GUARD_BYTES);   // guards AND the alignment tail [bytes, padded)
+  if (e != hipSuccess) { (void)hipFree(raw); return e; }
+  if (bytes) {
+    e = hipMemset(raw + RB_GUARD_BYTES, 0, bytes);
+    if (e != hipSuccess) { (void)hipFree(raw); return e; }
+  }
+  g_guarded.push_back(GuardedBlock{raw, raw + RB_GUARD_BYTES, bytes});
+  *p = raw + RB_GUARD_BYTES;
+  return hipSuccess;
+}
+void rb_dev_free(void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < g_guarded.size(); ++i)
+    if (g_guarded[i].user == (char*)p) {
+      (void)hipFree(g_guarded[i].raw);
+      g_guarded.erase(g_guarded.begin() + (long)i);
+      return;
+    }
+  (void)hipFree(p);
+}
+
 void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nbytes);   // replay.hip
 
 extern "C" {
@@ -143,6 +181,29 @@ int rb_profile_overhead(rb_stream_t stream, int32_t n, double* mean_ms) {
 #else
   (void)stream;
 #endif
+  return RB_OK;
+}
+
+int rb_debug_check_guards(int64_t* n_blocks, int64_t* n_bad) {
+  RB_REQUIRE(n_blocks && n_bad, "rb_debug_check_guards: NULL argument");
+  *n_blocks = (int64_t)g_guarded.size();
+  *n_bad = 0;
+  if (!guard_on()) return RB_OK;
+  RB_HIP_TRY(hipDeviceSynchronize());
+  std::vector<unsigned char> lo(RB_GUARD_BYTES), hi;
+  for (const GuardedBlock& b : g_guarded) {
+    const size_t padded = (b.bytes + 255) / 256 * 256;
+    hi.resize(padded - b.bytes + RB_GUARD_BYTES);
+    RB_HIP_TRY(hipMemcpy(lo.data(), b.raw, RB_GUARD_BYTES, hipMemcpyDeviceToHost));
+    RB_HIP_TRY(hipMemcpy(hi.data(), b.user + b.bytes, hi.size(), hipMemcpyDeviceToHost));
+    bool bad = false;
+    for (unsigned char c : lo) bad |= c != RB_GUARD_FILL;
+    for (unsigned char c : hi) bad |= c != RB_GUARD_FILL;
+    if (bad) {
+      if (*n_bad == 0) rb_set_error("rb_debug_check_guards: a guard band of the %lld-byte block at %p was overwritten", (long long)b.bytes, (void*)b.user);
+      *n_bad += 1;
+    }
+  }
   return RB_OK;
 }
 

@@ -1278,10 +1278,10 @@ int rb_learner_destroy(rb_learner_t* l) {
                      &l->logits, &l->dlogits, &l->dh, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
                      &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
   for (float** p : owned)
-    if (*p) (void)hipFree(*p);
-  if (l->a_star) (void)hipFree(l->a_star);
-  if (l->noise_ctr) (void)hipFree(l->noise_ctr);
-  if (l->job_dev) (void)hipFree(l->job_dev);
+    if (*p) rb_dev_free(*p);
+  if (l->a_star) rb_dev_free(l->a_star);
+  if (l->noise_ctr) rb_dev_free(l->noise_ctr);
+  if (l->job_dev) rb_dev_free(l->job_dev);
   if (l->ev_fact) (void)hipEventDestroy(l->ev_fact);
   if (l->use_side) {
     for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
@@ -1348,7 +1348,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   }
 #define RB_ALLOC(ptr, count)                                                                         \
   do {                                                                                               \
-    hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(count) * 4);                                  \
+    hipError_t e_ = rb_dev_malloc((void**)&(ptr), (size_t)(count) * 4);                                  \
     if (e_ != hipSuccess) {                                                                          \
       rb_set_error("rb_learner_create: hipMalloc(%lld B) failed: %s", (long long)(count) * 4, hipGetErrorString(e_)); \
       rb_learner_destroy(l);                                                                         \
@@ -1429,7 +1429,7 @@ static NoiseJob make_noise_job(rb_learner* l, int which) {
 // device copies of the three job variants (a hosting kernel reads them through NoiseJob::dev): at creation and whenever the
 // seed changes — never from rb_learner_noise_job, which may be called while a stream is capturing
 static int upload_noise_jobs(rb_learner* l) {
-  if (!l->job_dev) RB_HIP_TRY(hipMalloc((void**)&l->job_dev, 3 * sizeof(NoiseJob)));
+  if (!l->job_dev) RB_HIP_TRY(rb_dev_malloc((void**)&l->job_dev, 3 * sizeof(NoiseJob)));
   NoiseJob j[3];
   for (int which = 0; which < 3; ++which) j[which] = make_noise_job(l, which);
   RB_HIP_TRY(hipMemcpy(l->job_dev, j, sizeof(j), hipMemcpyHostToDevice));
@@ -1522,9 +1522,9 @@ static int ensure_rows(rb_learner* l, int rows) {
   const Layout& L = l->L;
   RB_HIP_TRY(hipDeviceSynchronize());
   auto regrow = [&](float** p, int64_t count) -> int {
-    if (*p) (void)hipFree(*p);
+    if (*p) rb_dev_free(*p);
     *p = nullptr;
-    hipError_t e = hipMalloc((void**)p, (size_t)count * 4);
+    hipError_t e = rb_dev_malloc((void**)p, (size_t)count * 4);
     if (e != hipSuccess) { rb_set_error("rb_learner_act_batch: hipMalloc(%lld B) failed: %s", (long long)count * 4, hipGetErrorString(e)); return RB_ERR_OOM; }
     return RB_OK;
   };

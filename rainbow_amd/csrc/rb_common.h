@@ -35,6 +35,12 @@ void rb_set_error(const char* fmt, ...);
     }                                                                                  \
   } while (0)
 
+// ---- device allocations of the library (workspaces, the replay ring) ---------------
+// hipMalloc / hipFree, except under RB_GUARD=1 (test runs): every block is then surrounded by two 4 KiB guard bands filled
+// with a fixed byte, and rb_debug_check_guards (C ABI) reports any band a kernel has written into.
+hipError_t rb_dev_malloc(void** p, size_t bytes);
+void rb_dev_free(void* p);
+
 static inline int64_t rb_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- Philox4x32-10 counter RNG (device sampler + noise) ------------------------------

@@ -657,7 +657,7 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr; r->fail_host = nullptr;
 #define RB_ALLOC(ptr, bytes)                                                                      \
   do {                                                                                            \
-    hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                                   \
+    hipError_t e_ = rb_dev_malloc((void**)&(ptr), (size_t)(bytes));                                   \
     if (e_ != hipSuccess) {                                                                       \
       rb_set_error("rb_replay_create: hipMalloc(%lld B) failed: %s", (long long)(bytes), hipGetErrorString(e_)); \
       rb_replay_destroy(r);                                                                       \
@@ -702,15 +702,15 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
 int rb_replay_destroy(rb_replay_t* r) {
   if (!r) return RB_OK;
   live_del(r);
-  if (r->tree) (void)hipFree(r->tree);
-  if (r->frames) (void)hipFree(r->frames);
-  if (r->timestep) (void)hipFree(r->timestep);
-  if (r->action) (void)hipFree(r->action);
-  if (r->reward) (void)hipFree(r->reward);
-  if (r->nonterminal) (void)hipFree(r->nonterminal);
-  if (r->hdr) (void)hipFree(r->hdr);
-  if (r->win) (void)hipFree(r->win);
-  if (r->scaling_dev) (void)hipFree(r->scaling_dev);
+  if (r->tree) rb_dev_free(r->tree);
+  if (r->frames) rb_dev_free(r->frames);
+  if (r->timestep) rb_dev_free(r->timestep);
+  if (r->action) rb_dev_free(r->action);
+  if (r->reward) rb_dev_free(r->reward);
+  if (r->nonterminal) rb_dev_free(r->nonterminal);
+  if (r->hdr) rb_dev_free(r->hdr);
+  if (r->win) rb_dev_free(r->win);
+  if (r->scaling_dev) rb_dev_free(r->scaling_dev);
   if (r->fail_host) (void)hipHostFree(r->fail_host);
   delete r;
   return RB_OK;

@@ -269,7 +269,8 @@ class CAbiLearnAdapter:
     grad_hook = None   # e.g. rainbow_amd.dist.average_gradients between backward and clip
     exchange = None    # or a rainbow_amd.dist.FactoredExchange over this handle
 
-    def learn_step(self, batch, target_raw):
+    def learn_only(self, batch, target_raw):
+        """rb_learner_reset_noise(target) + rb_learner_learn: everything of agent.py:61-96 (backward included)."""
         m = self.mem
         B = self.c["batch"]
         r = m.upload(np.asarray(target_raw, dtype=np.float32))
@@ -278,19 +279,17 @@ class CAbiLearnAdapter:
                     actions=m.upload(batch["actions"].astype(np.int64)), returns=m.upload(batch["returns"]),
                     nonterminals=m.upload(batch["nonterminals"].astype(np.float32).reshape(B)),
                     weights=m.upload(batch["weights"]))
-        loss = m.empty((B,), np.float32)
-        norm = m.empty((1,), np.float32)
+        self._loss = m.empty((B,), np.float32)
+        self._bufs = bufs                                    # keep the inputs alive until the stream has consumed them
         L.check(self.lib, self.lib.rb_learner_learn(self.h, m.ptr(bufs["states"]), m.ptr(bufs["next_states"]),
                                                     m.ptr(bufs["actions"]), m.ptr(bufs["returns"]),
-                                                    m.ptr(bufs["nonterminals"]), m.ptr(bufs["weights"]), m.ptr(loss),
+                                                    m.ptr(bufs["nonterminals"]), m.ptr(bufs["weights"]), m.ptr(self._loss),
                                                     m.stream))
-        if self.exchange is not None:       # rainbow_amd.dist.FactoredExchange: FC gradients from all-gathered factors
-            m.sync()
-            self.exchange.run(m.stream)
-        elif self.grad_hook is not None:
-            m.sync()
-            self.grad_hook(self._as_torch(self.grads))
-            L.check(self.lib, self.lib.rb_learner_grads_modified(self.h))
+
+    def finish_step(self):
+        """clip_grad_norm_ + Adam (agent.py:97-98) on whatever the gradient buffer holds now."""
+        m = self.mem
+        norm = m.empty((1,), np.float32)
         if self.fused_adam:
             self.adam_t += 1
             L.check(self.lib, self.lib.rb_learner_clip_adam(self.h, self.hy["norm_clip"], m.ptr(self.adam_m),
@@ -305,7 +304,19 @@ class CAbiLearnAdapter:
             grads = self._unflat(m.download(self.grads))
             self.opt.step()                                                                        # agent.py:98
         m.sync()
-        return dict(loss=m.download(loss), grad_norm=float(m.download(norm)[0]), grads=grads)
+        return dict(loss=m.download(self._loss), grad_norm=float(m.download(norm)[0]), grads=grads)
+
+    def learn_step(self, batch, target_raw):
+        m = self.mem
+        self.learn_only(batch, target_raw)
+        if self.exchange is not None:       # rainbow_amd.dist.FactoredExchange: FC gradients from all-gathered factors
+            m.sync()
+            self.exchange.run(m.stream)
+        elif self.grad_hook is not None:
+            m.sync()
+            self.grad_hook(self._as_torch(self.grads))
+            L.check(self.lib, self.lib.rb_learner_grads_modified(self.h))
+        return self.finish_step()
 
     def debug(self, what, shape, dtype):
         m = self.mem

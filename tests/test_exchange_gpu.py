@@ -1,0 +1,116 @@
+"""GPU parity of BASELINE config 5's exchange kernels on ONE device (no RCCL needed): two learner handles stand for two
+replicas (own batch, own noise, identical parameters); the collectives are replaced by device-side copies — a torch.cat
+for the all-gather of the factor blocks, an elementwise mean for the all-reduce — so that what runs on the GPU is exactly
+rb_learner_learn with the exchange armed (k_pack_factors, deferred FC weight gradients), rb_learner_finish_grads
+(k_finish_grads) and, in the 'allreduce' mode, rb_learner_grads_modified -> k_sumsq, followed by the one-pass clip + Adam.
+Insert point in the reference: between agent.py:96 (backward) and agent.py:97 (clip_grad_norm_).
+Required: both handles bit-identical, and gradients / parameters == the oracle fed with the MEAN gradient."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import scenarios
+from helpers import assert_learn_trace_matches
+from oracle import learner_oracle as O
+from test_learner_gpu import BASELINE_SHAPES
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = ["cfg2-canonical-h512-b32-a6", "cfg4-dataeff-h256-n20-b32-a6"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rainbow_amd import _lib
+    return _lib.load()
+
+
+class PairFactoredExchange:
+    """What rainbow_amd.dist.FactoredExchange does per rank, for two handles in one process."""
+
+    def __init__(self, lib, ads):
+        from rainbow_amd import _lib as L
+        self.lib, self.ads, self.L = lib, ads, L
+        f, off, n = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.check(lib, lib.rb_learner_exchange_layout(ads[0].h, C.byref(f), C.byref(off), C.byref(n)))
+        self.f, self.off, self.n = f.value, off.value, n.value
+        dev = ads[0].grads.device
+        self.local = [torch.zeros(self.f, dtype=torch.float32, device=dev) for _ in ads]
+        self.all = [torch.zeros(len(ads) * self.f, dtype=torch.float32, device=dev) for _ in ads]
+        for ad, lo, al in zip(ads, self.local, self.all):
+            L.check(lib, lib.rb_learner_set_exchange(ad.h, len(ads), lo.data_ptr(), al.data_ptr()))
+
+    def run(self):
+        L, lib = self.L, self.lib
+        stream = self.ads[0].mem.stream
+        for ad in self.ads:
+            L.check(lib, lib.rb_learner_wait_factors(ad.h, stream))
+        gathered = torch.cat(self.local)                       # the all-gather
+        small = [ad.grads[self.off:self.off + self.n] for ad in self.ads]
+        mean = (small[0] + small[1]) / 2                       # the all-reduce (mean) of the conv range
+        for ad, al, sm in zip(self.ads, self.all, small):
+            al.copy_(gathered)
+            sm.copy_(mean)
+            L.check(lib, lib.rb_learner_finish_grads(ad.h, stream))
+
+    def close(self):
+        for ad in self.ads:
+            self.lib.rb_learner_set_exchange(ad.h, 1, None, None)
+
+
+@pytest.mark.parametrize("mode", ["factored", "allreduce"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_replica_exchange_kernels_match_oracle_on_mean_gradient(hip, monkeypatch, shape, mode):
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    from rainbow_amd import _lib as L
+    cfgd = BASELINE_SHAPES[shape]
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
+    cfg = O.Config(**cfgd)
+    hy = scenarios.LEARN_HYPER
+    ads = [CAbiLearnAdapter(hip, TorchMem(), shape) for _ in range(2)]
+    online, target = O.init_params(cfg, 611), O.init_params(cfg, 612)
+    for ad in ads:
+        ad.load(online, target)
+    exch = PairFactoredExchange(hip, ads) if mode == "factored" else None
+    adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
+    draws = O.noise_draw_count(cfg)
+    got_t, want_t = {}, {}
+    for k in range(2):
+        per_rank = []
+        for r, ad in enumerate(ads):
+            rs = np.random.RandomState(100 + 10 * k + r)                 # per-replica noise and data
+            raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+            batch = scenarios.make_batch(cfgd, 200 + 10 * k + r)
+            ad.reset_noise_online(raw_on)
+            ad.learn_only(batch, raw_tg)
+            per_rank.append(O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch))
+        if exch is not None:
+            exch.run()
+        else:
+            mean = (ads[0].grads + ads[1].grads) / 2                     # the flat all-reduce (mean)
+            for ad in ads:
+                ad.grads.copy_(mean)
+                L.check(hip, hip.rb_learner_grads_modified(ad.h))
+        outs = [ad.finish_step() for ad in ads]
+        # replicas: identical bits
+        assert torch.equal(ads[0].grads, ads[1].grads), "step %d: replica gradients differ" % k
+        assert torch.equal(ads[0].p_on.detach(), ads[1].p_on.detach()), "step %d: replica parameters differ" % k
+        assert outs[0]["grad_norm"] == outs[1]["grad_norm"]
+        # oracle on the mean gradient
+        gmean = {n: (per_rank[0]["grads"][n] + per_rank[1]["grads"][n]) / np.float32(2) for n in per_rank[0]["grads"]}
+        total, clipped = O.clip_grads(gmean, hy["norm_clip"])
+        online = adam.step(clipped)
+        for r in range(2):
+            got_t["s%d_r%d_loss" % (k, r)], want_t["s%d_r%d_loss" % (k, r)] = outs[r]["loss"], per_rank[r]["loss"]
+        got_t["s%d_grad_norm" % k], want_t["s%d_grad_norm" % k] = np.float32(outs[0]["grad_norm"]), np.float32(total)
+        for name in clipped:
+            got_t["s%d_grad/%s" % (k, name)], want_t["s%d_grad/%s" % (k, name)] = outs[0]["grads"][name], clipped[name]
+        for name, p in ads[0].params().items():
+            got_t["s%d_param/%s" % (k, name)], want_t["s%d_param/%s" % (k, name)] = p, online[name]
+    assert_learn_trace_matches(got_t, want_t, label="exchange-%s/%s" % (mode, shape))
+    if exch is not None:
+        exch.close()
+    for ad in ads:
+        ad.close()
