@@ -325,7 +325,10 @@ def main():
         probe = {k: bracketed(k, 30)[0] for k in ktab}
         kname = max((k for k in probe if probe[k] is not None), key=lambda k: probe[k])
     lib.rb_profile_select(kname.encode() if kname else None)
-    lib.rb_profile_stride(PROFILE_STRIDE)       # 1 launch in 8 is bracketed inside the timed region
+    # 1 launch in 8 is bracketed inside a long timed region; a short one (the driver's 20-step run) brackets every launch,
+    # so that `roofline` is never a 2- or 3-sample mean
+    stride = PROFILE_STRIDE if opt.steps >= 200 else 1
+    lib.rb_profile_stride(stride)
     if world > 1 or force_dist:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
@@ -399,7 +402,19 @@ def main():
                        "replay_capacity_per_gpu": cfg["capacity"], "parallelism": par},
             "per_samples_per_s": per_rate * world,
             "ms_per_step_unbracketed": plain_ms,
+            "library_source_hash": L.source_hash(lib),
         }
+        assert out["library_source_hash"] == __graft_entry__.source_hash(), "the loaded library was not built from this tree"
+        # the second BASELINE metric (memory.py:148-159: sample(B) + update_priorities, no learner), priced against HBM with
+        # SURVEY 8(d)'s algorithmic bytes — (h + n) frames read + 2h frames written per sample — and against what actually
+        # bounds it at one batch in flight: a chain of DEPENDENT round trips (sampler: tree top in LDS, 2 trips below it,
+        # 1 trip for the window's timesteps/rewards, then the frame gather; update: 9 hashed levels + the dense top)
+        per_bytes = (4 + cfg["multi_step"] + 2 * 4) * 7056          # history 4 in every BASELINE config
+        out["roofline_per"] = {"bound": "hbm", "achieved": per_rate * per_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": per_rate * per_bytes / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_sample": per_bytes,
+                               "batch": B, "us_per_batch": 1e6 * B / per_rate,
+                               "binding": "latency: one batch in flight = 3 dependent launches (sample, gather, update) of "
+                                          "single-workgroup dependent-load chains; bytes are 0.1% of what HBM moves in that time"}
         # counter traffic: only from a PMC pass of THIS config that is committed under profiles/ (tools/gpu_pmc.sh);
         # null otherwise — never a number measured on another workload
         pmc_path = os.path.join(ROOT, "profiles", "round2_pmc_%s.json" % opt.config)
@@ -418,7 +433,7 @@ def main():
         if launches.value > 0:
             out["roofline"] = roof(kname, tot_ms.value / launches.value * 1e-3, launches.value)
             out["roofline"]["event_pair_overhead_us"] = ev_us
-            out["roofline"]["bracketed"] = "every %dth launch of the timed region" % PROFILE_STRIDE
+            out["roofline"]["bracketed"] = "every %s launch of the timed region" % ("%dth" % stride if stride > 1 else "single")
             out["roofline"]["selected"] = "forced" if opt.roofline_kernel in ktab else "largest mean launch time of a 30-step probe"
             out["roofline_others"] = [roof(o, t, n) for o, (t, n) in sorted(others.items(), key=lambda kv: -kv[1][0])]
         flops, nbytes = step_work(cfg, int(agent.params.numel()))

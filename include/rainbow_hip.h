@@ -47,6 +47,9 @@ typedef struct rb_learner rb_learner_t;
 
 const char* rb_last_error(void);
 int rb_abi_version(void);
+/* Hash of the sources this binary was built from (__graft_entry__.source_hash(), baked in at build time; "" for a build
+ * made by hand).  bench.py and smoke() print it, build() rebuilds when it differs from the sources in the tree.        */
+const char* rb_source_hash(void);
 /* Synchronous copies between host memory and library/torch-owned device memory (state
  * dump/restore of the replay buffer — main.py:94-100,118 pickles the whole memory — and
  * white-box tests).  `stream` is synchronised first.                                     */
@@ -155,6 +158,10 @@ int rb_replay_sample_fused_noise(rb_replay_t* r, int32_t batch, double priority_
  * has an exactly zero gradient), sets last_status = 1 in the device header and increments a pinned host counter.
  * This call reads that counter WITHOUT synchronising: the number of failed sampler launches that have completed so far. */
 int rb_replay_failed_samples(rb_replay_t* r, int64_t* count_host);
+/* Zero that counter (after the caller has reported the failure and, e.g., appended more transitions).  A learn step that
+ * consumed a failed batch left no trace: its priority write-back (rb_replay_update_priorities and the learner's fused
+ * sink), the optimiser update and the optimiser's step number are all skipped on the device when last_status != 0.     */
+int rb_replay_reset_failed_samples(rb_replay_t* r);
 /* SegmentTree.index / .full (memory.py:14,16) from the library's host mirror, without touching the device: exact as long
  * as every append went through this handle (a header restored with rb_copy_to_device is picked up as well).        */
 int rb_replay_position(rb_replay_t* r, int64_t* index_host, int32_t* full_host);
@@ -376,7 +383,8 @@ int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream);
 
 /* White-box access for parity tests: copies an internal activation to out_dev.
  * what: 0 log_ps_a [B][atoms], 1 m (projected target) [B][atoms], 2 argmax a* i32[B],
- *       3 pns_a [B][atoms].                                                          */
+ *       3 pns_a [B][atoms], 4 logits [3B][atoms*(actions+1)], 5 u32[1]: 1 when a bounded in-launch
+ *       wait of the chained conv launches expired (must stay 0).                      */
 int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream);
 
 #ifdef __cplusplus

@@ -56,6 +56,7 @@ class TensorDesc(C.Structure):
 SIGNATURES = {
     "rb_last_error": (c_char_p, []),
     "rb_abi_version": (c_int, []),
+    "rb_source_hash": (c_char_p, []),
     "rb_copy_to_host": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "rb_copy_to_device": (c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "rb_profile_select": (c_int, [c_char_p]),
@@ -74,6 +75,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rb_replay_set_beta_source": (c_int, [c_void_p, c_void_p]),
     "rb_replay_failed_samples": (c_int, [c_void_p, C.POINTER(c_int64)]),
+    "rb_replay_reset_failed_samples": (c_int, [c_void_p]),
     "rb_replay_position": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_int32)]),
     "rb_replay_sample_fused_noise": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(NoiseJob), c_void_p]),
@@ -163,3 +165,8 @@ def load():
     import torch  # noqa: F401  (loads libamdhip64 from torch/lib)
     _lib = declare(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
     return _lib
+
+
+def source_hash(lib):
+    """Hash of the sources the loaded library was built from (see __graft_entry__.source_hash)."""
+    return lib.rb_source_hash().decode()

@@ -41,6 +41,35 @@ def _query_layout(lib, cfg, fn):
     return [(d.name.decode(), int(d.offset), tuple(d.shape[i] for i in range(d.ndim))) for d in descs[:n.value]]
 
 
+def init_parameters_flat(layout, n_params, noisy_std):
+    """The reference's initial parameter distributions over the flat layout (a CPU float32 tensor; `layout` = the
+    (name, offset, shape) triples of rb_learner_param_layout): Conv2d's default U(+-1/sqrt(fan_in)) for weight and bias
+    (model.py:56-62, torch.nn.Conv2d.reset_parameters), and NoisyLinear.reset_parameters (model.py:25-30):
+    weight_mu, bias_mu ~ U(+-1/sqrt(in)); weight_sigma = std_init/sqrt(in); bias_sigma = std_init/sqrt(out).
+    Drawn from torch's CPU generator."""
+    flat = torch.zeros(n_params, dtype=torch.float32)
+    shapes = dict((n, s) for n, _o, s in layout)
+    fan_in = None
+    for name, off, shape in layout:
+        numel = int(np.prod(shape))
+        if name.startswith("convs"):
+            if name.endswith("weight"):
+                fan_in = int(np.prod(shape[1:]))
+            bound = 1.0 / math.sqrt(fan_in)                   # the bias of a layer follows its weight in the layout
+            flat[off:off + numel] = torch.empty(numel).uniform_(-bound, bound)
+        else:
+            kind = name.split(".")[1]
+            out_f, in_f = shapes[name.split(".")[0] + ".weight_mu"]
+            if kind in ("weight_mu", "bias_mu"):
+                bound = 1.0 / math.sqrt(in_f)                 # model.py:26,28
+                flat[off:off + numel] = torch.empty(numel).uniform_(-bound, bound)
+            elif kind == "weight_sigma":
+                flat[off:off + numel] = noisy_std / math.sqrt(in_f)      # model.py:27
+            else:
+                flat[off:off + numel] = noisy_std / math.sqrt(out_f)     # model.py:29
+    return flat
+
+
 class _FlatAdam(torch.optim.Adam):
     """torch.optim.Adam over the single flat parameter tensor (agent.py:46).  The state is ordinary Adam state
     (step / exp_avg / exp_avg_sq, so state_dict() and load_state_dict() work as usual), but step() runs the library's
@@ -53,6 +82,12 @@ class _FlatAdam(torch.optim.Adam):
         self.state[p] = dict(step=torch.tensor(0.0, dtype=torch.float32),
                              exp_avg=torch.zeros_like(p, memory_format=torch.preserve_format),
                              exp_avg_sq=torch.zeros_like(p, memory_format=torch.preserve_format))
+
+    def state_dict(self):
+        ag = self._agent()
+        if ag is not None:
+            ag._sync_step()          # graph replay counts steps on the device: refresh the host mirror first
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=float("inf")):
@@ -167,6 +202,7 @@ class Agent:
         # the whole step as ONE C call (rb_learner_train_step) when nothing needs the interpreter in between
         self._one_call = os.environ.get("RAINBOW_AMD_ONE_CALL", "1") == "1"
         self._ts = self._ts_mem = self._ts_out = None
+        self._sink_watched = set()
         # priority write-back beside clip + Adam on a second stream (one fork/join per step)
         self._overlap_update = os.environ.get("RAINBOW_AMD_UPDATE_OVERLAP", "0") == "1"
         # priority write-back as one extra workgroup of the learner's backward launch (see rb_learner_set_priority_sink)
@@ -222,32 +258,8 @@ class Agent:
         raise KeyError(name)
 
     def _init_parameters(self, noisy_std):
-        """Same distributions as the reference: Conv2d default U(+-1/sqrt(fan_in)) and
-        NoisyLinear.reset_parameters (model.py:25-30), drawn from torch's CPU generator."""
-        flat = torch.zeros(self.params.numel(), dtype=torch.float32)
-        for name, off, shape in self._layout:
-            numel = int(np.prod(shape))
-            if name.startswith("convs"):
-                if name.endswith("weight"):
-                    fan_in = int(np.prod(shape[1:]))
-                    self._last_fan_in = fan_in
-                else:
-                    fan_in = self._last_fan_in
-                bound = 1.0 / math.sqrt(fan_in)
-                flat[off:off + numel] = torch.empty(numel).uniform_(-bound, bound)
-            else:
-                kind = name.split(".")[1]
-                w_shape = dict((n, s) for n, _o, s in self._layout)[name.split(".")[0] + ".weight_mu"]
-                out_f, in_f = w_shape
-                if kind in ("weight_mu", "bias_mu"):
-                    bound = 1.0 / math.sqrt(in_f)
-                    flat[off:off + numel] = torch.empty(numel).uniform_(-bound, bound)
-                elif kind == "weight_sigma":
-                    flat[off:off + numel] = noisy_std / math.sqrt(in_f)
-                else:
-                    flat[off:off + numel] = noisy_std / math.sqrt(out_f)
         with torch.no_grad():
-            self.params.copy_(flat)
+            self.params.copy_(init_parameters_flat(self._layout, self.params.numel(), noisy_std))
 
     # ------------------------------------------------------------------ reference API
     def reset_noise(self, raw_normals=None):
@@ -341,9 +353,10 @@ class Agent:
         return out
 
     def evaluate_q_memory(self, val_mem, chunk=512):
-        """test.py:38-39 in one call: Q of every state of a validation ReplayMemory (its first `len` = index-or-capacity
-        states), states built on the device by rb_replay_states_at."""
-        n = val_mem.capacity if val_mem.transitions.full else val_mem.transitions.index
+        """test.py:38-39 in one call: Q of every state the reference's `for state in val_mem` visits — ALL `capacity` slots
+        (memory.py:166-168 walks data indices 0 .. capacity-1 whether or not they were ever written; unwritten slots are
+        blank states) — built on the device by rb_replay_states_at."""
+        n = val_mem.capacity
         qs = np.empty(n, dtype=np.float32)
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
@@ -357,6 +370,8 @@ class Agent:
         device-resident and launched eagerly.  hipGraph replay is OPT-IN (RAINBOW_AMD_GRAPH=1): after GRAPH_WARMUP eager
         calls the step is then captured once and replayed.  The injected-randomness arguments are parity-test hooks."""
         injected = _target_raw_normals is not None or _unit_uniforms is not None
+        if isinstance(mem, ReplayMemory):
+            self._raise_on_failed_samples(mem)
         if (self._use_graph and not injected and not self._dist and isinstance(mem, ReplayMemory)):
             if self._graph is not None and self._graph_mem is mem:
                 self._flush_noise()
@@ -368,6 +383,23 @@ class Agent:
                 return
             self._eager_steps += 1
         self._learn_eager(mem, _target_raw_normals, _unit_uniforms)
+
+    def _raise_on_failed_samples(self, mem):
+        """The device sampler is bounded where the reference's rejection loop (memory.py:128-132) would spin forever.  A
+        launch that gave up left NO trace on the device (zero importance weights; the priority write-back, the optimiser
+        update and the device-resident step number are skipped when the header says so): here the host side is put back
+        in step — the optimiser's step count is rolled back by the number of skipped updates, the counter is cleared —
+        and the failure is raised.  The caller may append more transitions and call learn() again."""
+        failed = mem.failed_samples()
+        if not failed:
+            return
+        if isinstance(self.optimiser, _FlatAdam) and getattr(self, "_sink_mem", None) is mem:
+            st = self.optimiser.state[self.params]
+            st["step"] -= float(min(failed, int(st["step"].item())))
+        mem.reset_failed_samples()
+        raise RuntimeError("ReplayMemory: %d sampler launch(es) found no valid batch in %d attempts (replay too small for "
+                           "batch %d?); those steps were skipped on the device (no priority write-back, no optimiser update)"
+                           % (failed, mem.MAX_ATTEMPTS, self.batch_size))
 
     def _sync_step(self):
         """Host mirror of the optimiser's step number after graph replays (state_dict / checkpoint read it)."""
@@ -398,8 +430,7 @@ class Agent:
             if getattr(self, "_sink_mem", None) is not mem or self._sink_idx is not o["tree_idxs"]:
                 L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, mem._h, o["tree_idxs"].data_ptr()))
                 self._sink_mem, self._sink_idx = mem, o["tree_idxs"]
-                me = weakref.ref(self)
-                weakref.finalize(mem, lambda: me() is not None and me()._clear_sink())
+                self._watch_sink(mem)
             ts = L.TrainStep(replay=mem._h, batch=B, max_attempts=mem.MAX_ATTEMPTS, window_len=wlen,
                              tree_idx_dev=o["tree_idxs"].data_ptr(), actions_dev=o["actions"].data_ptr(),
                              returns_dev=o["returns"].data_ptr(), nonterminals_dev=o["nonterminals"].data_ptr(),
@@ -434,10 +465,6 @@ class Agent:
         B = self.batch_size
         device_mem = isinstance(mem, ReplayMemory)
         stream = self._stream()                       # ONE lookup per step (torch.cuda.current_stream costs ~4 us a call)
-        if device_mem and mem.failed_samples():
-            raise RuntimeError("ReplayMemory: %d sampler launch(es) found no valid batch in %d attempts (replay too small "
-                               "for batch %d?); those steps ran with zero importance weights"
-                               % (mem.failed_samples(), mem.MAX_ATTEMPTS, B))
         if self._zero_copy_ok is None:                # a property of the learner's configuration: asked once
             self._zero_copy_ok = bool(self._lib.rb_learner_zero_copy_ok(self._h))
         zero_copy = device_mem and self._zero_copy_ok and mem.history == self._cfg.history and mem.n == self.n
@@ -484,9 +511,7 @@ class Agent:
             # the learner writes the new priorities into mem's sum-tree itself (one extra workgroup of its backward)
             L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, mem._h, idxs.data_ptr()))
             self._sink_mem, self._sink_idx = mem, idxs
-            # the library caches raw pointers into `mem`: drop them when the memory goes away before the agent does
-            me = weakref.ref(self)
-            weakref.finalize(mem, lambda: me() is not None and me()._clear_sink())
+            self._watch_sink(mem)
         elif not device_mem and getattr(self, "_sink_mem", None) is not None:
             L.check(self._lib, self._lib.rb_learner_set_priority_sink(self._h, None, None))
             self._sink_mem, self._sink_idx = None, None
@@ -533,10 +558,34 @@ class Agent:
         else:
             mem.update_priorities(idxs, self._loss.detach().cpu().numpy())                 # agent.py:100
 
+    def _watch_sink(self, mem):
+        """The library caches raw pointers into `mem` (priority sink): drop them when THAT memory goes away before the agent
+        does.  One finalizer per memory, and it only acts if that memory is still the current sink (after a switch from
+        memory A to memory B, collecting A must not clear B's sink)."""
+        key = id(mem)
+        if key in self._sink_watched:
+            return
+        self._sink_watched.add(key)
+        me = weakref.ref(self)
+
+        def gone(key=key):
+            ag = me()
+            if ag is not None:
+                ag._sink_watched.discard(key)
+                if ag._sink_key == key:
+                    ag._clear_sink()
+        weakref.finalize(mem, gone)
+
+    @property
+    def _sink_key(self):
+        m = getattr(self, "_sink_mem", None)
+        return id(m) if m is not None else None
+
     def _clear_sink(self):
         if getattr(self, "_h", None):
             self._lib.rb_learner_set_priority_sink(self._h, None, None)
         self._sink_mem, self._sink_idx = None, None
+        self._ts = self._ts_mem = self._ts_out = None      # the one-call path re-arms the sink on its next step
 
     def update_target_net(self):
         """agent.py:102-103."""
@@ -649,6 +698,8 @@ class Agent:
 
     def restore(self, ck):
         """Inverse of checkpoint(): `ck` is the dict or a path."""
+        if not isinstance(self.optimiser, _FlatAdam):     # before anything is overwritten
+            raise NotImplementedError("restore() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1)")
         if not isinstance(ck, dict):
             ck = torch.load(ck, map_location="cpu")
         if ck.get("version") != 1 or ck["config"] != bytes(self._cfg):

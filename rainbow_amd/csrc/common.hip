@@ -207,6 +207,12 @@ int rb_debug_check_guards(int64_t* n_blocks, int64_t* n_bad) {
   return RB_OK;
 }
 
+#ifndef RB_SOURCE_HASH
+#define RB_SOURCE_HASH ""
+#endif
+// (the marker lets build() read the hash of a library on disk without loading it)
+__attribute__((used)) static const char g_rb_hash_marker[] = "@@RB_SOURCE_HASH=" RB_SOURCE_HASH "@@";
+const char* rb_source_hash(void) { return RB_SOURCE_HASH; }
 const char* rb_last_error(void) { return g_rb_error; }
 int rb_abi_version(void) { return 1; }
 

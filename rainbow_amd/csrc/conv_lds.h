@@ -22,9 +22,18 @@ extern __device__ long long g_cstamp[64];
 #endif
 #define RB_CSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_cstamp[i] = wall_clock64(); } while (0)
 #define RB_CSTAMP_LAST(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) g_cstamp[i] = wall_clock64(); } while (0)
+// per-workgroup timeline: g_wgt[kernel id][workgroup][slot] = wall_clock64 (100 MHz) at phase boundaries, slot 7 = where
+// it ran (XCC id << 16 | HW_ID bits) — tools/wg_timeline.py draws the schedule of a launch from it
+#define RB_WGT_KERNELS 8
+#define RB_WGT_WGS 2048
+extern __device__ long long g_wgt[RB_WGT_KERNELS][RB_WGT_WGS][8];
+#define RB_WGT(kid, wg, slot) do { if (threadIdx.x == 0 && (wg) < RB_WGT_WGS) g_wgt[kid][wg][slot] = wall_clock64(); } while (0)
+#define RB_WGT_HW(kid, wg) do { if (threadIdx.x == 0 && (wg) < RB_WGT_WGS) g_wgt[kid][wg][7] = ((long long)__builtin_amdgcn_s_getreg(6164) << 16) | (__builtin_amdgcn_s_getreg(63492) & 0xffff); } while (0)
 #else
 #define RB_CSTAMP(i) ((void)0)
 #define RB_CSTAMP_LAST(i) ((void)0)
+#define RB_WGT(kid, wg, slot) ((void)0)
+#define RB_WGT_HW(kid, wg) ((void)0)
 #endif
 struct ConvLdsFwdArgs {
   int cin, cout;
@@ -108,17 +117,35 @@ __device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, i
 // indexes the patch-offset table, a sum does not care.  That removes the transposing LDS stores (4- to 16-way bank
 // conflicts, 34-52 % of the LDS-active cycles of these kernels), one LDS read per MFMA step, and 34-76 KB of LDS per
 // workgroup: two workgroups share a CU and the staging of one runs under the MFMAs of the other.
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false>
-__global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
-  constexpr int KGRAN = WREG ? 8 * RB_CONV_WAVES : 2 * RB_CONV_WAVES;
-  constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
+// In-launch dependency of one workgroup (rb_device.h rb_chain_*; all NULL = none): it may not read its INPUT IMAGE before
+// `wait_ctr` has reached `wait_target` (weights, tap table and everything else that does not depend on the producer are
+// staged before the wait), and it announces its own output on `done_ctr`.
+struct ChainLink {
+  const unsigned* wait_ctr;
+  unsigned wait_target;
+  unsigned* done_ctr;
+  unsigned* err;
+};
+template <class G, int NT, int PR, int KMAX, bool WREG = false>
+struct ConvFwdLdsSize {
+  static constexpr int KGRAN = WREG ? 8 * RB_CONV_WAVES : 2 * RB_CONV_WAVES;
+  static constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
+  static constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
+  static constexpr int OPS = (WREG ? 0 : KPAD * 33) + (KMAX / G::KK) * PR * G::IH;     // [weights then] patch, contiguous
+  static constexpr int WSZ = OPS > RED ? OPS : RED;
+  static constexpr int FLOATS = WSZ + KPAD;                // + the tap table (ints)
+};
+// body with explicit block coordinates and caller-provided LDS, so the layers of the stack can share one launch
+// COH bit 0: the input image was produced inside this launch — read it with agent-coherent (sc1) loads after the wait;
+// bit 1: the output is consumed inside this launch — store it write-through (sc1).  0 with a link: fences instead.
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false, int COH = 0>
+__device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx, int by, int img, float* smem, const ChainLink& link) {
+  typedef ConvFwdLdsSize<G, NT, PR, KMAX, WREG> SZ;
+  constexpr int KPAD = SZ::KPAD;
   constexpr int PLANE = PR * G::IH;                 // floats per channel in the patch
   constexpr int CMAX = KMAX / G::KK;
-  constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
-  constexpr int OPS = (WREG ? 0 : KPAD * 33) + CMAX * PLANE;     // [weights then] patch, contiguous
-  constexpr int WSZ = OPS > RED ? OPS : RED;
-  __shared__ __attribute__((aligned(16))) float s_all[WSZ];
-  __shared__ int s_koff[KPAD];
+  float* s_all = smem;
+  int* s_koff = reinterpret_cast<int*>(smem + SZ::WSZ);
   float* s_w = s_all;
   float* s_patch = s_all + (WREG ? 0 : KPAD * 33);
 
@@ -126,10 +153,14 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   constexpr int SB = G::KS == 8 ? 0 : G::KS == 4 ? 8 : 16;    // stamp slots per layer (RB_STAMP builds only)
   RB_CSTAMP(SB + 0);
   RB_CSTAMP_LAST(SB + 4);
-  const int img = (int)blockIdx.z;
+  constexpr int WK = FIRST ? 0 : (G::KS == 3 ? 2 : 1);          // timeline id of this layer (RB_STAMP builds only)
+  const int wgi = img * 16 + by * 8 + bx;
+  (void)wgi;
+  RB_WGT(WK, wgi, 0);
+  RB_WGT_HW(WK, wgi);
   const int net = img < a.n_on ? 0 : 1;
-  const int cout0 = (int)blockIdx.y * 32;
-  const int p0 = (int)blockIdx.x * PCH;
+  const int cout0 = by * 32;
+  const int p0 = bx * PCH;
   const int cin = a.cin;
   const int K = cin * G::KK;
   const int oy0 = p0 / G::OH;
@@ -166,6 +197,9 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
     const int c = kc / G::KK, r = kc % G::KK;
     s_koff[k] = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
   }
+  RB_WGT(WK, wgi, 1);
+  if (link.wait_ctr) rb_chain_wait<(COH & 1) != 0>(link.wait_ctr, link.wait_target, link.err);   // the input image is final from here on
+  RB_WGT(WK, wgi, 2);
   if (FIRST && !a.src.f32) {
     const int per_c = rows * G::IH;                 // bytes per channel, 16-byte multiple for the frame geometries
     const int v16 = per_c >> 4;
@@ -212,7 +246,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int e = e0 + i * RB_CONV_THREADS + t;
-          if (e < total) { const int c = e / v4, q = e - c * v4; v[i] = rb_ld4(base + (int64_t)c * G::IP + iy0 * G::IH + q * 4); }
+          if (e < total) {
+            const int c = e / v4, q = e - c * v4;
+            if constexpr ((COH & 1) != 0) v[i] = rb_ld4_buf_sc1(rb_make_buf(base), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q * 4), 0u);
+            else v[i] = rb_ld4(base + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+          }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -231,7 +269,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
           const int e = e0 + i * RB_CONV_THREADS + t;
-          if (e < total) { const int c = e / per_c, q = e - c * per_c; v[i] = base[(int64_t)c * G::IP + iy0 * G::IH + q]; }
+          if (e < total) {
+            const int c = e / per_c, q = e - c * per_c;
+            if constexpr ((COH & 1) != 0) v[i] = rb_ld1_buf_sc1(rb_make_buf(base), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q), 0u);
+            else v[i] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
+          }
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -243,6 +285,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   }
   __syncthreads();
   RB_CSTAMP(SB + 1);
+  RB_WGT(WK, wgi, 3);
 
   // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW) of the padded reduction (weights beyond K are zero)
   const int kb = wave * KW;
@@ -280,6 +323,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
   RB_CSTAMP(SB + 2);
+  RB_WGT(WK, wgi, 4);
   // cross-wave sum one 32-position tile at a time (32 KB of scratch whatever NT is: the LDS footprint decides how many
   // workgroups share a CU), fixed order w0..w7
 #pragma unroll
@@ -300,7 +344,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
       if (m < a.cout && p < G::P && p < p0 + PCH) {
         const float o = fmaxf(v + bias_r[it], 0.0f);      // (bias fetched before the MFMA loop: a global load here sat on
                                                           //  the critical path of every tile's epilogue)
-        a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+        if constexpr ((COH & 2) != 0) rb_st1_wt(a.out, 4u * (unsigned)((img * a.cout + m) * G::P + p), o);
+        else a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
         if (a.out_blocked) {
           const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
           a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
@@ -310,6 +355,67 @@ __global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(
   }
   RB_CSTAMP(SB + 3);
   RB_CSTAMP_LAST(SB + 5);
+  RB_WGT(WK, wgi, 5);
+  if (link.done_ctr) rb_chain_signal<(COH & 2) != 0>(link.done_ctr);
+  RB_WGT(WK, wgi, 6);
+}
+
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false>
+__global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS];
+  const ChainLink none{nullptr, 0u, nullptr, nullptr};
+  rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem, none);
+}
+
+// The whole conv stack of the learn step in ONE launch at small batches (<= 96 images): block ranges [layer 0 | layer 1 |
+// layer 2], image-major inside a range.  A layer's workgroup for image i depends only on the previous layer's workgroups
+// of the SAME image, so instead of two kernel boundaries (each a full drain, an L2 write-back / invalidate and ~4.7 us of
+// dispatch floor on this part) it waits on image i's arrival counter — after it has staged its weight slab and tap
+// table, which do not depend on the producer.  Workgroups are dispatched in index order, so by the time a layer-1
+// workgroup occupies a CU every layer-0 workgroup is resident or finished (rb_device.h rb_chain_*).
+struct ConvFwdChainArgs {
+  ConvLdsFwdArgs layer[3];
+  int nblocks[3];            // workgroups of each layer
+  int per_img[3];            // workgroups per image (= arrivals that complete an image of that layer)
+  int cotiles[3];
+  unsigned* done[3];         // [images] arrival counters of each layer's output (monotonic across launches)
+  unsigned epoch;            // this launch's number (1-based): an image of layer l is final at done[l][img] == epoch * per_img[l]
+  unsigned* err;
+};
+// SC1: hand-offs by write-through stores + agent-coherent loads (no fences); else release / acquire fences.
+template <class G0, int NT0, int PR0, int K0, int PCH0, class G1, int NT1, int PR1, int K1, class G2, int NT2, int PR2, int K2, int NL, bool SC1>
+__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_chain(ConvFwdChainArgs a) {
+  typedef ConvFwdLdsSize<G0, NT0, PR0, K0> S0;
+  typedef ConvFwdLdsSize<G1, NT1, PR1, K1> S1;
+  typedef ConvFwdLdsSize<G2, NT2, PR2, K2> S2;
+  constexpr int M01 = S0::FLOATS > S1::FLOATS ? S0::FLOATS : S1::FLOATS;
+  constexpr int MAXF = (NL > 2 && S2::FLOATS > M01) ? S2::FLOATS : M01;
+  __shared__ __attribute__((aligned(16))) float smem[MAXF];
+  int b = (int)blockIdx.x;
+  if (b < a.nblocks[0]) {                               // decode: position chunk fastest, then cout tile, then image
+    constexpr int CH = (G0::P + PCH0 - 1) / PCH0;
+    const int img = b / a.per_img[0], r = b - img * a.per_img[0];
+    const ChainLink link{nullptr, 0u, a.done[0] + img, a.err};
+    rb_conv_fwd_body<G0, NT0, PR0, K0, true, PCH0, false, SC1 ? 2 : 0>(a.layer[0], r % CH, r / CH, img, smem, link);
+    return;
+  }
+  b -= a.nblocks[0];
+  if (NL == 2 || b < a.nblocks[1]) {
+    constexpr int CH = (G1::P + 32 * NT1 - 1) / (32 * NT1);
+    const int img = b / a.per_img[1], r = b - img * a.per_img[1];
+    // (nblocks[0] == 0: the first layer ran as a launch of its own — nothing to wait for)
+    const ChainLink link{a.nblocks[0] > 0 ? a.done[0] + img : nullptr, a.epoch * (unsigned)a.per_img[0], NL > 2 ? a.done[1] + img : nullptr, a.err};
+    if (a.nblocks[0] > 0) rb_conv_fwd_body<G1, NT1, PR1, K1, false, 32 * NT1, false, SC1 ? (NL > 2 ? 3 : 1) : 0>(a.layer[1], r % CH, r / CH, img, smem, link);
+    else rb_conv_fwd_body<G1, NT1, PR1, K1, false, 32 * NT1, false, SC1 ? (NL > 2 ? 2 : 0) : 0>(a.layer[1], r % CH, r / CH, img, smem, link);
+    return;
+  }
+  if (NL > 2) {
+    b -= a.nblocks[1];
+    constexpr int CH = (G2::P + 32 * NT2 - 1) / (32 * NT2);
+    const int img = b / a.per_img[2], r = b - img * a.per_img[2];
+    const ChainLink link{a.done[1] + img, a.epoch * (unsigned)a.per_img[1], nullptr, a.err};
+    rb_conv_fwd_body<G2, NT2, PR2, K2, false, 32 * NT2, false, SC1 ? 1 : 0>(a.layer[2], r % CH, r / CH, img, smem, link);
+  }
 }
 
 // ---- large batches: one weight slab per workgroup, a loop over images -----------------------------------------

@@ -40,7 +40,14 @@ extern "C" int rb_debug_spans(long long* out, int reset) {
 }
 __device__ long long g_cstamp[64];
 extern "C" int rb_debug_cstamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamp), sizeof(long long) * 64) == hipSuccess ? 0 : -2; }
+__device__ long long g_wgt[RB_WGT_KERNELS][RB_WGT_WGS][8];
+extern "C" int rb_debug_wgtrace(long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), sizeof(long long) * RB_WGT_KERNELS * RB_WGT_WGS * 8) != hipSuccess) return -2;
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wgt)) != hipSuccess || hipMemset(p, 0, sizeof(long long) * RB_WGT_KERNELS * RB_WGT_WGS * 8) != hipSuccess) return -2; }
+  return 0;
+}
 #endif
+#define RB_CHAIN_ARRAYS 8     // per-image arrival counter arrays of the chained conv launches (3 forward, up to 5 backward)
 #define RB_HEAD_MAX_NZ 1408   // 3 logit rows of this many floats live in the head kernel's LDS (18 actions x 51 atoms = 969)
 typedef ConvGeom<8, 4, 84, 20> GeomC1;   // model.py:56
 typedef ConvGeom<4, 2, 20, 9> GeomC2;    // model.py:57
@@ -164,11 +171,19 @@ struct rb_learner {
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   NoiseJob* job_dev;               // [3] device copies of the noise jobs (rb_learner_noise_job), uploaded on request
+  // in-launch dataflow of the conv stack at small batches (conv_lds.h k_conv_fwd_chain / k_conv_bwd_chain): arrival
+  // counters [8][3B] (monotonic: one epoch per launch, never reset), the launch numbers, an error word the kernels set
+  // when a bounded spin expires
+  unsigned* chain_ctr;
+  unsigned chain_epoch_fwd, chain_epoch_bwd;
+  int opt_chain;        // RB_CONV_CHAIN (A/B switch, read once): 0 = one launch per layer
   int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
   ImgSrc cur_src;       // input frames of the learn step in flight
   int sink_done;        // the last learn() performed the priority write-back itself
+  const int32_t* batch_status;   // device word (the sink replay's header.last_status): non-zero = the sampler gave up on the
+                                 // batch in flight; the optimiser update and its step number are then skipped (k_head, k_clip_adam)
   rb_replay_t* sink;    // priority sink: when set, learn() writes loss^w back into this replay's sum-tree itself
   const int64_t* sink_idx;
   int fast_fc;          // streamed 16x16x4 noisy-linear kernels usable (alignment preconditions hold)
@@ -395,7 +410,8 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
                                                const float* returns, const float* nonterminals, const float* weights,
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
-                                               int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr) {
+                                               int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr,
+                                               const int32_t* batch_status) {
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
   __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
@@ -439,7 +455,8 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
       if (s_ev[a] > best) { best = s_ev[a]; a_star = a; }         // argmax, first maximum
   }
   if (t == 0) a_star_out[b] = a_star;
-  if (step_ctr && b == 0 && t == 0) *step_ctr = *step_ctr + 1;      // this learn call's optimiser step number (1-based)
+  // this learn call's optimiser step number (1-based); a batch the sampler gave up on does not count (no update follows)
+  if (step_ctr && b == 0 && t == 0 && !(batch_status && *batch_status != 0)) *step_ctr = *step_ctr + 1;
 
   if (wave == 0) {
     // ---------------- target(next_states)[a*] probabilities      agent.py:75-76, projection inputs agent.py:79-86
@@ -638,6 +655,10 @@ struct ClipAdamArgs {
   // FUSED: elements [skip_lo, skip_lo + skip_len) (the hidden layer's mu | sigma weight arrays) are not touched by the
   // elementwise part: the tile part below updates them from gradients it recomputes on the fly
   int64_t skip_lo4, skip_len4;        // in float4 units
+  // non-NULL and non-zero on the device: the batch behind this gradient was not a legal one (the sampler gave up; its
+  // importance weights are zero and so is the gradient) — the whole update is skipped instead of letting Adam's momentum
+  // move the parameters on a step the reference would never have taken
+  const int32_t* batch_status;
 };
 // (IEEE sqrt and divisions, as torch computes them: hardware rcp / approximate sqrt measured 1.5 us faster per launch
 // and stay far inside the test tolerance, but the update would no longer be the reference's formula rounding for rounding)
@@ -767,6 +788,10 @@ __global__ __launch_bounds__(256, RB_ADAM_MINWAVES) void k_clip_adam(ClipAdamArg
       idx[u] = i;
       P[u] = rb_ld4(a.p + 4 * i); G[u] = rb_ld4(a.g + 4 * i); M[u] = rb_ld4(a.m + 4 * i); V[u] = rb_ld4(a.v + 4 * i);
     }
+  }
+  if (a.batch_status && *a.batch_status != 0) {                     // block-uniform (every block reads the same word)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) *a.norm_out = 0.0f;
+    return;
   }
   float acc = 0.0f;
   for (int i = (int)threadIdx.x; i < a.nparts; i += 256) acc += a.part[i];
@@ -938,6 +963,68 @@ static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& 
   return launch_conv_fwd<GeomD2>(l, layer, n_on, n_tg, src, on, tg, stream);
 }
 
+// The chained conv launches run the learn step's geometry only (3B images, u8 frames: the arrival counters advance by one
+// epoch per launch for exactly those images), at batches whose per-image workgroups are what fills the chip, and never
+// under stream capture (the launch number is a by-value argument: a replayed graph would wait for a stale epoch).
+static bool conv_chain_usable(rb_learner* l, int NI, const ImgSrc& src, hipStream_t stream) {
+  if (!l->opt_chain || !l->fast_conv || !l->chain_ctr || src.f32 || NI != 3 * l->L.B || NI > 96) return false;
+#if !defined(RB_HOST_INTERP)
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+#else
+  (void)stream;
+#endif
+  return true;
+}
+
+static int conv_fwd_chain(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on, const NetPtrs& tg,
+                          hipStream_t stream) {
+  const Layout& L = l->L;
+  const int NI = n_on + n_tg;
+  ConvFwdChainArgs c;
+  memset(&c, 0, sizeof(c));
+  // position-chunk sizes of the per-layer launches (conv_fwd above): C1 80, C2 96, C3 64, D1 64, D2 32
+  const int pch[2][3] = {{80, 96, 64}, {64, 32, 32}};
+  unsigned total = 0;
+  for (int i = 0; i < L.nconv; ++i) {
+    const ConvLayer& cl = L.conv[i];
+    ConvLdsFwdArgs& a = c.layer[i];
+    a.cin = cl.cin; a.cout = cl.cout; a.n_on = n_on;
+    a.w[0] = on.conv_w[i]; a.w[1] = tg.conv_w[i]; a.bias[0] = on.conv_b[i]; a.bias[1] = tg.conv_b[i];
+    a.src = src; a.in_f = i > 0 ? l->act[i - 1] : nullptr; a.out = l->act[i];
+    a.out_blocked = (i == L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
+    a.rows_total = NI; a.ipb = 1;
+    c.cotiles[i] = (int)rb_div_up(cl.cout, 32);
+    c.per_img[i] = (int)rb_div_up(cl.P(), pch[L.nconv == 3 ? 0 : 1][i]) * c.cotiles[i];
+    c.nblocks[i] = c.per_img[i] * NI;
+    c.done[i] = l->chain_ctr + (int64_t)i * NI;
+    total += (unsigned)c.nblocks[i];
+  }
+  for (int i = L.nconv; i < 3; ++i) { c.layer[i] = c.layer[0]; c.nblocks[i] = 0; c.per_img[i] = 1; c.cotiles[i] = 1; c.done[i] = c.done[0]; }
+  c.epoch = l->chain_epoch_fwd + 1;
+  c.err = l->chain_ctr + (int64_t)RB_CHAIN_ARRAYS * NI;
+  // RB_CONV_CHAIN: 1 = hand-offs by release / acquire fences, 2 = by write-through stores + coherent loads (default),
+  // 3 = as 2 with the first layer as a launch of its own (it runs two workgroups per CU there; the chain's LDS footprint
+  // — the largest of its layers — allows one)
+  const bool sc1 = l->opt_chain >= 2;
+  if (l->opt_chain == 3) {
+    int rc = conv_fwd(l, 0, n_on, n_tg, src, on, tg, stream);
+    if (rc != RB_OK) return rc;
+    total -= (unsigned)c.nblocks[0];
+    c.nblocks[0] = 0;
+  }
+  if (L.nconv == 3) {
+    if (sc1) { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomC1, 3, 20, 256, 80, GeomC2, 3, 20, 512, GeomC3, 2, 9, 576, 3, true>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
+    else { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomC1, 3, 20, 256, 80, GeomC2, 3, 20, 512, GeomC3, 2, 9, 576, 3, false>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
+  } else {
+    if (sc1) { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomD1, 2, 20, 100, 64, GeomD2, 1, 16, 800, GeomD2, 1, 16, 800, 2, true>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
+    else { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomD1, 2, 20, 100, 64, GeomD2, 1, 16, 800, GeomD2, 1, 16, 800, 2, false>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
+  }
+  RB_LAUNCH_CHECK();
+  l->chain_epoch_fwd += 1;
+  return RB_OK;
+}
+
 static NlWeights nl_h(const NetPtrs& p) {
   NlWeights w;
   w.mu = p.h_mu; w.sigma = p.h_sigma; w.eout = p.h_eout; w.ein = p.h_ein; w.bmu = p.h_bmu; w.bsigma = p.h_bsigma;
@@ -954,9 +1041,14 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
                    hipStream_t stream) {
   const Layout& L = l->L;
   const int NI = n_on + n_tg;
-  for (int layer = 0; layer < L.nconv; ++layer) {
-    int rc = conv_fwd(l, layer, n_on, n_tg, src, on, tg, stream);
+  if (conv_chain_usable(l, NI, src, stream)) {
+    int rc = conv_fwd_chain(l, n_on, n_tg, src, on, tg, stream);
     if (rc != RB_OK) return rc;
+  } else {
+    for (int layer = 0; layer < L.nconv; ++layer) {
+      int rc = conv_fwd(l, layer, n_on, n_tg, src, on, tg, stream);
+      if (rc != RB_OK) return rc;
+    }
   }
   const float* feat = l->act[L.nconv - 1];
   const int m_max = n_on > n_tg ? n_on : n_tg;
@@ -1281,6 +1373,7 @@ int rb_learner_destroy(rb_learner_t* l) {
     if (*p) rb_dev_free(*p);
   if (l->a_star) rb_dev_free(l->a_star);
   if (l->noise_ctr) rb_dev_free(l->noise_ctr);
+  if (l->chain_ctr) rb_dev_free(l->chain_ctr);
   if (l->job_dev) rb_dev_free(l->job_dev);
   if (l->ev_fact) (void)hipEventDestroy(l->ev_fact);
   if (l->use_side) {
@@ -1329,6 +1422,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     l->opt_conv_full = (e = getenv("RB_CONV_FULL")) ? (e[0] != '0') : 1;
     l->opt_dx_ipb = (e = getenv("RB_DX_IPB")) ? atoi(e) : 0;
     l->opt_dx_wt = (e = getenv("RB_DX_WT")) ? atoi(e) : 0;      // measured slower (batch 256: 45 -> 53 us): off
+    l->opt_chain = (e = getenv("RB_CONV_CHAIN")) ? atoi(e) : 0;      // measured: 3 = -1.5 us per step, 2 = equal, 1 = +13 us (profiles/round3_chain_*): opt-in
   }
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
@@ -1382,7 +1476,9 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->zero_noise, L.n_noise);
   RB_ALLOC(l->norm_part, 16384);
   RB_ALLOC(l->noise_ctr, 4);
+  RB_ALLOC(l->chain_ctr, (int64_t)RB_CHAIN_ARRAYS * NI + 64);
 #undef RB_ALLOC
+  RB_HIP_TRY(hipMemset(l->chain_ctr, 0, ((size_t)RB_CHAIN_ARRAYS * NI + 64) * 4));
   RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
   {
     // measured on MI355X (gpurun_out/ab.log, round 1): cross-stream fork/join costs more than the overlap buys at
@@ -1642,7 +1738,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head, dim3((unsigned)B), dim3(RB_HEAD_THREADS), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr);
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
@@ -1901,6 +1997,7 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
   a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
   a.neg_step_size = (float)(-(lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)eps;
   a.step_dev = step == 0 ? l->step_ctr : nullptr; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
+  a.batch_status = l->batch_status;
   const int64_t n4 = n >> 2;
   // 4 quadruples per thread: measured best of {2, 4, 8} on MI355X (254.3 / 255.6 / 256.6 us per step)
   // write-through stores: same-box A/B 253.7 -> 250.8 us per step (RB_ADAM_WT=0 restores plain stores)
@@ -2031,6 +2128,13 @@ int rb_learner_set_priority_sink(rb_learner_t* l, rb_replay_t* replay, const int
   RB_REQUIRE((replay == nullptr) == (tree_idx_dev == nullptr), "rb_learner_set_priority_sink: pass both or neither");
   l->sink = replay;
   l->sink_idx = tree_idx_dev;
+  l->batch_status = nullptr;
+  if (replay) {
+    ReplayView v;
+    double omega;
+    if (rb_replay_internal_view(replay, &v, &omega) != RB_OK) { rb_set_error("rb_learner_set_priority_sink: bad replay handle"); return RB_ERR_INVALID; }
+    l->batch_status = &v.hdr->last_status;
+  }
   return RB_OK;
 }
 
@@ -2071,6 +2175,7 @@ int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_strea
     case 2: src = l->a_star; bytes = (size_t)L.B * 4; break;
     case 3: src = l->pns_a; bytes = (size_t)L.B * L.Z * 4; break;
     case 4: src = l->logits; bytes = (size_t)3 * L.B * L.NZ * 4; break;
+    case 5: src = l->chain_ctr + (int64_t)RB_CHAIN_ARRAYS * 3 * L.B; bytes = 4; break;   // chained conv launches: 1 = a bounded spin expired
     default: rb_set_error("rb_learner_debug_read: unknown selector %d", what); return RB_ERR_INVALID;
   }
   RB_HIP_TRY(hipMemcpyAsync(out_dev, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));

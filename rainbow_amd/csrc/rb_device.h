@@ -90,6 +90,55 @@ __device__ __forceinline__ void rb_atomic_inc_system(int32_t* p) {
 #endif
 }
 
+// ---- in-launch hand-off between workgroups of ONE launch (block-range "roles" with a partial dependency, e.g. the conv
+// layers of one image).  The 8 XCDs have private, mutually non-coherent L2s and every CU a private L1, so a hand-off is an
+// agent-scope release on the producer and an agent-scope acquire on EVERY consumer workgroup (cdna_hip_programming
+// Guideline 16): producer = stores -> every wave drains (vmcnt 0) -> workgroup barrier -> one lane: release fence, drain,
+// relaxed agent-scope add on the arrival counter; consumer = one lane polls the counter RELAXED (an acquire per poll would
+// drop the CU's L1 every iteration), then ONE acquire fence, then the workgroup barrier, then plain loads.
+// Counters are MONOTONIC across launches (target = launch number x arrivals per launch, passed by value): no memset
+// between launches, no in-kernel reset.  Deadlock freedom: a consumer's producers always have LOWER block indices in a
+// 1-D grid, workgroups are dispatched in index order, so every producer is resident or finished before a consumer can
+// occupy a CU.  The spin is bounded all the same: on expiry the consumer flags `err` (read back by the host) and goes on.
+// WT = the payload was stored write-through (sc1: rb_st1_wt / rb_st4_wt) — it is in memory once the stores have drained,
+// no release fence (a fence writes back EVERY dirty line of the XCD's L2, not just this workgroup's).
+// COH = the consumer reads the payload with agent-coherent loads (sc1: rb_ld*_buf_sc1) — no acquire fence (which drops the
+// whole L1 of the CU, ~1.7 us).
+template <bool WT>
+__device__ __forceinline__ void rb_chain_signal(unsigned* counter) {       // all threads of the workgroup call
+#if defined(RB_HOST_INTERP)
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = *counter + 1u;
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!WT) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                   // write the XCD's dirty lines back
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (the fence's own wait, restated: Guideline 16 pitfall 12)
+    }
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
+}
+template <bool COH>
+__device__ __forceinline__ void rb_chain_wait(const unsigned* counter, unsigned target, unsigned* err) {   // all threads call
+#if defined(RB_HOST_INTERP)
+  if (threadIdx.x == 0 && (int)(*counter - target) < 0) *err = 1u;         // blocks run in index order: producers are done
+  __syncthreads();
+#else
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~1 s
+    }
+    if (!COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+#endif
+}
+
 // 16-byte global/LDS accesses (pointers must be 16-byte aligned)
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -164,6 +213,28 @@ __device__ __forceinline__ float4 rb_ld4_buf(const rb_buf& b, unsigned lane_off,
   float4 v;
   v.x = __uint_as_float(t.x); v.y = __uint_as_float(t.y); v.z = __uint_as_float(t.z); v.w = __uint_as_float(t.w);
   return v;
+#endif
+}
+
+// agent-coherent variants (sc1): the load is served from the point where the XCDs agree (not from this CU's L1 / a stale
+// line of this XCD's L2) — for data another workgroup of the SAME launch produced (rb_chain_*)
+__device__ __forceinline__ float4 rb_ld4_buf_sc1(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
+#if defined(RB_HOST_INTERP)
+  return rb_ld4_buf(b, lane_off, uniform_off);
+#else
+  typedef unsigned int rb_v4u __attribute__((ext_vector_type(4)));
+  const rb_v4u t = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)lane_off, (int)uniform_off, 16);   // aux bit 4 = sc1
+  float4 v;
+  v.x = __uint_as_float(t.x); v.y = __uint_as_float(t.y); v.z = __uint_as_float(t.z); v.w = __uint_as_float(t.w);
+  return v;
+#endif
+}
+__device__ __forceinline__ float rb_ld1_buf_sc1(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
+#if defined(RB_HOST_INTERP)
+  if ((size_t)lane_off + uniform_off + 4 > b.nbytes) return 0.0f;
+  return *reinterpret_cast<const float*>(b.base + lane_off + uniform_off);
+#else
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, (int)lane_off, (int)uniform_off, 16));
 #endif
 }
 

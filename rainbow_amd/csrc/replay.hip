@@ -797,6 +797,12 @@ int rb_replay_failed_samples(rb_replay_t* r, int64_t* count) {
   return RB_OK;
 }
 
+int rb_replay_reset_failed_samples(rb_replay_t* r) {
+  RB_REQUIRE(r != nullptr, "rb_replay_reset_failed_samples: NULL handle");
+  *(volatile int32_t*)r->fail_host = 0;        // (a failed launch still in flight re-increments it when it completes)
+  return RB_OK;
+}
+
 int rb_replay_position(rb_replay_t* r, int64_t* index, int32_t* full) {
   RB_REQUIRE(r != nullptr, "rb_replay_position: NULL handle");
   if (index) *index = r->host_index;

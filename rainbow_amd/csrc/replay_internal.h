@@ -94,6 +94,11 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
   float* s_red = lds + 8 * HS + NMAX;
   float* s_heap = lds + 8 * HS + NMAX + 16;
   const int i = (int)threadIdx.x;
+  // ReplayMemory.update_priorities after a sampler launch that gave up (no valid batch within max_attempts: the reference
+  // would still be spinning in memory.py:128-132): the tree indices of that draw are NOT a legal batch — a never-written
+  // leaf or one straddling the write head would receive a non-zero priority and defeat the `prob != 0` validity test of
+  // every later draw.  The write-back of such a batch is dropped (block-uniform).
+  if (apply_pow && v.hdr->last_status != 0) return;
   // dense top: only when the tree is deeper than the top itself (block-uniform)
   const bool dense = v.levels > RB_UPD_TOP;
   const int path_levels = dense ? v.levels - RB_UPD_TOP : v.levels;

@@ -162,6 +162,10 @@ class ReplayMemory:
         L.check(self._lib, self._lib.rb_replay_failed_samples(self._h, C.byref(n)))
         return int(n.value)
 
+    def reset_failed_samples(self):
+        """Zero that counter (the failure has been reported to the caller)."""
+        L.check(self._lib, self._lib.rb_replay_reset_failed_samples(self._h))
+
     def frame_source(self):
         """(frames_ptr, windows_ptr, window_len): lets the learner read frames straight from the ring (zero-copy)."""
         if not hasattr(self, "_bufs"):

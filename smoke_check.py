@@ -1,6 +1,7 @@
 """smoke(): ONE tiny learn step of the hot path on cuda:0 (replay sample -> learn -> clip -> Adam ->
 priority update through librainbow_hip.so), checked against the CPU oracle.  The oracle is only
-the checker here; the measured/shipped path never touches it."""
+the checker here; the measured/shipped path never touches it.  Lives beside __graft_entry__.py, NOT inside the rainbow_amd
+package: nothing under rainbow_amd/ imports the oracle."""
 import os
 import sys
 import types
@@ -10,7 +11,7 @@ import torch
 
 
 def run(verbose=True):
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.abspath(__file__))
     if root not in sys.path:
         sys.path.insert(0, root)
     from oracle import learner_oracle as O
@@ -53,4 +54,5 @@ def run(verbose=True):
     assert np.array_equal(idx, batch["tree_idxs"]), (idx, batch["tree_idxs"])
     np.testing.assert_allclose(loss, want["loss"], rtol=2e-5, atol=1e-6)
     if verbose:
-        print("smoke ok: loss", loss, "grad_norm", float(agent._norm.item()))
+        from rainbow_amd import _lib
+        print("smoke ok: loss", loss, "grad_norm", float(agent._norm.item()), "library source hash", _lib.source_hash(_lib.load()))

@@ -263,6 +263,44 @@ def sampler_gives_up_check(lib, mem):
         assert np.array_equal(mem.download(outs["weights"]), np.zeros(B, np.float32))
         L.check(lib, lib.rb_replay_failed_samples(ad.h, C.byref(n0)))
         assert n0.value == k + 1
+    # ... and the failed draw leaves NO trace: (a) ReplayMemory.update_priorities on its (illegal) indices is dropped,
+    tree0 = ad.tree()
+    losses = mem.upload(np.full(B, 2.5, np.float32))
+    L.check(lib, lib.rb_replay_update_priorities(ad.h, mem.ptr(outs["tree_idx"]), mem.ptr(losses), B, mem.stream))
+    mem.sync()
+    assert np.array_equal(ad.tree(), tree0), "update_priorities after a failed draw changed the sum-tree"
+    # (b) a learner whose priority sink is this replay skips the fused write-back, the optimiser update and the
+    # device-resident step number (Adam's momentum would otherwise move the parameters on a zero gradient)
+    from cabi_adapter import CAbiLearnAdapter
+    from oracle import learner_oracle as O
+    c = LEARN_CONFIGS["canon"]
+    assert c["batch"] == B
+    cfg = O.Config(**c)
+    la = CAbiLearnAdapter(lib, mem, "canon")
+    la.load(O.init_params(cfg, 31), O.init_params(cfg, 32))
+    if not isinstance(la.adam_m, np.ndarray):
+        la.adam_m.fill_(0.25)                 # non-zero momentum: an un-skipped Adam pass WOULD move the parameters
+    else:
+        la.adam_m[:] = 0.25
+    step_dev = mem.empty((1,), np.int64)
+    L.check(lib, lib.rb_learner_set_step_counter(la.h, mem.ptr(step_dev)))
+    L.check(lib, lib.rb_learner_set_priority_sink(la.h, ad.h, mem.ptr(outs["tree_idx"])))
+    p0, m0 = mem.download(la.p_on.detach() if hasattr(la.p_on, "detach") else la.p_on), mem.download(la.adam_m)
+    la.reset_noise_online(rs.randn(O.noise_draw_count(cfg)).astype(np.float32))
+    batch = make_batch(c, 17)
+    batch["weights"] = np.zeros(B, np.float32)                    # what the sampler wrote
+    out = la.learn_step(batch, rs.randn(O.noise_draw_count(cfg)).astype(np.float32))
+    assert out["grad_norm"] == 0.0
+    assert np.array_equal(mem.download(la.p_on.detach() if hasattr(la.p_on, "detach") else la.p_on), p0), "parameters moved"
+    assert np.array_equal(mem.download(la.adam_m), m0), "Adam moments moved"
+    assert int(mem.download(step_dev)[0]) == 0, "device step counter advanced"
+    assert np.array_equal(ad.tree(), tree0), "fused priority write-back ran on an illegal batch"
+    L.check(lib, lib.rb_learner_set_priority_sink(la.h, None, None))
+    la.close()
+    # (c) the counter can be cleared once the failure has been reported
+    L.check(lib, lib.rb_replay_reset_failed_samples(ad.h))
+    L.check(lib, lib.rb_replay_failed_samples(ad.h, C.byref(n0)))
+    assert n0.value == 0
     # the host mirror of the write position needs no device round trip and follows a raw header restore
     idx, full = C.c_int64(-1), C.c_int32(-1)
     L.check(lib, lib.rb_replay_position(ad.h, C.byref(idx), C.byref(full)))

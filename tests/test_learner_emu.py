@@ -345,3 +345,27 @@ def test_train_step_entry_point_equals_its_three_calls(emu):
         assert rp1.raw_header().last_status == 0
     assert not np.array_equal(a["params"], ad1._flat(O.init_params(O.Config(**c), 1))), "the online net must have moved"
     ad1.close(); ad2.close(); rp1.close(); rp2.close()
+
+
+def test_sync_target_copies_parameters_and_noise(emu):
+    """Agent.update_target_net (agent.py:102-103) is load_state_dict(online.state_dict()): the registered epsilon BUFFERS
+    travel with the parameters (model.py:19,22).  rb_learner_sync_target must therefore leave target == online for both
+    the parameter buffer and the (factorised) noise buffer — and leave the online side alone."""
+    from rainbow_amd import _lib as L
+    name = "atoms21"
+    c = scenarios.LEARN_CONFIGS[name]
+    cfg = O.Config(**c)
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    ad.load(O.init_params(cfg, 3), O.init_params(cfg, 4))
+    rs = np.random.RandomState(8)
+    draws = O.noise_draw_count(cfg)
+    ad.reset_noise_online(rs.randn(draws).astype(np.float32))
+    r = ad.mem.upload(rs.randn(draws).astype(np.float32))
+    L.check(emu, emu.rb_learner_reset_noise(ad.h, 1, ad.mem.ptr(r), None))          # a DIFFERENT target noise first
+    p_on, z_on = ad.p_on.copy(), ad.z_on.copy()
+    assert not np.array_equal(ad.z_tg, z_on) and not np.array_equal(ad.p_tg, p_on)
+    assert np.abs(z_on).sum() > 0
+    L.check(emu, emu.rb_learner_sync_target(ad.h, None))
+    assert np.array_equal(ad.p_tg, p_on) and np.array_equal(ad.z_tg, z_on)
+    assert np.array_equal(ad.p_on, p_on) and np.array_equal(ad.z_on, z_on)
+    ad.close()

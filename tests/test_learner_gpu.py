@@ -527,3 +527,22 @@ def test_one_call_step_equals_three_call_step(hip, monkeypatch):
     for k in ("params", "m", "v", "losses", "idx"):
         assert np.array_equal(a[k], b[k]), k
     assert a["total"] == b["total"]
+
+
+def test_update_target_net_copies_noise_buffers_too(hip):
+    """agent.py:102-103: target.load_state_dict(online.state_dict()) carries the epsilon buffers (model.py:19,22) — after
+    update_target_net the target's noise IS the online noise (until the next learn() redraws it, agent.py:74)."""
+    from rainbow_amd.agent import Agent
+    env = types.SimpleNamespace(action_space=lambda: 4)
+    torch.manual_seed(5)
+    agent = Agent(_args(), env)
+    agent.reset_noise(torch.randn(int(agent.noise.numel())))          # injected online draw (materialised at once)
+    agent._reset_target_noise()                                       # device RNG: a different target draw
+    with torch.no_grad():
+        agent.params.add_(0.5)
+    torch.cuda.synchronize()
+    assert not torch.equal(agent.target_noise, agent.noise) and not torch.equal(agent.target_params, agent.params.detach())
+    agent.update_target_net()
+    torch.cuda.synchronize()
+    assert torch.equal(agent.target_noise, agent.noise) and float(agent.noise.abs().sum()) > 0
+    assert torch.equal(agent.target_params, agent.params.detach())

@@ -1,0 +1,63 @@
+"""Per-workgroup timeline of the conv launches of one learn step (RB_STAMP build: bash tools/build_variant.sh stamp -DRB_STAMP;
+RAINBOW_AMD_LIB=$PWD/rainbow_amd/librainbow_hip_stamp.so python tools/wg_timeline.py [config]).  For every traced kernel:
+when its workgroups start / finish relative to the first start, the median duration of each phase, how many CUs it used and
+how many workgroups shared a CU."""
+import ctypes as C
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.getcwd())
+import bench  # noqa: E402
+from rainbow_amd import _lib as L  # noqa: E402
+from rainbow_amd.agent import Agent  # noqa: E402
+from rainbow_amd.memory import ReplayMemory  # noqa: E402
+
+cfgname = sys.argv[1] if len(sys.argv) > 1 else "pong-canonical-b32"
+dev = torch.device("cuda", 0)
+cfg = dict(bench.CONFIGS[cfgname])
+cfg["capacity"] = 100000
+args = bench.make_args(cfg, dev)
+env = types.SimpleNamespace(action_space=lambda: cfg["actions"])
+agent = Agent(args, env)
+mem = ReplayMemory(args, cfg["capacity"], seed=7)
+bench.fill_replay(mem, cfg["capacity"], cfg["actions"], seed=0)
+lib = L.load()
+K, W = 8, 2048
+buf = (C.c_longlong * (K * W * 8))()
+lib.rb_debug_wgtrace.argtypes = [C.c_void_p, C.c_int]
+for it in range(40):
+    agent.reset_noise()
+    agent.learn(mem)
+torch.cuda.synchronize()
+lib.rb_debug_wgtrace(buf, 1)
+agent.reset_noise()
+agent.learn(mem)
+torch.cuda.synchronize()
+lib.rb_debug_wgtrace(buf, 0)
+a = np.frombuffer(buf, dtype=np.int64).reshape(K, W, 8).astype(np.float64)
+names = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "conv3_dx", "conv2_dx", "conv_dw", "reduce", "other"]
+phase = ["stage weights", "wait", "stage input", "mfma", "epilogue", "signal"]
+t0_all = None
+for k in range(K):
+    rows = a[k][a[k][:, 0] > 0]
+    if not len(rows):
+        continue
+    if t0_all is None:
+        t0_all = rows[:, 0].min()
+    t0 = rows[:, 0].min()
+    us = lambda x: x * 0.01
+    print("== %s: %d workgroups; first start at +%.2f us of the first traced kernel" % (names[k], len(rows), us(t0 - t0_all)))
+    print("   starts: median +%.2f  p90 +%.2f  last +%.2f | ends: median +%.2f  last +%.2f us"
+          % (us(np.median(rows[:, 0]) - t0), us(np.percentile(rows[:, 0], 90) - t0), us(rows[:, 0].max() - t0),
+             us(np.median(rows[:, 6]) - t0), us(rows[:, 6].max() - t0)))
+    d = np.diff(rows[:, 0:7], axis=1)
+    print("   phases (median / p90 us): " + "  ".join("%s %.2f/%.2f" % (phase[i], us(np.median(d[:, i])), us(np.percentile(d[:, i], 90))) for i in range(6)))
+    print("   workgroup total: median %.2f  p90 %.2f  max %.2f us" % (us(np.median(rows[:, 6] - rows[:, 0])), us(np.percentile(rows[:, 6] - rows[:, 0], 90)), us((rows[:, 6] - rows[:, 0]).max())))
+    hw = rows[:, 7].astype(np.int64)
+    cu = (hw >> 16) * 4096 + ((hw >> 8) & 0xff)          # XCC id, (se, sh, cu) bits of HW_ID
+    uniq, cnt = np.unique(cu, return_counts=True)
+    print("   ran on %d distinct CUs; workgroups per CU: max %d, mean %.2f" % (len(uniq), cnt.max(), cnt.mean()))
