@@ -131,23 +131,47 @@ struct ConvFwdLdsSize {
   static constexpr int KGRAN = WREG ? 8 * RB_CONV_WAVES : 2 * RB_CONV_WAVES;
   static constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
   static constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
-  static constexpr int OPS = (WREG ? 0 : KPAD * 33) + (KMAX / G::KK) * PR * G::IH;     // [weights then] patch, contiguous
+  // the weight slab keeps its GLOBAL orientation in LDS: 32 rows (output channels) of KPAD + 4 floats.  Staging is then
+  // 16-byte loads -> 16-byte LDS stores, conflict-free (the former [k][33] transposed image took 16 scalar stores per
+  // thread at 8-way bank conflicts: 1-1.5 us of every workgroup, and it serialised the two first-layer workgroups of a CU —
+  // tools/wg_timeline.py: 5.3 us input stage for the second one); the MFMA operand read (lane = row) is 4-way conflicted
+  // instead, one read per NT MFMAs, hidden under them.
+  static constexpr int WS = KPAD + 4;
+  // patch rows are stored DE-INTERLEAVED by stride phase: x -> (x % S) * SUB + x / S, SUB = ceil(IH / S).  The lanes of an
+  // MFMA operand read are neighbouring output positions, i.e. inputs S apart: in the plain row that is a stride-S access
+  // (4-way bank conflicts in the first layer, 2-way in the second; the MFMA loop was LDS-bound enough that the two
+  // first-layer workgroups of a CU stretched each other's staging and epilogue from 1.4 / 2.4 to 4.9 / 4.1 us,
+  // tools/wg_timeline.py); de-interleaved they are consecutive words.
+  static constexpr int SUB = (G::IH + G::S - 1) / G::S;
+  static constexpr int RP = G::S * SUB;                    // row pitch (>= IH)
+  static_assert((G::OH - 1) + (G::KS - 1) / G::S < SUB, "a tap's positions stay inside their phase's sub-row");
+  static constexpr int OPS = (WREG ? 0 : 32 * WS) + (KMAX / G::KK) * PR * RP;     // [weights then] patch, contiguous
   static constexpr int WSZ = OPS > RED ? OPS : RED;
   static constexpr int FLOATS = WSZ + KPAD;                // + the tap table (ints)
 };
 // body with explicit block coordinates and caller-provided LDS, so the layers of the stack can share one launch
 // COH bit 0: the input image was produced inside this launch — read it with agent-coherent (sc1) loads after the wait;
 // bit 1: the output is consumed inside this launch — store it write-through (sc1).  0 with a link: fences instead.
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false, int COH = 0>
+// F32SRC (first layer only): the input is a.src.f32 (act / evaluate: float states) instead of the u8 frames.  The kind of
+// the input loads is a compile-time property so that only ONE staging register array exists (all three alive at once cost
+// the first layer its second workgroup per CU).
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false, int COH = 0, bool F32SRC = false>
 __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx, int by, int img, float* smem, const ChainLink& link) {
   typedef ConvFwdLdsSize<G, NT, PR, KMAX, WREG> SZ;
   constexpr int KPAD = SZ::KPAD;
-  constexpr int PLANE = PR * G::IH;                 // floats per channel in the patch
+  constexpr int SUB = SZ::SUB, RP = SZ::RP;
+  constexpr int PLANE = PR * RP;                    // floats per channel in the patch
   constexpr int CMAX = KMAX / G::KK;
   float* s_all = smem;
   int* s_koff = reinterpret_cast<int*>(smem + SZ::WSZ);
+  constexpr int WS = SZ::WS;
+  // patch cell of (channel c, element `off` of the channel's [rows][IH] patch)
+  auto pcell = [&](int c, int off) -> int {
+    const int r = off / G::IH, x = off - r * G::IH;
+    return c * PLANE + r * RP + (x % G::S) * SUB + x / G::S;
+  };
   float* s_w = s_all;
-  float* s_patch = s_all + (WREG ? 0 : KPAD * 33);
+  float* s_patch = s_all + (WREG ? 0 : 32 * WS);
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int SB = G::KS == 8 ? 0 : G::KS == 4 ? 8 : 16;    // stamp slots per layer (RB_STAMP builds only)
@@ -158,6 +182,12 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   (void)wgi;
   RB_WGT(WK, wgi, 0);
   RB_WGT_HW(WK, wgi);
+#if !defined(RB_HOST_INTERP)
+  // staging outranks the MFMA phase of a co-resident workgroup: two first-layer workgroups share a CU, and the one that
+  // got there second spent 4.4 us converting and storing 7 KB of frames while the first ran its MFMA loop (0.9 us alone;
+  // tools/_fine_stage.py) — the wave scheduler favours the older waves.  Dropped again before this workgroup's own MFMAs.
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const int net = img < a.n_on ? 0 : 1;
   const int cout0 = by * 32;
   const int p0 = bx * PCH;
@@ -168,122 +198,258 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   int rows = G::IH - iy0;
   if (rows > PR) rows = PR;
 
-  // ---- stage: weights (transposed into LDS, or this wave's slice into registers), k -> patch offset table, input patch
+  // ---- stage: weights (transposed into LDS, or this wave's slice into registers), k -> patch offset table, input patch.
+  // Per-workgroup timeline (tools/wg_timeline.py): weights 1.8-2.3 us and input 1.9-3.8 us used to be two memory round
+  // trips in sequence (load, store to LDS, load, store to LDS).  Now every global load of BOTH operands is issued before the
+  // first LDS store — first-layer frames: the window-table entries first, they gate the frame addresses — and the LDS
+  // stores follow in issue order.  (Chain mode: the weight loads are in flight while the workgroup waits for its image.)
   constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time: the MFMA loop is fully unrolled
   constexpr int HW = KW / 2;
+  const int rows_valid_w = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
   float areg[WREG ? HW : 1];
+  // weights: the fast path of rb_stage_weights_t split into issue (loads) and commit (transposing LDS stores)
+  constexpr int WR = 4, WQ = (KMAX + 255) / 256;      // 32 rows / 8 waves; K <= KMAX: quads of a row per lane
+  const bool w_fast = !WREG && (K & 3) == 0 && (K >> 2) <= 64 * WQ;
+  float4 wv[WREG ? 1 : WR][WREG ? 1 : WQ];
+  // input: one batch of loads per thread (every geometry of the two networks fits one batch; more: the loops after it)
+  constexpr bool x_u8 = FIRST && !F32SRC;
+  constexpr bool x_vec = !x_u8 && (G::IH % 4) == 0;   // then per_c, iy0 * IH and IP are multiples of 4 as well
+  // u8 frames, stride-4 geometry (the canonical first layer): DWORD loads — the four bytes of a dword are the four stride
+  // phases of one de-interleaved index, so consecutive lanes store consecutive words of each phase's sub-row (conflict-free
+  // scalar stores; 16-byte loads put 16-byte-strided lanes on 8 banks)
+  constexpr bool x_dw = x_u8 && G::S == 4 && (G::IH % 4) == 0;
+  constexpr int XD = x_dw ? (CMAX * PR * G::IH / 4 + RB_CONV_THREADS - 1) / RB_CONV_THREADS : 1;
+  constexpr int XU = (x_u8 && !x_dw) ? 2 : 1, XV = x_vec ? 8 : 1, XS = (!x_u8 && !x_vec) ? 12 : 1;
+  const float* xbase = x_u8 ? nullptr : (FIRST ? a.src.f32 + (int64_t)img * cin * G::IP : a.in_f + (int64_t)img * cin * G::IP);
+  const int per_c = rows * G::IH;                     // elements per channel of the patch (u8: bytes, a 16-byte multiple for the frame geometries)
+  const int v16 = per_c >> 4, total16 = cin * v16;
+  const int v4 = per_c >> 2, total4 = cin * v4;
+  const int total1 = cin * per_c;
+  const uint8_t* fp[x_dw ? XD : XU];
+  uint4 xu[XU];
+  unsigned xd[XD];
+  const int dpc = per_c >> 2, total_dw = cin * dpc;   // x_dw: dwords per channel of the patch
+  float4 xv[XV];
+  float xs[XS];
+  // zero-copy frames: the window-table entries are REQUESTED here and turned into frame addresses only after the weight
+  // loads have been issued (an address formed at once put the table's round trip in front of every other load: 1.5 us
+  // from workgroup start to the first weight load, tools/_fine_stage.py)
+  int32_t widx[x_dw ? XD : XU];
+  if constexpr (x_u8) {
+#pragma unroll
+    for (int i = 0; i < (x_dw ? XD : XU); ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      const int c = x_dw ? e / dpc : e / v16;
+      widx[i] = -1;
+      if ((x_dw ? e < total_dw : e < total16) && a.src.ring) {
+        const int sample = img < a.src.B ? img : (img - a.src.B) % a.src.B;
+        widx[i] = a.src.win[(int64_t)sample * a.src.win_len + (img < a.src.B ? c : a.src.n_step + c)];
+      }
+    }
+  }
   if constexpr (WREG) {
     const int ml_ = lane & 31, kh_ = lane >> 5;
-    const int rows_valid = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
-    const float* wrow = a.w[net] + (int64_t)(cout0 + (ml_ < rows_valid ? ml_ : 0)) * K;
+    const float* wrow = a.w[net] + (int64_t)(cout0 + (ml_ < rows_valid_w ? ml_ : 0)) * K;
     const int k0 = wave * KW + kh_ * HW;
     if ((K & 3) == 0) {
 #pragma unroll
       for (int j4 = 0; j4 < HW / 4; ++j4) {
         const int k = k0 + 4 * j4;
-        float4 v4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (k < K && ml_ < rows_valid) v4 = rb_ld4(wrow + k);            // K % 4 == 0: a quad is inside or outside as a whole
-        areg[4 * j4 + 0] = v4.x; areg[4 * j4 + 1] = v4.y; areg[4 * j4 + 2] = v4.z; areg[4 * j4 + 3] = v4.w;
+        float4 v4_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < K && ml_ < rows_valid_w) v4_ = rb_ld4(wrow + k);            // K % 4 == 0: a quad is inside or outside as a whole
+        areg[4 * j4 + 0] = v4_.x; areg[4 * j4 + 1] = v4_.y; areg[4 * j4 + 2] = v4_.z; areg[4 * j4 + 3] = v4_.w;
       }
     } else {                                           // odd history lengths
 #pragma unroll
-      for (int j = 0; j < HW; ++j) areg[j] = (k0 + j < K && ml_ < rows_valid) ? wrow[k0 + j] : 0.0f;
+      for (int j = 0; j < HW; ++j) areg[j] = (k0 + j < K && ml_ < rows_valid_w) ? wrow[k0 + j] : 0.0f;
     }
-  } else {
-    rb_stage_weights_t(s_w, a.w[net], cout0, a.cout - cout0 < 32 ? a.cout - cout0 : 32, K, KPAD);
-  }
-  for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
-    const int kc = k < K ? k : K - 1;
-    const int c = kc / G::KK, r = kc % G::KK;
-    s_koff[k] = c * PLANE + (r / G::KS) * G::IH + (r % G::KS);
+  } else if (w_fast) {
+    const int kq = K >> 2;
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+      const int m = wave + r * RB_CONV_WAVES;
+#pragma unroll
+      for (int i = 0; i < WQ; ++i) {
+        const int q = lane + 64 * i;
+        wv[r][i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (m < rows_valid_w && q < kq) wv[r][i] = rb_ld4(a.w[net] + (int64_t)(cout0 + m) * K + 4 * q);
+      }
+    }
   }
   RB_WGT(WK, wgi, 1);
   if (link.wait_ctr) rb_chain_wait<(COH & 1) != 0>(link.wait_ctr, link.wait_target, link.err);   // the input image is final from here on
   RB_WGT(WK, wgi, 2);
-  if (FIRST && !a.src.f32) {
-    const int per_c = rows * G::IH;                 // bytes per channel, 16-byte multiple for the frame geometries
-    const int v16 = per_c >> 4;
-    const int total16 = cin * v16;
-    for (int e0 = 0; e0 < total16; e0 += 2 * RB_CONV_THREADS) {        // both 16-byte loads of a thread are in flight together
-      uint4 raw[2];
+  if constexpr (x_u8) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = e0 + i * RB_CONV_THREADS + t;
-        raw[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (e < total16) {
-          const int c = e / v16, q = e - c * v16;
-          const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
-          if (fp) raw[i] = *reinterpret_cast<const uint4*>(fp + iy0 * G::IH + q * 16);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = e0 + i * RB_CONV_THREADS + t;
-        if (e < total16) {
-          const int c = e / v16, q = e - c * v16;
-          float* d = s_patch + c * PLANE + q * 16;
-          const unsigned wds[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
-#pragma unroll
-          for (int wd = 0; wd < 4; ++wd)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) d[wd * 4 + b] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
-        }
-      }
-    }
-    for (int e = t; e < cin * (per_c & 15); e += RB_CONV_THREADS) {   // (no tail for 84-wide frames; kept for generality)
-      const int c = e / (per_c & 15), q = (v16 << 4) + e % (per_c & 15);
-      const uint8_t* fp = rb_frame_ptr(a.src, img, c, cin, G::IP);
-      s_patch[c * PLANE + q] = fp ? rb_unit(fp[iy0 * G::IH + q]) : 0.0f;
-    }
-  } else {
-    const float* base = FIRST ? a.src.f32 + (int64_t)img * cin * G::IP : a.in_f + (int64_t)img * cin * G::IP;
-    const int per_c = rows * G::IH;
-    if ((per_c & 3) == 0 && ((iy0 * G::IH) & 3) == 0 && (G::IP & 3) == 0) {
-      const int v4 = per_c >> 2;
-      const int total = cin * v4;
-      for (int e0 = 0; e0 < total; e0 += 8 * RB_CONV_THREADS) {       // 8 float4 loads in flight per thread
-        float4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int e = e0 + i * RB_CONV_THREADS + t;
-          if (e < total) {
-            const int c = e / v4, q = e - c * v4;
-            if constexpr ((COH & 1) != 0) v[i] = rb_ld4_buf_sc1(rb_make_buf(base), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q * 4), 0u);
-            else v[i] = rb_ld4(base + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int e = e0 + i * RB_CONV_THREADS + t;
-          if (e < total) {
-            const int c = e / v4, q = e - c * v4;
-            float* d = s_patch + c * PLANE + q * 4;
-            d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
-          }
-        }
-      }
-    } else {
-      const int total = cin * per_c;
-      for (int e0 = 0; e0 < total; e0 += 12 * RB_CONV_THREADS) {      // 12 scalar loads in flight per thread
-        float v[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          const int e = e0 + i * RB_CONV_THREADS + t;
-          if (e < total) {
-            const int c = e / per_c, q = e - c * per_c;
-            if constexpr ((COH & 1) != 0) v[i] = rb_ld1_buf_sc1(rb_make_buf(base), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q), 0u);
-            else v[i] = base[(int64_t)c * G::IP + iy0 * G::IH + q];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          const int e = e0 + i * RB_CONV_THREADS + t;
-          if (e < total) { const int c = e / per_c, q = e - c * per_c; s_patch[c * PLANE + q] = v[i]; }
-        }
+    for (int i = 0; i < (x_dw ? XD : XU); ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      const int c = x_dw ? e / dpc : e / v16;
+      fp[i] = nullptr;
+      if (x_dw ? e < total_dw : e < total16) {
+        if (a.src.ring) fp[i] = widx[i] < 0 ? nullptr : a.src.ring + (int64_t)widx[i] * G::IP;       // rb_frame_ptr, second half
+        else fp[i] = rb_frame_ptr(a.src, img, c, cin, G::IP);
       }
     }
   }
+  // ---- input loads (first batch)
+  if constexpr (x_dw) {
+#pragma unroll
+    for (int i = 0; i < XD; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      xd[i] = 0u;
+      if (e < total_dw && fp[i]) xd[i] = *reinterpret_cast<const unsigned*>(fp[i] + iy0 * G::IH + 4 * (e - (e / dpc) * dpc));
+    }
+  } else if constexpr (x_u8) {
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        xu[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < total16 && fp[i]) xu[i] = *reinterpret_cast<const uint4*>(fp[i] + iy0 * G::IH + (e - (e / v16) * v16) * 16);
+      }
+    }
+  } else if constexpr (x_vec) {
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      if (e < total4) {
+        const int c = e / v4, q = e - c * v4;
+        if constexpr ((COH & 1) != 0) xv[i] = rb_ld4_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q * 4), 0u);
+        else xv[i] = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      if (e < total1) {
+        const int c = e / per_c, q = e - c * per_c;
+        if constexpr ((COH & 1) != 0) xs[i] = rb_ld1_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q), 0u);
+        else xs[i] = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
+      }
+    }
+  }
+#if defined(RB_STAMP) && defined(RB_STAMP_FINE)
+  RB_WGT(WK + 4, wgi, 0);                               // (fine: loads issued)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RB_WGT(WK + 4, wgi, 1);                               // (fine: thread 0's loads have landed)
+#endif
+  // ---- LDS: tap table (no memory operand), then the weights, then the input
+  for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
+    const int kc = k < K ? k : K - 1;
+    const int c = kc / G::KK, r = kc % G::KK;
+    s_koff[k] = c * PLANE + (r / G::KS) * RP + ((r % G::KS) % G::S) * SUB + (r % G::KS) / G::S;
+  }
+  if constexpr (!WREG) {
+    if (w_fast) {
+      const int kq = K >> 2;
+#pragma unroll
+      for (int r = 0; r < WR; ++r) {
+        const int m = wave + r * RB_CONV_WAVES;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+          const int q = lane + 64 * i;
+          if (q < kq) rb_st4(s_w + m * WS + 4 * q, wv[r][i]);        // rows >= rows_valid were loaded as zeros
+        }
+      }
+    } else {                                           // odd history lengths: scalar staging
+      for (int m = wave; m < 32; m += RB_CONV_WAVES)
+        for (int k = lane; k < K; k += 64) s_w[m * WS + k] = m < rows_valid_w ? a.w[net][(int64_t)(cout0 + m) * K + k] : 0.0f;
+    }
+    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(e & 31) * WS + K + (e >> 5)] = 0.0f;   // columns [K, KPAD)
+  }
+  if constexpr (x_dw) {
+    constexpr int DPR = G::IH / 4;                       // dwords per input row
+#pragma unroll
+    for (int i = 0; i < XD; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      if (e < total_dw) {
+        const int c = e / dpc, d = e - c * dpc;
+        const int r = d / DPR, xi = d - r * DPR;        // bytes 4 xi .. 4 xi + 3 of row r: phases 0..3 of de-interleaved index xi
+        float* cell = s_patch + c * PLANE + r * RP + xi;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cell[b * SUB] = rb_unit((uint8_t)((xd[i] >> (8 * b)) & 0xFFu));
+      }
+    }
+  } else if constexpr (x_u8) {
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int e = i * RB_CONV_THREADS + t;
+        if (e < total16) {
+          const int c = e / v16, q = e - c * v16;
+          const unsigned wds[4] = {xu[i].x, xu[i].y, xu[i].z, xu[i].w};
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s_patch[pcell(c, q * 16 + wd * 4 + b)] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+        }
+      }
+      for (int e = XU * RB_CONV_THREADS + t; e < total16; e += RB_CONV_THREADS) {          // beyond one batch (not the frame geometries)
+        const int c = e / v16, q = e - c * v16;
+        const uint8_t* f = rb_frame_ptr(a.src, img, c, cin, G::IP);
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (f) raw = *reinterpret_cast<const uint4*>(f + iy0 * G::IH + q * 16);
+        const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) s_patch[pcell(c, q * 16 + wd * 4 + b)] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
+      }
+      for (int e = t; e < cin * (per_c & 15); e += RB_CONV_THREADS) {   // (no tail for 84-wide frames; kept for generality)
+        const int c = e / (per_c & 15), q = (v16 << 4) + e % (per_c & 15);
+        const uint8_t* f = rb_frame_ptr(a.src, img, c, cin, G::IP);
+        s_patch[pcell(c, q)] = f ? rb_unit(f[iy0 * G::IH + q]) : 0.0f;
+      }
+    }
+  } else if constexpr (x_vec) {
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      if (e < total4) {
+        const int c = e / v4, q = e - c * v4;
+        if constexpr (G::S == 1) { rb_st4(s_patch + c * PLANE + q * 4, xv[i]); }       // RP == IH: the quad stays a quad
+        else if constexpr (G::S == 2 && (SUB % 2) == 0) {
+          // x, x+2 are neighbours of phase 0 and x+1, x+3 of phase 1: two 8-byte stores, lanes 8 bytes apart (conflict-free)
+          const int off = q * 4, r = off / G::IH, x = off - r * G::IH;
+          float* cell = s_patch + c * PLANE + r * RP + x / 2;
+          *reinterpret_cast<float2*>(cell) = make_float2(xv[i].x, xv[i].z);
+          *reinterpret_cast<float2*>(cell + SUB) = make_float2(xv[i].y, xv[i].w);
+        } else {
+          s_patch[pcell(c, q * 4 + 0)] = xv[i].x; s_patch[pcell(c, q * 4 + 1)] = xv[i].y;
+          s_patch[pcell(c, q * 4 + 2)] = xv[i].z; s_patch[pcell(c, q * 4 + 3)] = xv[i].w;
+        }
+      }
+    }
+    for (int e = XV * RB_CONV_THREADS + t; e < total4; e += RB_CONV_THREADS) {               // beyond one batch
+      const int c = e / v4, q = e - c * v4;
+      float4 v;
+      if constexpr ((COH & 1) != 0) v = rb_ld4_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q * 4), 0u);
+      else v = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+      s_patch[pcell(c, q * 4 + 0)] = v.x; s_patch[pcell(c, q * 4 + 1)] = v.y;
+      s_patch[pcell(c, q * 4 + 2)] = v.z; s_patch[pcell(c, q * 4 + 3)] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = i * RB_CONV_THREADS + t;
+      if (e < total1) { const int c = e / per_c, q = e - c * per_c; s_patch[pcell(c, q)] = xs[i]; }
+    }
+    for (int e = XS * RB_CONV_THREADS + t; e < total1; e += RB_CONV_THREADS) {               // beyond one batch
+      const int c = e / per_c, q = e - c * per_c;
+      float v;
+      if constexpr ((COH & 1) != 0) v = rb_ld1_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q), 0u);
+      else v = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
+      s_patch[pcell(c, q)] = v;
+    }
+  }
+#if defined(RB_STAMP) && defined(RB_STAMP_FINE)
+  RB_WGT(WK + 4, wgi, 2);                               // (fine: thread 0's LDS stores issued; then the barrier)
+#endif
   __syncthreads();
+#if !defined(RB_HOST_INTERP)
+  __builtin_amdgcn_s_setprio(0);
+#endif
   RB_CSTAMP(SB + 1);
   RB_WGT(WK, wgi, 3);
 
@@ -294,7 +460,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   for (int nt = 0; nt < NT; ++nt) {
     int p = p0 + nt * 32 + (lane & 31);
     if (p > G::P - 1) p = G::P - 1;                  // clamped lanes are never stored
-    noff[nt] = (p / G::OH - oy0) * G::S * G::IH + (p % G::OH) * G::S;
+    noff[nt] = (p / G::OH - oy0) * G::S * RP + (p % G::OH);        // (de-interleaved rows: neighbouring outputs, neighbouring words)
   }
   rb_f32x16 acc[NT];
 #pragma unroll
@@ -318,37 +484,47 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   for (int j = 0; j < HW; ++j) {
     float av;
     if constexpr (WREG) av = areg[j];
-    else av = s_w[(kb + 2 * j + kh) * 33 + ml];
+    else av = s_w[ml * WS + kb + 2 * j + kh];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
   RB_CSTAMP(SB + 2);
   RB_WGT(WK, wgi, 4);
-  // cross-wave sum one 32-position tile at a time (32 KB of scratch whatever NT is: the LDS footprint decides how many
-  // workgroups share a CU), fixed order w0..w7
+  // cross-wave sum, fixed order w0..w7.  Where the operand area is large enough for the partial sums of ALL NT tiles
+  // (the later layers: 2-3 x 32 KB inside 97-118 KB) they are exchanged in one pass — two barriers instead of 2 NT; the
+  // first layer keeps one 32 KB tile at a time (its LDS footprint decides how many workgroups share a CU).
+  constexpr int EIT = (16 * 64) / RB_CONV_THREADS;
+  constexpr bool ONEPASS = NT * SZ::RED <= SZ::WSZ;
+  constexpr int TP = ONEPASS ? NT : 1;                  // tiles per pass
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    __syncthreads();                                  // operands (nt == 0) / the previous tile's sums are no longer read
+  for (int nt0 = 0; nt0 < NT; nt0 += TP) {
+    __syncthreads();                                  // operands (first pass) / the previous pass's sums are no longer read
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_all[(wave * 16 + r) * 64 + lane] = acc[nt][r];
+    for (int u = 0; u < TP; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_all[u * SZ::RED + (wave * 16 + r) * 64 + lane] = acc[nt0 + u][r];
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < (16 * 64) / RB_CONV_THREADS; ++it) {
-      const int idx = t + it * RB_CONV_THREADS;
-      const int l = idx & 63, r = idx >> 6;
-      float v = s_all[(0 * 16 + r) * 64 + l];
+    for (int u = 0; u < TP; ++u) {
+      const int nt = nt0 + u;
 #pragma unroll
-      for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_all[(wv * 16 + r) * 64 + l];
-      const int m = cout0 + rb_mfma_row(r, l);
-      const int p = p0 + nt * 32 + (l & 31);
-      if (m < a.cout && p < G::P && p < p0 + PCH) {
-        const float o = fmaxf(v + bias_r[it], 0.0f);      // (bias fetched before the MFMA loop: a global load here sat on
-                                                          //  the critical path of every tile's epilogue)
-        if constexpr ((COH & 2) != 0) rb_st1_wt(a.out, 4u * (unsigned)((img * a.cout + m) * G::P + p), o);
-        else a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
-        if (a.out_blocked) {
-          const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
-          a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+      for (int it = 0; it < EIT; ++it) {
+        const int idx = t + it * RB_CONV_THREADS;
+        const int l = idx & 63, r = idx >> 6;
+        float v = s_all[u * SZ::RED + (0 * 16 + r) * 64 + l];
+#pragma unroll
+        for (int wv_ = 1; wv_ < RB_CONV_WAVES; ++wv_) v += s_all[u * SZ::RED + (wv_ * 16 + r) * 64 + l];
+        const int m = cout0 + rb_mfma_row(r, l);
+        const int p = p0 + nt * 32 + (l & 31);
+        if (m < a.cout && p < G::P && p < p0 + PCH) {
+          const float o = fmaxf(v + bias_r[it], 0.0f);      // (bias fetched before the MFMA loop: a global load here sat on
+                                                            //  the critical path of every tile's epilogue)
+          if constexpr ((COH & 2) != 0) rb_st1_wt(a.out, 4u * (unsigned)((img * a.cout + m) * G::P + p), o);
+          else a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+          if (a.out_blocked) {
+            const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+            a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+          }
         }
       }
     }
@@ -360,11 +536,14 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   RB_WGT(WK, wgi, 6);
 }
 
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false>
-__global__ __launch_bounds__(RB_CONV_THREADS, WREG ? 2 : 1) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
+// (second launch bound = waves per SIMD: a 512-thread workgroup is 2; 4 where the LDS footprint lets two workgroups share a
+// CU — the first layer on u8 frames — so that the register allocation does too; the float-input variant of the acting path
+// would spill under that cap, and no kernel of this library may carry a scratch segment)
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false, bool F32SRC = false>
+__global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS * 4 <= 80 * 1024 && !F32SRC) ? 4 : 2) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS];
   const ChainLink none{nullptr, 0u, nullptr, nullptr};
-  rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem, none);
+  rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG, 0, F32SRC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem, none);
 }
 
 // The whole conv stack of the learn step in ONE launch at small batches (<= 96 images): block ranges [layer 0 | layer 1 |
@@ -852,6 +1031,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   __shared__ int s_koff[KPAD];      // co*PP - ty*PW - tx
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int WK = G::KS == 3 ? 3 : 4;                   // timeline ids (RB_STAMP builds only)
+  const int wgi = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  (void)wgi;
+  RB_WGT(WK, wgi, 0);
+  RB_WGT_HW(WK, wgi);
   const int ipb = MULTI ? a.ipb : 1;
   const int img0 = (int)blockIdx.z * ipb;
   const int c0 = (int)blockIdx.y * 32;
@@ -872,33 +1056,6 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
     const int ty = r / ntx, tx = r - ty * ntx;
     s_koff[k] = co * PP - ty * PW - tx;
   }
-  {   // thread = (c, co mod 16), no divisions
-    const int m = t & 31;
-    const bool cv = c0 + m < a.cin;
-    constexpr int TAPS_MAX = TMAX * TMAX, CO_STEP = RB_CONV_THREADS / 32, CO_IT = (COUT + CO_STEP - 1) / CO_STEP;
-    float v[CO_IT][TAPS_MAX];                          // every load of this thread is issued before the first LDS store
-#pragma unroll
-    for (int it = 0; it < CO_IT; ++it) {
-      const int co = (t >> 5) + it * CO_STEP;
-      const float* src = a.w + ((int64_t)(co < a.cout ? co : 0) * a.cin + c0 + (cv ? m : 0)) * G::KK;
-#pragma unroll
-      for (int ty = 0; ty < TMAX; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < TMAX; ++tx)
-          v[it][ty * TMAX + tx] = (cv && co < a.cout && ty < nty && tx < ntx) ? src[(py + ty * G::S) * G::KS + px + tx * G::S] : 0.0f;
-    }
-#pragma unroll
-    for (int it = 0; it < CO_IT; ++it) {
-      const int co = (t >> 5) + it * CO_STEP;
-#pragma unroll
-      for (int ty = 0; ty < TMAX; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < TMAX; ++tx)
-          if (co < a.cout && ty < nty && tx < ntx) s_w[(co * taps + ty * ntx + tx) * 33 + m] = v[it][ty * TMAX + tx];
-    }
-    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
-  }
-
   constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time (rows >= K of s_w are zero): full unroll
   const int kb = wave * KW;
   int noff[NT];
@@ -926,67 +1083,188 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 
   // dY of an image: global loads into registers (issue), LDS stores later (commit) — with MULTI the next image's loads
   // are in flight under this image's MFMA loop and reduction
+  // The staging of these kernels is INSTRUCTION-bound, not memory-bound (fine-grained stamps, tools/_fine_dx.py: 7.5 us from
+  // workgroup start to the first MFMA with every load landed at 3.3 us — two waves per SIMD executing ~2000 VALU
+  // instructions of index arithmetic each).  So: only the INTERIOR cells of dY are loaded and stored (contiguous in memory:
+  // no halo-indexed gather), the zero halo is one block of 16-byte stores at kernel start, all offsets are 32-bit and go
+  // through buffer loads (no 64-bit pointer arithmetic per load).
   constexpr int LIT = (COUT * G::P + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
-  static_assert(COUT * PP <= 16 * RB_CONV_THREADS, "one 16-deep batch covers the haloed dY image");
-  float pre_m[LAZY ? LIT : 1], pre_p[LAZY ? LIT : 1][4], pre_v[LAZY ? 1 : 16];
+  float pre_m[LAZY ? LIT : 1], pre_p[LAZY ? LIT : 1][4], pre_v[LAZY ? 1 : LIT];
   const int ni = a.cout * G::P, nh = a.cout * PP;
+  int cell[LIT];                                        // LDS cell of this thread's i-th interior element (image-independent)
+#pragma unroll
+  for (int i = 0; i < LIT; ++i) {
+    const int e = t + i * RB_CONV_THREADS;
+    const int ec = e < ni ? e : ni - 1;
+    const int co = ec / G::P, r = ec - co * G::P;
+    const int y = r / G::OH, x = r - y * G::OH;
+    cell[i] = e < ni ? co * PP + (y + PAD) * PW + x + PAD : -1;
+  }
+  if (PW > G::OH) {                                     // zero the whole haloed image once: the halo stays zero from image to image
+    for (int e = t; e < (COUT * PP) / 4; e += RB_CONV_THREADS) rb_st4(s_dy + 4 * e, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int e = (COUT * PP) / 4 * 4 + t; e < COUT * PP; e += RB_CONV_THREADS) s_dy[e] = 0.0f;
+  }
   auto issue = [&](int img) {
+    const unsigned ibase = 4u * (unsigned)(img * ni);
     if constexpr (LAZY) {
       // interior cells: the mask and every partial of a thread's cells are requested before the first add (one round trip)
-      const float* mk = a.dy_mask + (int64_t)img * ni;
-      const float* pp = a.dy_part + (int64_t)img * ni;
+      const rb_buf mk = rb_make_buf(a.dy_mask);
+      rb_buf pp[4];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) pp[sp] = rb_make_buf(a.dy_part + (int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride);
 #pragma unroll
       for (int i = 0; i < LIT; ++i) {
         const int e = t + i * RB_CONV_THREADS;
-        const int ec = e < ni ? e : ni - 1;
-        pre_m[i] = mk[ec];
+        const unsigned off = 4u * (unsigned)(e < ni ? e : ni - 1);
+        pre_m[i] = rb_ld1_buf(mk, off, ibase);
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) pre_p[i][sp] = pp[(int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride + ec];
+        for (int sp = 0; sp < 4; ++sp) pre_p[i][sp] = rb_ld1_buf(pp[sp], off, ibase);
       }
     } else {
-      const float* src = a.dy + (int64_t)img * ni;
+      const rb_buf src = rb_make_buf(a.dy);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = i * RB_CONV_THREADS + t;
-        const int co = e / PP, r = e - co * PP;
-        const int y = r / PW - PAD, x = r % PW - PAD;
-        pre_v[i] = 0.0f;
-        if (e < nh && y >= 0 && y < G::OH && x >= 0 && x < G::OH) pre_v[i] = src[co * G::P + y * G::OH + x];
+      for (int i = 0; i < LIT; ++i) {
+        const int e = t + i * RB_CONV_THREADS;
+        pre_v[i] = rb_ld1_buf(src, 4u * (unsigned)(e < ni ? e : ni - 1), ibase);
       }
     }
   };
   auto commit = [&](bool first) {
+    (void)first;
     if constexpr (LAZY) {
 #pragma unroll
       for (int i = 0; i < LIT; ++i) {
-        const int e = t + i * RB_CONV_THREADS;
-        if (e < ni) {
-          const int co = e / G::P, r = e - co * G::P;
-          const int y = r / G::OH, x = r - y * G::OH;
+        if (cell[i] >= 0) {
           float acc = 0.0f;                                                 // k_dfeat_finish's order: ((0 + p0) + p1) + ...
 #pragma unroll
           for (int sp = 0; sp < 4; ++sp) acc += sp < a.dy_splits ? pre_p[i][sp] : 0.0f;
-          s_dy[co * PP + (y + PAD) * PW + x + PAD] = pre_m[i] > 0.0f ? acc : 0.0f;
-        }
-      }
-      if (PW > G::OH && first) {                      // the halo stays zero from image to image
-        for (int e = t; e < nh; e += RB_CONV_THREADS) {
-          const int r = e % PP;
-          const int y = r / PW - PAD, x = r % PW - PAD;
-          if (!(y >= 0 && y < G::OH && x >= 0 && x < G::OH)) s_dy[e] = 0.0f;
+          s_dy[cell[i]] = pre_m[i] > 0.0f ? acc : 0.0f;
         }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const int e = i * RB_CONV_THREADS + t; if (e < nh) s_dy[e] = pre_v[i]; }
+      for (int i = 0; i < LIT; ++i) if (cell[i] >= 0) s_dy[cell[i]] = pre_v[i];
     }
   };
 
   issue(img0);
+#if defined(RB_STAMP) && defined(RB_STAMP_FINE)
+  RB_WGT(WK + 3, wgi, 0);
+#endif
+  // (the weight slab is staged AFTER the first image's dY loads have been issued: its own loads then share their round
+  // trip instead of preceding it — tools/wg_timeline.py showed the two as 1.8 + 2.8 us in sequence in the forward kernels)
+  {
+    // The slab W[co][c0 .. c0+31][taps of this phase] is read with COALESCED 16-byte loads (per-workgroup timeline: the
+    // former one-scalar-load-per-(co, tap) pattern — lanes 36 or 64 bytes apart — took 6.6-7.0 us of a 10.3 us workgroup,
+    // three times the MFMA loop and its reduction together):
+    //   stride 1 (every tap belongs to the single phase): the 32 channels x KK taps of one co are one contiguous run;
+    //   4x4 kernel, stride 2: the two kernel rows of the phase are one float4 each, half of whose elements are taps.
+    // Every load is issued before the first LDS store.  Other geometries keep the scalar pattern.
+    const int cvalid = a.cin - c0 < 32 ? a.cin - c0 : 32;
+    if constexpr (G::S == 1 && (G::KK * 32) % 4 == 0) {
+      constexpr int RUN4 = G::KK * 32 / 4;                 // float4s per output channel
+      constexpr int NLD = (COUT * RUN4 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
+      const bool full = cvalid == 32 && ((a.cin * G::KK) & 3) == 0 && ((c0 * G::KK) & 3) == 0;   // runs complete and 16-byte aligned
+      if (full) {
+        float4 v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int n = t + i * RB_CONV_THREADS;
+          const int co = n / RUN4, f = n - co * RUN4;
+          v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (co < a.cout) v[i] = rb_ld4(a.w + ((int64_t)co * a.cin + c0) * G::KK + 4 * f);
+        }
+#if defined(RB_STAMP) && defined(RB_STAMP_FINE)
+        RB_WGT(WK + 3, wgi, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RB_WGT(WK + 3, wgi, 2);
+#endif
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int n = t + i * RB_CONV_THREADS;
+          const int co = n / RUN4, f = n - co * RUN4;
+          if (co < a.cout) {
+            const float vv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            int m = (4 * f) / G::KK, tap = 4 * f - m * G::KK;                   // one division per quad, then carry
+            int adr = (co * G::KK + tap) * 33 + m;                              // phase 0 of stride 1: tap index == (ty, tx)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s_w[adr] = vv[e];
+              ++tap;
+              const bool wrap = tap == G::KK;
+              adr += wrap ? 1 - (G::KK - 1) * 33 : 33;                          // next tap of this channel, or tap 0 of the next one
+              tap = wrap ? 0 : tap;
+            }
+          }
+        }
+      } else {                                             // partial channel tile / unaligned: element by element
+        for (int n = t; n < a.cout * cvalid * G::KK; n += RB_CONV_THREADS) {
+          const int co = n / (cvalid * G::KK), r = n - co * (cvalid * G::KK);
+          const int m = r / G::KK, tap = r - m * G::KK;
+          s_w[(co * taps + tap) * 33 + m] = a.w[((int64_t)co * a.cin + c0 + m) * G::KK + tap];
+        }
+        for (int n = t; n < a.cout * taps * (32 - cvalid); n += RB_CONV_THREADS)
+          s_w[(n / (32 - cvalid)) * 33 + cvalid + n % (32 - cvalid)] = 0.0f;
+      }
+    } else if constexpr (G::S == 2 && G::KS == 4) {
+      constexpr int NLD = (COUT * 64 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;     // (co, c, ty): one kernel row each
+      float4 v[NLD];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int n = t + i * RB_CONV_THREADS;
+        const int co = n >> 6, m = (n >> 1) & 31, ty = n & 1;
+        v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (co < a.cout && m < cvalid) v[i] = rb_ld4(a.w + ((int64_t)co * a.cin + c0 + m) * 16 + (py + 2 * ty) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int n = t + i * RB_CONV_THREADS;
+        const int co = n >> 6, m = (n >> 1) & 31, ty = n & 1;
+        if (co < a.cout) {                                 // (ntx == nty == 2 for every phase of this geometry)
+          s_w[(co * 4 + ty * 2 + 0) * 33 + m] = px ? v[i].y : v[i].x;
+          s_w[(co * 4 + ty * 2 + 1) * 33 + m] = px ? v[i].w : v[i].z;
+        }
+      }
+    } else {
+    // thread = (c, co mod 16), no divisions
+    const int m = t & 31;
+    const bool cv = c0 + m < a.cin;
+    constexpr int TAPS_MAX = TMAX * TMAX, CO_STEP = RB_CONV_THREADS / 32, CO_IT = (COUT + CO_STEP - 1) / CO_STEP;
+    float v[CO_IT][TAPS_MAX];                          // every load of this thread is issued before the first LDS store
+#pragma unroll
+    for (int it = 0; it < CO_IT; ++it) {
+      const int co = (t >> 5) + it * CO_STEP;
+      const float* src = a.w + ((int64_t)(co < a.cout ? co : 0) * a.cin + c0 + (cv ? m : 0)) * G::KK;
+#pragma unroll
+      for (int ty = 0; ty < TMAX; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TMAX; ++tx)
+          v[it][ty * TMAX + tx] = (cv && co < a.cout && ty < nty && tx < ntx) ? src[(py + ty * G::S) * G::KS + px + tx * G::S] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < CO_IT; ++it) {
+      const int co = (t >> 5) + it * CO_STEP;
+#pragma unroll
+      for (int ty = 0; ty < TMAX; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TMAX; ++tx)
+          if (co < a.cout && ty < nty && tx < ntx) s_w[(co * taps + ty * ntx + tx) * 33 + m] = v[it][ty * TMAX + tx];
+    }
+    }
+    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
+  }
+
+#if defined(RB_STAMP) && defined(RB_STAMP_FINE)
+  RB_WGT(WK + 3, wgi, 3);
+#endif
+  if (PW > G::OH) __syncthreads();                    // the zero fill (other threads' cells) precedes the interior stores
   for (int ii = 0; ii < ipb; ++ii) {
     const int img = img0 + ii;
     if (MULTI && img >= a.batch) break;               // block-uniform
     commit(ii == 0);
+#if defined(RB_STAMP) && defined(RB_STAMP_FINE)
+    if (ii == 0) RB_WGT(WK + 3, wgi, 4);
+#endif
     // the ReLU mask of this image's output cells: requested now, consumed after the MFMA loop (in the epilogue the load
     // sat on the critical path of every store)
     const float* xa = a.x_act + (int64_t)img * a.cin * G::IP;
@@ -994,6 +1272,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 #pragma unroll
     for (int it = 0; it < EIT; ++it) mask[it] = xa[eoff[it] >= 0 ? eoff[it] : 0];
     __syncthreads();            // operands complete (and, MULTI, the previous image's reduction scratch has been consumed)
+    if (ii == 0) { RB_WGT(WK, wgi, 1); RB_WGT(WK, wgi, 2); RB_WGT(WK, wgi, 3); }
     if (MULTI && ii + 1 < ipb && img + 1 < a.batch) issue(img + 1);
     if (ii == 0) {
 #pragma unroll
@@ -1010,6 +1289,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_dy[kos[j] + noff[nt]], acc[nt]);
     }
+    if (ii == 0) RB_WGT(WK, wgi, 4);
     if (!MULTI) __syncthreads();                      // the scratch overlays the operands
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1031,6 +1311,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       }
     }
   }
+  RB_WGT(WK, wgi, 5);
+  RB_WGT(WK, wgi, 6);
 }
 
 // ======================================================================= weight gradient ==
@@ -1085,6 +1367,10 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 #if defined(RB_STAMP)
   if (stamp_me) g_cstamp[SBW + 0] = wall_clock64();
 #endif
+  const int wgi = (int)blockIdx.x;
+  (void)wgi;
+  RB_WGT(5, wgi, 0);
+  RB_WGT_HW(5, wgi);
   const int co0 = cotile * 32;
   const int cin = a.cin, K = cin * G::KK;
   const int oy0 = chunk * RC;
@@ -1222,6 +1508,7 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 #if defined(RB_STAMP)
     if (stamp_me && ii == 0) g_cstamp[SBW + 1] = wall_clock64();
 #endif
+    if (ii == 0) { RB_WGT(5, wgi, 1); RB_WGT(5, wgi, 2); RB_WGT(5, wgi, 3); }
 
     // bias column: sum over the chunk's positions in a fixed order (then over the images, ascending).  Eight lanes per
     // channel take every eighth position and meet through shuffles (lane = 8 * channel-in-wave + part): one thread per
@@ -1257,6 +1544,7 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 #if defined(RB_STAMP)
     if (stamp_me && ii == 0) g_cstamp[SBW + 2] = wall_clock64();
 #endif
+    if (ii == 0) RB_WGT(5, wgi, 4);
   }
 
   float* out = a.part + (((int64_t)grp * nchunks + chunk) * a.cout) * (K + 1);
@@ -1276,6 +1564,8 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 #if defined(RB_STAMP)
   if (stamp_me) g_cstamp[SBW + 3] = wall_clock64();
 #endif
+  RB_WGT(5, wgi, 5);
+  RB_WGT(5, wgi, 6);
 }
 
 template <class G, int RC, int KMAX, bool FIRST>

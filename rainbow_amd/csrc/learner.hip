@@ -918,9 +918,12 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
       return RB_OK;
     }
   }
-  RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG>),
-              dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg)),
-              dim3(RB_CONV_THREADS), stream, a);
+  const dim3 grid1((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg));
+  if (FIRST && src.f32) {       // float states (act / evaluate): an instantiation of its own (conv_lds.h F32SRC)
+    RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG, FIRST>), grid1, dim3(RB_CONV_THREADS), stream, a);
+  } else {
+    RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG>), grid1, dim3(RB_CONV_THREADS), stream, a);
+  }
   RB_LAUNCH_CHECK();
   return RB_OK;
 }

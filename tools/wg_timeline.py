@@ -61,3 +61,24 @@ for k in range(K):
     cu = (hw >> 16) * 4096 + ((hw >> 8) & 0xff)          # XCC id, (se, sh, cu) bits of HW_ID
     uniq, cnt = np.unique(cu, return_counts=True)
     print("   ran on %d distinct CUs; workgroups per CU: max %d, mean %.2f" % (len(uniq), cnt.max(), cnt.mean()))
+
+# conv1: which workgroups pay the long input stage?  (wg index = img * 16 + cotile * 8 + chunk)
+rows_all = a[0]
+idx = np.nonzero(rows_all[:, 0] > 0)[0]
+if len(idx):
+    st_in = (rows_all[idx, 3] - rows_all[idx, 2]) * 0.01
+    img, chunk = idx // 16, idx % 8
+    xcc = (rows_all[idx, 7].astype(np.int64) >> 16)
+    lin = chunk + (chunk.max() + 1) * img
+    print("conv1 input stage by chunk:", " ".join("%d: %.2f" % (c, np.median(st_in[chunk == c])) for c in range(chunk.max() + 1)))
+    print("conv1 input stage by image group (16 images each):", " ".join("%.2f" % np.median(st_in[(img // 16) == g]) for g in range(img.max() // 16 + 1)))
+    print("conv1 slow (> 4 us) workgroups: %d of %d; per image count of slow:" % ((st_in > 4).sum(), len(idx)),
+          np.bincount(img[st_in > 4], minlength=img.max() + 1).tolist())
+    print("dispatch id %% 8 -> XCC id (first 32 workgroups):", [(int(l) % 8, int(x)) for l, x in sorted(zip(lin, xcc))[:32]])
+    agree = np.mean((lin % 8) == ((xcc - xcc[np.argmin(lin)]) % 8))
+    print("fraction of workgroups with XCC == (dispatch id + const) %% 8: %.3f" % agree)
+    first = img < 51
+    d0 = np.diff(rows_all[idx][:, 0:7], axis=1) * 0.01
+    for nm, sel in (("first 255 workgroups (images < 51)", first), ("the rest (second workgroup of its CU)", ~first)):
+        print("conv1 %s: start +%.2f | " % (nm, np.median(rows_all[idx][sel, 0] - rows_all[idx][:, 0].min()) * 0.01)
+              + "  ".join("%s %.2f" % (phase[i], np.median(d0[sel, i])) for i in range(6)) + " | total %.2f" % np.median(d0[sel].sum(axis=1)))
