@@ -420,6 +420,8 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
   const int b = (int)blockIdx.x;
   const int NZ = Z + A * Z;
+  RB_WGT(7, b, 0);
+  RB_WGT_HW(7, b);
   for (int i = t; i < NZ; i += RB_HEAD_THREADS) {
     s_lg[0][i] = logits[(int64_t)b * NZ + i];
     s_lg[1][i] = logits[(int64_t)(B + b) * NZ + i];
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
 #pragma unroll
   for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = support[z < Z ? z : Z - 1]; }
   __syncthreads();
+  RB_WGT(7, b, 1);
 #pragma unroll
   for (int i = 0; i < RB_ZI; ++i) sup[i] = lane + 64 * i < Z ? sup[i] : 0.0f;
   HeadWave hw;
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     if (lane == 0) s_ev[a] = sv / se;                             // sum_z z * p(z)
   }
   __syncthreads();
+  RB_WGT(7, b, 2);
   int a_star = 0;
   {
     float best = s_ev[0];
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     }
   }
   __syncthreads();
+  RB_WGT(7, b, 3);
   // ---------------- scatter into atom bins in the reference's accumulation order   agent.py:89-92
   // b is monotone in the atom index (support increasing, nt*gamma^n >= 0), so equal l (and equal u) form
   // contiguous runs: the first atom of a run owns its bin and adds the run left to right — exactly the order of
@@ -521,6 +526,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     }
   }
   __syncthreads();
+  RB_WGT(7, b, 4);
   for (int k = t; k < Z; k += RB_HEAD_THREADS) m_out[(int64_t)b * Z + k] = s_m[k];
   if (wave == 0) {                                                // loss = -sum m * log p   agent.py:94
     float pl = 0.0f, pm = 0.0f;
@@ -533,6 +539,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   // ---------------- backward of mean(w * loss) to the logits     agent.py:96
   // d/dq[z] = (w/B) * (p[z] * sum(m) - m[z]) on the taken action; dueling adjoint:
   // dv[z] = g[z] ; da[a'][z] = (delta(a',act) - 1/A) * g[z]
+  RB_WGT(7, b, 5);
   const float coef = wgt / (float)B;
   const float msum = s_scal[0];
   float* dl = dlogits + (int64_t)b * NZ;
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     else o = ((i - Z) / Z == act ? g : 0.0f) - g / (float)A;
     dl[i] = o;
   }
+  RB_WGT(7, b, 6);
 }
 
 // Agent.act / evaluate_q head (agent.py:53-55, 110-112) for ONE image at logits row `row`.

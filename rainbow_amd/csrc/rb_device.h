@@ -273,17 +273,50 @@ __device__ __forceinline__ void rb_wave_sync() {
 #endif
 }
 
-// wave64 butterfly reductions (all 64 lanes must call)
+// wave64 reductions (all 64 lanes must call; the result is returned to every lane).
+// Six DPP steps — row_shr 1, 2, 4, 8 build each 16-lane row's total in its last lane, row_bcast:15 / :31 fold the rows
+// into lane 63 — then one v_readlane.  The butterfly of __shfl_xor compiles to six ds_bpermute round trips through the
+// LDS crossbar (~0.3-0.5 us per reduction: the head kernel's per-sample chain has ten of them, the sampler's three);
+// a DPP operand costs an ordinary VALU slot.  Fixed summation order (deterministic), different from the butterfly's.
+#if defined(RB_HOST_INTERP)
 __device__ __forceinline__ float rb_wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  // same association as the DPP sequence: prefix sums inside rows of 16, then row 0 + 1 and row 2 + 3, then the halves
+  float x = v;
+  for (int sh = 1; sh <= 8; sh <<= 1) {
+    const float y = __shfl_up(x, (unsigned)sh, 64);
+    if ((rb_lane() & 15) >= sh) x = x + y;
+  }
+  const float r0 = __shfl(x, 15, 64), r1 = __shfl(x, 31, 64), r2 = __shfl(x, 47, 64), r3 = __shfl(x, 63, 64);
+  return (r3 + r2) + (r1 + r0);
 }
 __device__ __forceinline__ float rb_wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
   return v;
 }
+#else
+#define RB_DPP_F(old, src, ctrl, rmask, bmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, bmask, false))
+__device__ __forceinline__ float rb_wave_sum(float v) {
+  v += RB_DPP_F(0.0f, v, 0x111, 0xf, 0xf);       // row_shr:1
+  v += RB_DPP_F(0.0f, v, 0x112, 0xf, 0xf);       // row_shr:2
+  v += RB_DPP_F(0.0f, v, 0x114, 0xf, 0xf);       // row_shr:4
+  v += RB_DPP_F(0.0f, v, 0x118, 0xf, 0xf);       // row_shr:8   -> lane 15 of every row holds the row's sum
+  v += RB_DPP_F(0.0f, v, 0x142, 0xa, 0xf);       // row_bcast:15 into rows 1, 3
+  v += RB_DPP_F(0.0f, v, 0x143, 0xc, 0xf);       // row_bcast:31 into rows 2, 3  -> lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float rb_wave_max(float v) {
+  const float ninf = -__builtin_inff();
+  v = fmaxf(v, RB_DPP_F(ninf, v, 0x111, 0xf, 0xf));
+  v = fmaxf(v, RB_DPP_F(ninf, v, 0x112, 0xf, 0xf));
+  v = fmaxf(v, RB_DPP_F(ninf, v, 0x114, 0xf, 0xf));
+  v = fmaxf(v, RB_DPP_F(ninf, v, 0x118, 0xf, 0xf));
+  v = fmaxf(v, RB_DPP_F(ninf, v, 0x142, 0xa, 0xf));
+  v = fmaxf(v, RB_DPP_F(ninf, v, 0x143, 0xc, 0xf));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
 __device__ __forceinline__ double rb_wave_sum_f64(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

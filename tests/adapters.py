@@ -69,5 +69,8 @@ class OracleLearnAdapter:
     def params(self):
         return self.online
 
+    def sync_target(self):
+        self.target = {k: v.copy() for k, v in self.online.items()}     # agent.py:102-103 (the noise is re-drawn every step)
+
     def act(self, state, noisy):
         return O.act(self.cfg, self.online, self.noise_online if noisy else None, state)

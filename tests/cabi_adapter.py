@@ -319,6 +319,10 @@ class CAbiLearnAdapter:
             L.check(self.lib, self.lib.rb_learner_grads_modified(self.h))
         return self.finish_step()
 
+    def sync_target(self):
+        L.check(self.lib, self.lib.rb_learner_sync_target(self.h, self.mem.stream))
+        self.mem.sync()
+
     def debug(self, what, shape, dtype):
         m = self.mem
         out = m.empty(shape, dtype)

@@ -110,6 +110,9 @@ class ReferenceLearnAdapter:
     def params(self):
         return {k: p.detach().numpy().copy() for k, p in self.dqn.online_net.named_parameters()}
 
+    def sync_target(self):
+        self.dqn.update_target_net()                              # agent.py:102-103
+
     def act(self, state, noisy):
         (self.dqn.train if noisy else self.dqn.eval)()
         st = torch.from_numpy(state)

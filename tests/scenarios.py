@@ -154,10 +154,15 @@ LEARN_CONFIGS = {
 }
 LEARN_CONFIGS["k10"] = dict(architecture="data-efficient", hidden=32, actions=3, atoms=51, batch=4, multi_step=3,
                             discount=0.99, history=4, v_min=-10.0, v_max=10.0)   # K = 1 and K = 10
+# north_star: "loss curves matching reference within tolerance" — a 200-step trajectory of the reference (agent.py:61-100)
+# with injected noise and fixed per-step batches, one update_target_net (agent.py:102-103) on the way
+LEARN_CONFIGS["k200"] = dict(architecture="data-efficient", hidden=32, actions=3, atoms=51, batch=4, multi_step=3,
+                             discount=0.99, history=4, v_min=-10.0, v_max=10.0)
 LEARN_HYPER = dict(lr=6.25e-5, adam_eps=1.5e-4, norm_clip=10.0)   # main.py:43-46 defaults
 LEARN_STEPS = 3
-LEARN_STEPS_BY = {"k10": 10}                 # other configs: LEARN_STEPS
-LEARN_FULL_RECORD = {"k10": (0, 9)}          # steps whose gradient / parameter summaries are kept (default: all)
+LEARN_STEPS_BY = {"k10": 10, "k200": 200}    # other configs: LEARN_STEPS
+LEARN_FULL_RECORD = {"k10": (0, 9), "k200": (29, 99, 199)}   # steps whose gradient / parameter summaries are kept (default: all)
+LEARN_SYNC_AT = {"k200": (100,)}             # backend.sync_target() (agent.py:102-103) BEFORE these steps
 
 
 def make_batch(cfg, seed):
@@ -198,10 +203,11 @@ def learn_scenario(backend, name, oracle_mod, steps=None):
          learn_step(batch, target_raw_normals) -> dict(loss f32[B], grad_norm float, grads {name: f32 array (clipped)})
          params() -> {name: array}                      # online, after the optimiser step
          act(state_f32[h,84,84], noisy) -> (action, q)
+         sync_target()                                  # Agent.update_target_net (only scenarios listed in LEARN_SYNC_AT)
     oracle_mod supplies Config/init_params/noise_draw_count only (pure bookkeeping)."""
     c = LEARN_CONFIGS[name]
     cfg = oracle_mod.Config(**c)
-    seed0 = {"canon": 1000, "dataeff": 2000, "atoms21": 3000, "k10": 4000}[name]
+    seed0 = {"canon": 1000, "dataeff": 2000, "atoms21": 3000, "k10": 4000, "k200": 5000}[name]
     online = oracle_mod.init_params(cfg, seed0)
     target = oracle_mod.init_params(cfg, seed0 + 1)
     backend.load(online, target)
@@ -209,6 +215,8 @@ def learn_scenario(backend, name, oracle_mod, steps=None):
     trace = {}
     full = LEARN_FULL_RECORD.get(name)
     for k in range(steps if steps is not None else LEARN_STEPS_BY.get(name, LEARN_STEPS)):
+        if k in LEARN_SYNC_AT.get(name, ()):
+            backend.sync_target()
         rs = np.random.RandomState(seed0 + 10 + k)
         backend.reset_noise_online(rs.randn(draws).astype(np.float32))
         batch = make_batch(c, seed0 + 20 + k)

@@ -39,7 +39,7 @@ agent.learn(mem)
 torch.cuda.synchronize()
 lib.rb_debug_wgtrace(buf, 0)
 a = np.frombuffer(buf, dtype=np.int64).reshape(K, W, 8).astype(np.float64)
-names = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "conv3_dx", "conv2_dx", "conv_dw", "reduce", "other"]
+names = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "conv3_dx", "conv2_dx", "conv_dw", "(fine)", "head: logits loaded | double-Q | softmaxes | projection | loss | dlogits"]
 phase = ["stage weights", "wait", "stage input", "mfma", "epilogue", "signal"]
 t0_all = None
 for k in range(K):
