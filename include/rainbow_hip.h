@@ -112,6 +112,16 @@ int rb_replay_buffers(rb_replay_t* r, rb_replay_buffers_t* out_host);
 /* synchronises `stream`, then copies the header to host */
 int rb_replay_header(rb_replay_t* r, rb_replay_header_t* out_host, rb_stream_t stream);
 
+/* Frame preprocessing of the environment wrapper on the device (env.py:27-29 `_get_state` =
+ * cv2.resize(ale.getScreenGrayscale() u8 [height][width], (84, 84), INTER_LINEAR) as float32 / 255, and env.py:57-69: the
+ * observation of a step is the element-wise max of the states after frames 3 and 4 of the action repeat).
+ * frame_a_dev / frame_b_dev: n raw grayscale screens each ([n][height][width] u8; frame_b_dev NULL = no max, env.py:50 reset);
+ * out_dev: [n][84][84] float32 in [0, 1] — one slice of the `state` tensor that Agent.act and ReplayMemory.append take.
+ * PARITY UNPINNED: cv2 is absent from the build container; the kernel is bit-exact against oracle/frame_oracle.py, a
+ * restatement of OpenCV's published 8-bit fixed-point INTER_LINEAR (11-bit coefficients).                                  */
+int rb_frame_preprocess(const uint8_t* frame_a_dev, const uint8_t* frame_b_dev, int32_t height, int32_t width, int32_t n,
+                        float* out_dev, rb_stream_t stream);
+
 /* ReplayMemory.append (memory.py:105-108) + SegmentTree.append (memory.py:56-61):
  * quantises state_dev[history-1] (f32 in [0,1]) to u8 by x*255 truncation ON DEVICE,
  * stores (timestep, frame, action, reward, nonterminal) at `index`, sets the leaf to

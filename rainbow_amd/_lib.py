@@ -68,6 +68,7 @@ SIGNATURES = {
     "rb_replay_destroy": (c_int, [c_void_p]),
     "rb_replay_buffers": (c_int, [c_void_p, C.POINTER(ReplayBuffers)]),
     "rb_replay_header": (c_int, [c_void_p, C.POINTER(ReplayHeader), c_void_p]),
+    "rb_frame_preprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rb_replay_append": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
     "rb_replay_append_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rb_replay_find": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -111,6 +111,51 @@ __global__ __launch_bounds__(256) void k_append_one(ReplayView v, const float* l
   }
 }
 
+// ---------------------------------------------------------------- frame pipeline --
+// env.py:27-29 (cv2.resize(gray [H][W] u8, (84, 84), INTER_LINEAR) -> f32 / 255) and env.py:57-69 (element-wise max over the
+// last two frames of the action repeat) on the device: raw emulator screens in, the observation the actor and
+// ReplayMemory.append consume out — no host-side resize, no 28 KB H2D float frame per environment step.
+// The resize is OpenCV's 8-bit fixed-point INTER_LINEAR (11-bit coefficients; oracle/frame_oracle.py has the algebra and
+// says why this row is parity-UNPINNED: cv2 is absent here).  One thread per output pixel; the taps of a pixel are four
+// bytes per frame, the coefficients two float operations — nothing worth staging.
+__device__ __forceinline__ void rb_resize_tap(int d, int dst, int src, bool clamp_f, int* s_out, int* c0, int* c1) {
+  const double scale = (double)src / (double)dst;
+  float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);          // float((d + 0.5) * scale - 0.5)
+  int s = (int)floorf(f);
+  f = __fsub_rn(f, (float)s);
+  if (clamp_f) {
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s >= src - 1) { f = 0.0f; s = src - 1; }
+  }
+  *s_out = s;
+  *c0 = __float2int_rn(__fmul_rn(__fsub_rn(1.0f, f), 2048.0f));               // saturate_cast<short>(cbuf * INTER_RESIZE_COEF_SCALE)
+  *c1 = __float2int_rn(__fmul_rn(f, 2048.0f));
+}
+__device__ __forceinline__ int rb_resize_pixel(const uint8_t* img, int H, int W, int sx, int a0, int a1, int sy, int b0, int b1) {
+  const int x1 = sx + 1 < W ? sx + 1 : W - 1;
+  const int y0 = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
+  const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > H - 1 ? H - 1 : sy + 1);
+  const int h0 = (int)img[(int64_t)y0 * W + sx] * a0 + (int)img[(int64_t)y0 * W + x1] * a1;
+  const int h1 = (int)img[(int64_t)y1 * W + sx] * a0 + (int)img[(int64_t)y1 * W + x1] * a1;
+  return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16)) + 2) >> 2;
+}
+__global__ __launch_bounds__(256) void k_frame_preprocess(const uint8_t* a, const uint8_t* b, int H, int W, int n_pairs,
+                                                           int64_t pair_stride, float* out) {
+  const int pair = (int)blockIdx.y;
+  const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (p >= 84 * 84 || pair >= n_pairs) return;
+  const int dy = p / 84, dx = p - dy * 84;
+  int sx, a0, a1, sy, b0, b1;
+  rb_resize_tap(dx, 84, W, true, &sx, &a0, &a1);
+  rb_resize_tap(dy, 84, H, false, &sy, &b0, &b1);
+  int v = rb_resize_pixel(a + pair * pair_stride, H, W, sx, a0, a1, sy, b0, b1);
+  if (b) {
+    const int w = rb_resize_pixel(b + pair * pair_stride, H, W, sx, a0, a1, sy, b0, b1);
+    v = w > v ? w : v;                               // max of the two states == state of the max (x / 255 is monotone)
+  }
+  out[(int64_t)pair * 84 * 84 + p] = __fdiv_rn((float)(v & 0xFF), 255.0f);    // torch .div_(255)
+}
+
 // Bulk append: frames + columns + leaves (any grid), then ancestor rebuild kernels.
 __global__ __launch_bounds__(256) void k_append_copy(ReplayView v, int64_t start, const uint8_t* frames,
                                                       const int32_t* timesteps, const int32_t* actions,
@@ -922,6 +967,18 @@ int rb_replay_states_at(rb_replay_t* r, const int64_t* data_index_dev, int32_t n
   RB_REQUIRE(n >= 0, "rb_replay_states_at: n must be >= 0");
   if (n == 0) return RB_OK;
   RB_LAUNCH(k_states_at, dim3((unsigned)n), dim3(256), stream, view_of(r), data_index_dev, out_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+
+int rb_frame_preprocess(const uint8_t* frame_a_dev, const uint8_t* frame_b_dev, int32_t height, int32_t width, int32_t n,
+                        float* out_dev, rb_stream_t stream) {
+  RB_REQUIRE(frame_a_dev && out_dev, "rb_frame_preprocess: NULL argument");
+  RB_REQUIRE(height >= 2 && width >= 2 && height <= 4096 && width <= 4096, "rb_frame_preprocess: frame size must be in [2, 4096]^2");
+  RB_REQUIRE(n >= 0, "rb_frame_preprocess: n must be >= 0");
+  if (n == 0) return RB_OK;
+  RB_LAUNCH(k_frame_preprocess, dim3((unsigned)rb_div_up(84 * 84, 256), (unsigned)n), dim3(256), stream, frame_a_dev, frame_b_dev,
+            height, width, n, (int64_t)height * width, out_dev);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }

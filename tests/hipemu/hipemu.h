@@ -199,4 +199,5 @@ inline double __dsub_rn(double a, double b) { return a - b; }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }
 inline float __fsub_rn(float a, float b) { return a - b; }
+inline int __float2int_rn(float a) { return (int)std::nearbyintf(a); }     // round half to even (default rounding mode)
 inline float __fdiv_rn(float a, float b) { return a / b; }
