@@ -20,8 +20,12 @@ Prints ONE JSON line (rank 0).  Extra objects:
                     timed live with HIP events on its launch stream over the timed region (rb_profile_*)
   roofline_others — every other candidate kernel, timed the same way in short passes after the timed region
   roofline_step   — the whole step against SURVEY §8d's per-step algorithmic bytes / FLOPs
+  roofline_per    — the second BASELINE metric (PER samples/s: sample + update_priorities, no learner) against HBM
   cpu_baseline    — the CPU oracle (a port of the reference's algorithm: numpy replay + torch-CPU
                     learner) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  library_source_hash — hash of the sources the loaded librainbow_hip.so was built from; must equal the tree's
+--no-profile: no HIP-event bracket anywhere (the run a rocprofv3 kernel trace should see).
+With --steps < 200 every launch of the dominant kernel is bracketed (else 1 in 8).
 """
 import argparse
 import ctypes as C
@@ -417,8 +421,9 @@ def main():
                                           "single-workgroup dependent-load chains; bytes are 0.1% of what HBM moves in that time"}
         # counter traffic: only from a PMC pass of THIS config that is committed under profiles/ (tools/gpu_pmc.sh);
         # null otherwise — never a number measured on another workload
-        pmc_path = os.path.join(ROOT, "profiles", "round2_pmc_%s.json" % opt.config)
-        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_%s.json" % opt.config)))   # newest round last
+        pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
 
         def roof(name, seconds, n):
             k = ktab[name]
@@ -433,6 +438,7 @@ def main():
         if launches.value > 0:
             out["roofline"] = roof(kname, tot_ms.value / launches.value * 1e-3, launches.value)
             out["roofline"]["event_pair_overhead_us"] = ev_us
+            out["roofline"]["traffic_source"] = os.path.basename(pmc_files[-1]) if pmc_files else None
             out["roofline"]["bracketed"] = "every %s launch of the timed region" % ("%dth" % stride if stride > 1 else "single")
             out["roofline"]["selected"] = "forced" if opt.roofline_kernel in ktab else "largest mean launch time of a 30-step probe"
             out["roofline_others"] = [roof(o, t, n) for o, (t, n) in sorted(others.items(), key=lambda kv: -kv[1][0])]

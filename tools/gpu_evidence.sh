@@ -6,9 +6,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT=$PWD
 timeout 900 python bench.py --config $CFG > gpurun_out/${TAG}_bench.json.log 2>&1; echo "bench rc=$?"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof -o ${TAG} -- python $ROOT/bench.py --config $CFG --steps 300 --warmup 50 --no-cpu-baseline --roofline-kernel clip_adam > $ROOT/gpurun_out/${TAG}_prof.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof -o ${TAG} -- python $ROOT/bench.py --config $CFG --steps 300 --warmup 50 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/${TAG}_prof.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_pmc_$C -o pmc -- python $ROOT/bench.py --config $CFG --steps 40 --warmup 10 --no-cpu-baseline --roofline-kernel clip_adam > $ROOT/gpurun_out/${TAG}_pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_pmc_$C -o pmc -- python $ROOT/bench.py --config $CFG --steps 40 --warmup 10 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/${TAG}_pmc_$C.log 2>&1
 done
 cd $ROOT
 python tools/pmc_summary.py gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE > gpurun_out/${TAG}_pmc.json
