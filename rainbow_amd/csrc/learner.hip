@@ -153,6 +153,7 @@ struct rb_learner {
   float* logits;        // [NI][NZ]
   float* dlogits;       // [B][NZ]
   float* dh;            // [B][2H]
+  float* dhT;           // [2H][B]: the same, transposed (the hidden layer's input gradient reads its dY operand from it)
   float* dfeat_part;    // [xs][B][F]
   int lazy_dfeat;       // this step: the last conv layer's backward kernels sum the partials themselves (no k_dfeat_finish)
   int lazy_splits;
@@ -1378,7 +1379,7 @@ int64_t rb_learner_noise_draws(const rb_learner_config_t* cfg) {
 int rb_learner_destroy(rb_learner_t* l) {
   if (!l) return RB_OK;
   float** owned[] = {&l->feat_b, &l->h_b, &l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
-                     &l->logits, &l->dlogits, &l->dh, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
+                     &l->logits, &l->dlogits, &l->dh, &l->dhT, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
                      &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
   for (float** p : owned)
     if (*p) rb_dev_free(*p);
@@ -1478,6 +1479,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->logits, (int64_t)NI * L.NZ);
   RB_ALLOC(l->dlogits, (int64_t)B * L.NZ);
   RB_ALLOC(l->dh, (int64_t)B * 2 * L.H);
+  RB_ALLOC(l->dhT, (int64_t)B * 2 * L.H);
   RB_ALLOC(l->dfeat_part, (int64_t)l->xs * B * L.F);
   RB_ALLOC(l->log_ps_a, (int64_t)B * L.Z);
   RB_ALLOC(l->pns_a, (int64_t)B * L.Z);
@@ -1705,6 +1707,10 @@ static FcDwPlan fc_dw_plan(rb_learner* l, const NetPtrs& on, int which, const fl
     p.dw_y = 2 * ht;
   }
   p.dw_x = (int)rb_div_up(w.K, 256 * (ct > 0 ? ct : 1));
+  if (ct < 0) {              // 64 x 64 tiles (rb_nl_dw_body_wide): the caller checked K % 64 == 0 and 64-row problems
+    p.dw_x = w.K / 64;
+    p.dw_y = (w.prob[0].row_cnt + w.prob[1].row_cnt) / 64;
+  }
   p.slots = 4 * p.dw_x * p.dw_y;
   return p;
 }
@@ -1778,7 +1784,13 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     static const int ct_env = getenv("RB_DW_CT") ? atoi(getenv("RB_DW_CT")) : -1;      // A/B switch
     const bool pipe = B <= 32 && !side && !exch;         // (the side-stream variant launches the plain k_nl_dw)
     const int z_ct = pipe ? (ct_env >= 0 ? (ct_env > 2 ? 2 : ct_env) : 2) : 0;
-    const int h_ct = pipe ? (ct_env >= 0 ? ct_env : 4) : 0;
+    // batch >= 64, RB_DW_WIDE=1: the hidden layer's weight gradient on LDS-shared 64 x 64 tiles as a launch of its own.
+    // Measured at batch 256 (profiles/round3_fc_bwd_b256_ab.txt): 26.2 us for the gradient alone (0.40 of f32 MFMA, against
+    // 0.31 for the fused launch as a whole) but the input-gradient part then runs alone for 45.5 us — 71.7 us in sequence
+    // against 67.4 us fused, where the two overlap.  Opt-in until the input-gradient part is rebuilt the same way.
+    static const bool wide_off = !(getenv("RB_DW_WIDE") && getenv("RB_DW_WIDE")[0] == '1');
+    const bool h_wide = !pipe && !side && !exch && !wide_off && B >= 64 && L.F % 64 == 0 && L.H % 64 == 0;
+    const int h_ct = pipe ? (ct_env >= 0 ? ct_env : 4) : (h_wide ? -1 : 0);
     FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
     FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, feat, B, h_ct);
     int64_t conv_out = 0;
@@ -1801,6 +1813,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     zx.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
     zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
     zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
+    static const bool dyt_off = getenv("RB_DX_DYT") && getenv("RB_DX_DYT")[0] == '0';          // A/B switch
+    zx.dyT = nullptr; zx.ldyT = 0; zx.outT = dyt_off ? nullptr : l->dhT;
     NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
     // ---- hidden layer
     NlDxArgs hx;
@@ -1810,7 +1824,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hx.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
     const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
     hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
-    NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : 2 * ht, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
+    hx.dyT = dyt_off ? nullptr : l->dhT; hx.ldyT = B; hx.outT = nullptr;
+    NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : hp.dw_y, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
     NlPriorityUpdate up;
     memset(&up, 0, sizeof(up));
     if (l->sink && B <= 256) {
@@ -1849,6 +1864,10 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         RB_LAUNCH_CHECK();
         if (l->ev_fact) RB_HIP_TRY(hipEventRecord(l->ev_fact, stream));
         l->exch_pending = 1;
+      }
+      if (h_wide) {        // batch >= 64: the weight gradient as a launch of its own (noisy_linear.h k_nl_dw_wide)
+        RB_LAUNCH_T("fc_h_dw:k_nl_dw_wide", k_nl_dw_wide, dim3((unsigned)(hg.dw_x * hg.dw_y)), dim3(256), stream, hw_, hg.dw_x);
+        hg.dw_x = 0; hg.dw_y = 0;
       }
       RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd,
                   dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled && !up_in_z) ? 1 : 0))), dim3(256),

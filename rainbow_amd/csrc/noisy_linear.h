@@ -429,6 +429,13 @@ struct NlDxArgs {
   float* out;                // split: part[s][M][ld_out]; else dx[M][ld_out]
   int ld_out;
   const float* mask_src;     // non-split only: dx = mask_src > 0 ? v : 0  (ReLU adjoint), same indexing as out
+  // Transposed companions.  dyT [rows][ldyT] (dyT[n][m] == dy[m][n]): when set, the dY operand is read from it — a lane
+  // group then reads 16 CONSECUTIVE m of one weight row (64 bytes) instead of 16 addresses a whole dy row (4 KB) apart:
+  // the gather made the hidden layer's input gradient 45 us for 1.6 GFLOP at batch 256 (0.23 of f32 MFMA).
+  // outT [ld_out][M] (non-split only): the result is ALSO stored transposed, for the next layer's dyT.
+  const float* dyT;
+  int ldyT;
+  float* outT;
 };
 
 // grid = (64-column tiles, row splits, n_prob * m-chunks of 64), block = 256 (4 waves split the rows)
@@ -481,7 +488,7 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + 16 * mt + c;
-        av[st][mt] = (mt < mt_cnt && nv && m < a.M) ? a.dy[(int64_t)m * a.ldy + n] : 0.0f;
+        av[st][mt] = (mt < mt_cnt && nv && m < a.M) ? (a.dyT ? a.dyT[(int64_t)n * a.ldyT + m] : a.dy[(int64_t)m * a.ldy + n]) : 0.0f;
       }
     }
 #pragma unroll
@@ -551,6 +558,10 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
         v.w = ms.w > 0.0f ? v.w : 0.0f;
       }
       rb_st4(a.out + o, v);
+      if (a.outT && a.mask_src) {                      // (non-split launches only: block-uniform)
+        float* ot = a.outT + (int64_t)(pr.out_off + k) * a.M + m;
+        ot[0] = v.x; ot[a.M] = v.y; ot[2 * (int64_t)a.M] = v.z; ot[3 * (int64_t)a.M] = v.w;
+      }
     }
   }
 }
@@ -577,7 +588,8 @@ struct NlDwArgs {
   const float *eout, *ein;
   float* sq_part;            // optional: one slot per (block, wave) receiving the sum of squares of what that wave wrote
                              // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
-  int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave
+  int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave;
+                             // < 0: the LDS-shared 64 x 64 tile body for large M (rb_nl_dw_body_wide)
   int norm_only;             // 1: the weight-gradient tiles are computed for their sum of squares only and NOT stored (the
                              // optimiser pass recomputes each tile while it streams the parameters, k_clip_adam<FUSED>);
                              // the bias gradients are still written
@@ -677,6 +689,105 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
     if (lane == 0) a.sq_part[slot_base + wave] = sq;
   }
 }
+// Large batches (M >= 64; the hidden layer at batch 256): a workgroup owns a 64-row x 64-column tile of the gradient and
+// walks the M reduction rows in chunks of 32 that are staged ONCE in LDS for its four waves (wave w: rows 16 w .. 16 w + 15
+// of the tile, all 64 columns) — the body above has every wave fetch its own operands from L2 (x re-read by each of the 64
+// row tiles: 205 MB of L2 -> CU traffic for 1.6 GFLOP, 3.6x the algorithmic HBM bytes at the counters).  The next
+// chunk's global loads are in flight under the current chunk's MFMAs (registers -> the other LDS buffer).
+// Same MFMA operand order per output element as the body above (k ascending in steps of 4): identical results.
+// grid: bx over K / 64 column tiles, by over (rows of both problems) / 64.  Requires K % 64 == 0, row_cnt % 64 == 0.
+#define RB_NL_DWW_DY_LD 80         // row stride (floats) of the dY chunk: lanes (q, c) of an operand read hit distinct banks
+#define RB_NL_DWW_X_LD 68
+#define RB_NL_DWW_LDS (2 * 32 * (RB_NL_DWW_DY_LD + RB_NL_DWW_X_LD))
+__device__ __forceinline__ void rb_nl_dw_body_wide(const NlDwArgs& a, int bx, int by, int slot_base, float* lds) {
+  const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
+  float* s_dy = lds;                                            // [2][32][RB_NL_DWW_DY_LD]
+  float* s_x = lds + 2 * 32 * RB_NL_DWW_DY_LD;                  // [2][32][RB_NL_DWW_X_LD]
+  const int tile_row0 = by * 64;                                // in the concatenated row space of the problems
+  const int g = (a.n_prob > 1 && tile_row0 >= a.prob[1].row_begin) ? 1 : 0;
+  const NlDwProblem pr = a.prob[g];
+  const int row0 = tile_row0 + 16 * wave;                       // this wave's 16 rows (problem rows are contiguous: row == dy column)
+  const int col0 = bx * 64;
+  const int c = lane & 15, q = lane >> 4;
+  const int col4 = col0 + 4 * c;
+  // staging coordinates of this thread: two float4 of each operand per chunk
+  const int sm = t >> 4, sc4 = t & 15;                          // rows sm and sm + 16 of the chunk, float4 column sc4
+  rb_f32x4 acc[4], accb;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+  const bool do_bias = bx == 0;
+  const float4 e4 = rb_ld4(a.ein + pr.ein_off + col4);
+  float eo4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) eo4[e] = a.eout[row0 + 4 * q + e];
+  float4 px[2], pd[2];
+  auto issue = [&](int mb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = mb + sm + 16 * u;
+      const int mc = m < a.M ? m : a.M - 1;
+      px[u] = rb_ld4(a.x + (int64_t)mc * a.ldx + pr.x_off + col0 + 4 * sc4);
+      pd[u] = rb_ld4(a.dy + (int64_t)mc * a.ldy + tile_row0 + 4 * sc4);
+      if (m >= a.M) { px[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); pd[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rb_st4(s_x + (buf * 32 + sm + 16 * u) * RB_NL_DWW_X_LD + 4 * sc4, px[u]);
+      rb_st4(s_dy + (buf * 32 + sm + 16 * u) * RB_NL_DWW_DY_LD + 4 * sc4, pd[u]);
+    }
+  };
+  issue(0);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int mb = 0; mb < a.M; mb += 32) {
+    const bool more = mb + 32 < a.M;
+    if (more) issue(mb + 32);
+    const float* dyb = s_dy + buf * 32 * RB_NL_DWW_DY_LD;
+    const float* xb = s_x + buf * 32 * RB_NL_DWW_X_LD;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      if (mb + 4 * st < a.M) {                                  // uniform
+        const float av = dyb[(4 * st + q) * RB_NL_DWW_DY_LD + 16 * wave + c];
+        const float4 xs = rb_ld4(xb + (4 * st + q) * RB_NL_DWW_X_LD + 4 * c);
+        acc[0] = rb_mfma16(av, xs.x, acc[0]);
+        acc[1] = rb_mfma16(av, xs.y, acc[1]);
+        acc[2] = rb_mfma16(av, xs.z, acc[2]);
+        acc[3] = rb_mfma16(av, xs.w, acc[3]);
+        if (do_bias) accb = rb_mfma16(av, 1.0f, accb);          // block-uniform
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();                                            // the other buffer is complete; this one may be overwritten next time
+    buf ^= 1;
+  }
+  float sq = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    const float eo = eo4[e];
+    float4 gm, gs;
+    gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
+    gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
+    rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
+    rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+    sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
+    sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
+    if (do_bias && c == 0) {
+      const float gb = accb[e], gbs = accb[e] * eo;
+      a.g_bmu[n] = gb;
+      a.g_bsigma[n] = gbs;
+      sq = fmaf(gb, gb, sq); sq = fmaf(gbs, gbs, sq);
+    }
+  }
+  if (a.sq_part) {                                              // block-uniform
+    sq = rb_wave_sum(sq);
+    if (lane == 0) a.sq_part[slot_base + wave] = sq;
+  }
+}
+
 // Replica-exchange variant (rb_learner_finish_grads): the reduction rows are `M / rpb` rank blocks of rpb rows each.  Every
 // rank's block is reduced on its own (same MFMA order as the single-device bodies, so acc_r has the bits that rank alone
 // would have produced), then folded in rank order:  g_mu += acc_r ;  g_sigma += acc_r * (eps_out_r * eps_in_r) ; the sums
@@ -889,6 +1000,13 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
     if (lane == 0) a.sq_part[slot_base + wave] = sq;
   }
 }
+// the wide body as a launch of its own: inside k_nl_bwd it would inherit that kernel's register allocation (145 + 64: two
+// workgroups per CU), and with 8 short chunks per workgroup it is latency-bound — it wants many resident workgroups
+__global__ __launch_bounds__(256, 4) void k_nl_dw_wide(NlDwArgs a, int dw_x) {
+  __shared__ __attribute__((aligned(16))) float lds[RB_NL_DWW_LDS];
+  const int b = (int)blockIdx.x;
+  rb_nl_dw_body_wide(a, b % dw_x, b / dw_x, 4 * b, lds);
+}
 __global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
   const int slot = 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x);
   if (a.rpb > 0) rb_nl_dw_body_ranks(a, (int)blockIdx.x, (int)blockIdx.y, slot);
@@ -923,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
   // ONE LDS buffer for whichever body this workgroup runs (separate static arrays would add up: 132 KB, one workgroup
   // per CU for the whole launch; 32 KB lets five share a CU)
   constexpr int LDSW = RB_NL_DX_LDS > UpdateLds<512, 256>::WORDS ? RB_NL_DX_LDS : UpdateLds<512, 256>::WORDS;
-  __shared__ float lds[LDSW];
+  __shared__ __attribute__((aligned(16))) float lds[LDSW];
   // the write-back block goes FIRST: it is the launch's longest single-workgroup chain and must not queue behind the tiles
   int b = (int)blockIdx.x;
   const int sb = dw.K > 1000 ? 3 : 0;                    // RB_STAMP builds: span slots of the hidden / output layer launch

@@ -6,7 +6,7 @@ from rainbow_amd import _lib as L
 from rainbow_amd.agent import Agent
 from rainbow_amd.memory import ReplayMemory
 dev = torch.device("cuda", 0)
-cfg = dict(bench.CONFIGS["pong-canonical-b32"]); cfg["capacity"] = 100000
+cfg = dict(bench.CONFIGS[os.environ.get("CFG", "pong-canonical-b32")]); cfg["capacity"] = 100000
 args = bench.make_args(cfg, dev)
 env = types.SimpleNamespace(action_space=lambda: cfg["actions"])
 agent = Agent(args, env)
