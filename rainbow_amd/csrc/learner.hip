@@ -290,6 +290,16 @@ struct ReduceAllArgs {
   int64_t total;
   float* sq_part;         // optional: one slot per block = sum of squares of the gradients this block produced
 };
+template <int N>
+__device__ __forceinline__ float rb_sum_slices(const float* part, int64_t per, int64_t j, int slices) {
+  float v[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] = part[(int64_t)(u < slices ? u : slices - 1) * per + j];   // clamped: always legal
+  float acc = 0.0f;
+#pragma unroll
+  for (int u = 0; u < N; ++u) acc += (u < slices) ? v[u] : 0.0f;
+  return acc;
+}
 __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float my = 0.0f;
@@ -300,23 +310,16 @@ __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const ReduceLayer L = a.layer[li];
   const int64_t j = i - L.begin;
   const int64_t per = (int64_t)L.cout * (L.K + 1);
-  // fixed add order, but 32 slice loads in flight at a time: with `#pragma unroll 8` the compiler waited for each group of
-  // 8 before it requested the next, i.e. 12 dependent round trips for the first layer's 96 slices (the kernel's 6.6 us)
+  // fixed add order (slice 0, 1, 2, ...), ALL slice loads of an element in flight at once: one memory round trip instead of
+  // one per group of 32 (the first layer's 96 slices were three dependent trips: 4.5 of the kernel's 6 us).  Slice counts:
+  // 96 / 64 / 64 at batch 32 (B images x row chunks), the same at larger batches (image groups).
   float acc = 0.0f;
-  int s = 0;
-  for (; s + 32 <= L.slices; s += 32) {
-    float v[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = L.part[(int64_t)(s + u) * per + j];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) acc += v[u];
-  }
-  {
-    float v[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = L.part[(int64_t)(s + u < L.slices ? s + u : L.slices - 1) * per + j];   // clamped: always legal
-#pragma unroll
-    for (int u = 0; u < 32; ++u) acc += (s + u < L.slices) ? v[u] : 0.0f;
+  if (L.slices <= 32) acc = rb_sum_slices<32>(L.part, per, j, L.slices);           // (a layer's elements share the branch)
+  else if (L.slices <= 64) acc = rb_sum_slices<64>(L.part, per, j, L.slices);
+  else if (L.slices <= 96) acc = rb_sum_slices<96>(L.part, per, j, L.slices);
+  else if (L.slices <= 128) acc = rb_sum_slices<128>(L.part, per, j, L.slices);    // data-efficient first layer: 4 chunks x 32
+  else {                                                                            // (same left-to-right order, a trip per 32)
+    for (int s0 = 0; s0 < L.slices; ++s0) acc += L.part[(int64_t)s0 * per + j];
   }
   const int co = (int)(j / (L.K + 1)), col = (int)(j % (L.K + 1));
   if (col < L.K) L.gw[(int64_t)co * L.K + col] = acc;
@@ -1080,7 +1083,8 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     a.grp[0] = NlRowGroup{0, L.H, 0, 0, 0};
     a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, ht16};
     a.out = l->h; a.out_blocked = l->h_b; a.ld_out = 2 * L.H; a.rows_total = NI; a.relu = 1;
-    const bool wide = m_max >= 128;                      // batch 256: 64-row m-chunks halve the passes over the weights
+    static const int wide_env = getenv("RB_FWD_WIDE") ? atoi(getenv("RB_FWD_WIDE")) : -1;   // A/B switch (1: 64-row m-chunks at any batch)
+    const bool wide = wide_env >= 0 ? (wide_env != 0 && m_max >= 64) : m_max >= 128;     // batch 256: 64-row m-chunks halve the passes over the weights
     const unsigned mch32 = (unsigned)rb_div_up(m_max, wide ? 64 : RB_FWD2_MROWS);
     static const int abl = getenv("RB_FWD2_ABLATE") ? atoi(getenv("RB_FWD2_ABLATE")) : 0;   // tools/gpu_ablate.sh only
     const dim3 hg((unsigned)(2 * ht16), 1, 2 * mch32), hb(64 * RB_NL_FWD_WAVES);
