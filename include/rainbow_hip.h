@@ -360,18 +360,21 @@ int rb_learner_priority_written(rb_learner_t* l);
 /* ---- Replica exchange (the reference is single-device, the insert point is between agent.py:96 and :97).
  * Every replica must apply the MEAN gradient.  27 MB of it are the noisy-linear weight gradients, and those are rank-B
  * products  dW = dY^T X  of two thin matrices: instead of all-reducing dW (2 x 7/8 x 27 MB through each GPU's xGMI links),
- * the replicas all-gather the FACTORS (dlogits, h, dh, feat rows of their batch: `factor_floats` per rank, 0.7 MB at the
- * canonical shape) and each computes the mean gradient of the global batch from the gathered rows itself — identical
- * inputs, identical kernel, identical bits on every replica.  Only the conv gradients ([small_offset, +small_floats) of
- * grads_dev, 0.3 MB) are all-reduced.
+ * the replicas all-gather the FACTORS (dlogits, h, dh, feat rows of their batch, their noise vectors) and each computes the
+ * mean gradient of the global batch from the gathered rows itself — identical inputs, identical kernel, identical bits on
+ * every replica.  The conv gradients (the leading `small_floats` of grads_dev, 0.3 MB) ride in the SAME block, so a step
+ * needs exactly ONE collective (an all-gather of `factor_floats` = 1.0 MB per rank at the canonical shape) and no event or
+ * side stream (round 2 all-gathered the FC factors on a side stream under the backward and all-reduced the conv range
+ * separately: two collectives, two stream joins — 75 us of idle GPU per step in the one-rank plumbing run).
  *   rb_learner_set_exchange(world > 1, local block, gathered blocks [world][factor_floats])   once
- *   per step:  rb_learner_learn*            input-gradient chain, conv grads, local factor block; NO FC weight grads
- *              rb_learner_wait_factors(s)   stream s waits until the local block is complete (it is after the output
- *                                           layer's backward launch, i.e. the all-gather overlaps the rest of the backward)
- *              [caller: all-gather factors on s; all-reduce(mean) grads_dev[small range]; join s]
- *              rb_learner_finish_grads      FC weight/bias gradients of the global batch (x 1/world) + norm partials
+ *   per step:  rb_learner_learn*            input-gradient chain, conv grads, the complete local block; NO FC weight grads
+ *              [caller: all-gather the local blocks into the gathered buffer, on the learn call's stream]
+ *              rb_learner_finish_grads      FC weight/bias gradients of the global batch and the conv gradients' replica
+ *                                           mean (rank order, x 1/world) into grads_dev + the norm partials
  *              rb_learner_clip_adam / rb_learner_clip_grad as usual
- * world == 1 (default) restores the single-device step.                                                           */
+ * rb_learner_wait_factors is kept for ABI compatibility and does nothing (the block is complete in stream order).
+ * world == 1 (default) restores the single-device step.  [small_offset, +small_floats) still names the conv range for
+ * hosts that prefer `allreduce` of the flat gradient + rb_learner_grads_modified.                                     */
 int rb_learner_exchange_layout(rb_learner_t* l, int64_t* factor_floats, int64_t* small_offset, int64_t* small_floats);
 int rb_learner_set_exchange(rb_learner_t* l, int32_t world, float* factors_local_dev, const float* factors_all_dev);
 int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream);

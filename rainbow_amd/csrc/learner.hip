@@ -199,9 +199,9 @@ struct rb_learner {
   int world;
   float* fact_local;        // [fact_stride] this rank's factor block, written by the learn call
   const float* fact_all;    // [world][fact_stride] every rank's block (the all-gather's output)
-  int64_t fact_off[5];      // dlogits [B][NZ] | h [B][2H] | dh [B][2H] | feat [B][F] | this rank's online noise [n_noise]
+  int64_t fact_off[6];      // dlogits [B][NZ] | h [B][2H] | dh [B][2H] | feat [B][F] | this rank's online noise [n_noise] |
+                            // this rank's conv gradients (the leading h_mu floats of the flat gradient)
   int64_t fact_stride;
-  hipEvent_t ev_fact;       // recorded when fact_local is complete (the all-gather may start under the rest of the backward)
   int exch_pending;         // a learn call left its FC weight gradients to rb_learner_finish_grads
   long long* step_ctr;      // optional device-resident optimiser step counter (rb_learner_set_step_counter)
   int flags;                // RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS (rb_learner_set_flags)
@@ -289,6 +289,10 @@ struct ReduceAllArgs {
   int n_layers;
   int64_t total;
   float* sq_part;         // optional: one slot per block = sum of squares of the gradients this block produced
+  // replica exchange: every reduced element is ALSO stored at copy_base + (its offset inside the flat gradient), i.e. into
+  // the conv segment of this rank's exchange block
+  const float* grads_base;
+  float* copy_base;
 };
 template <int N>
 __device__ __forceinline__ float rb_sum_slices(const float* part, int64_t per, int64_t j, int slices) {
@@ -322,8 +326,9 @@ __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
     for (int s0 = 0; s0 < L.slices; ++s0) acc += L.part[(int64_t)s0 * per + j];
   }
   const int co = (int)(j / (L.K + 1)), col = (int)(j % (L.K + 1));
-  if (col < L.K) L.gw[(int64_t)co * L.K + col] = acc;
-  else L.gb[co] = acc;
+  float* dst = col < L.K ? L.gw + (int64_t)co * L.K + col : L.gb + co;
+  *dst = acc;
+  if (a.copy_base) a.copy_base[dst - a.grads_base] = acc;
   my = acc * acc;
   }
   if (a.sq_part) {
@@ -616,7 +621,9 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* g, int64_t n, float*
 struct FinishArgs {
   NlDwArgs z, h;
   int z_x, z_n, h_x, h_n;      // grid.x and block count of each weight-gradient problem
-  const float* g; int64_t n; float* part; int nparts;
+  // conv range: g[i] = (sum over ranks, in rank order, of blocks[r * bstride + i]) * scale; part[b] = this block's sum of squares
+  float* g; int64_t n; float* part; int nparts;
+  const float* blocks; int64_t bstride; int world; float scale;
 };
 __global__ __launch_bounds__(256) void k_finish_grads(FinishArgs a) {
   __shared__ float s_red[16];
@@ -626,7 +633,13 @@ __global__ __launch_bounds__(256) void k_finish_grads(FinishArgs a) {
   if (b < a.h_n) { rb_nl_dw_body_ranks(a.h, b % a.h_x, b / a.h_x, 4 * b); return; }
   b -= a.h_n;
   float acc = 0.0f;
-  for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < a.n; i += (int64_t)a.nparts * 256) acc = fmaf(a.g[i], a.g[i], acc);
+  for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < a.n; i += (int64_t)a.nparts * 256) {
+    float v = 0.0f;
+    for (int r = 0; r < a.world; ++r) v += a.blocks[(int64_t)r * a.bstride + i];
+    v *= a.scale;
+    a.g[i] = v;
+    acc = fmaf(v, v, acc);
+  }
   acc = rb_block_sum(acc, s_red);
   if (threadIdx.x == 0) a.part[b] = acc;
 }
@@ -1391,7 +1404,6 @@ int rb_learner_destroy(rb_learner_t* l) {
   if (l->noise_ctr) rb_dev_free(l->noise_ctr);
   if (l->chain_ctr) rb_dev_free(l->chain_ctr);
   if (l->job_dev) rb_dev_free(l->job_dev);
-  if (l->ev_fact) (void)hipEventDestroy(l->ev_fact);
   if (l->use_side) {
     for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
     for (int i = 0; i < 8; ++i) if (l->ev[i]) (void)hipEventDestroy(l->ev[i]);
@@ -1418,9 +1430,9 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->seed = seed; l->noise_epoch = 0;
   l->world = 1;
   {
-    const int64_t seg[5] = {(int64_t)L.B * L.NZ, (int64_t)L.B * 2 * L.H, (int64_t)L.B * 2 * L.H, (int64_t)L.B * L.F, L.n_noise};
+    const int64_t seg[6] = {(int64_t)L.B * L.NZ, (int64_t)L.B * 2 * L.H, (int64_t)L.B * 2 * L.H, (int64_t)L.B * L.F, L.n_noise, L.h_mu};
     int64_t off = 0;
-    for (int i = 0; i < 5; ++i) { l->fact_off[i] = off; off = align64(off + seg[i]); }
+    for (int i = 0; i < 6; ++i) { l->fact_off[i] = off; off = align64(off + seg[i]); }
     l->fact_stride = off;
   }
   l->gamma_n = (float)pow(cfg->discount, (double)cfg->multi_step);
@@ -1856,8 +1868,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
                   dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z + ((up.enabled && up_in_z) ? 1 : 0))), dim3(256), stream,
                   zw, zx, zg, up_in_z ? up : none);
       if (exch) {
-        // every factor of the FC weight gradients exists now (dlogits, h, dh, feat rows [0, B)): pack them for the
-        // all-gather, which the caller starts on a side stream as soon as ev_fact fires — under the rest of the backward
+        // every factor of the FC weight gradients exists now (dlogits, h, dh, feat rows [0, B)): pack them into this rank's
+        // exchange block; the conv gradients join it at the end of the backward (k_reduce_conv_dw_all stores them twice)
         PackArgs pk;
         pk.src[0] = l->dlogits; pk.src[1] = l->h; pk.src[2] = l->dh; pk.src[3] = feat; pk.src[4] = l->n_online;
         pk.count[0] = (int64_t)B * L.NZ; pk.count[1] = (int64_t)B * 2 * L.H; pk.count[2] = (int64_t)B * 2 * L.H; pk.count[3] = (int64_t)B * L.F;
@@ -1866,7 +1878,6 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         pk.dst = l->fact_local;
         RB_LAUNCH(k_pack_factors, dim3(16, 5), dim3(256), stream, pk);
         RB_LAUNCH_CHECK();
-        if (l->ev_fact) RB_HIP_TRY(hipEventRecord(l->ev_fact, stream));
         l->exch_pending = 1;
       }
       if (h_wide) {        // batch >= 64: the weight gradient as a launch of its own (noisy_linear.h k_nl_dw_wide)
@@ -1954,6 +1965,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     }
     ra.n_layers = L.nconv; ra.total = off;
     ra.sq_part = l->norm_slots > 0 ? l->norm_part + l->norm_conv_base : nullptr;
+    ra.grads_base = l->grads;
+    ra.copy_base = exch ? l->fact_local + l->fact_off[5] : nullptr;
     RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(off, 64)), dim3(64), s_cv, ra);
     RB_LAUNCH_CHECK();
   }
@@ -2093,7 +2106,6 @@ int rb_learner_set_exchange(rb_learner_t* l, int32_t world, float* factors_local
                  "all-reduce the flat gradient and call rb_learner_grads_modified instead");
     return RB_ERR_STATE;
   }
-  if (!l->ev_fact) RB_HIP_TRY(hipEventCreateWithFlags(&l->ev_fact, hipEventDisableTiming));
   l->world = world; l->fact_local = factors_local_dev; l->fact_all = factors_all_dev;
   return RB_OK;
 }
@@ -2101,7 +2113,7 @@ int rb_learner_set_exchange(rb_learner_t* l, int32_t world, float* factors_local
 int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_wait_factors: NULL handle");
   RB_REQUIRE(l->exch_pending, "rb_learner_wait_factors: no learn call with a pending exchange");
-  RB_HIP_TRY(hipStreamWaitEvent((hipStream_t)side_stream, l->ev_fact, 0));
+  (void)side_stream;     // the block is complete in the stream order of the learn call: nothing to wait for (see the header)
   return RB_OK;
 }
 
@@ -2130,8 +2142,9 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   FinishArgs fa;
   fa.z = zp.a; fa.h = hp.a;
   fa.z_x = zp.dw_x; fa.z_n = zp.dw_x * zp.dw_y; fa.h_x = hp.dw_x; fa.h_n = hp.dw_x * hp.dw_y;
-  // the conv gradients were all-reduced by the caller: their sum of squares is re-derived from the reduced values (0.3 MB)
+  // the conv gradients travel in the same blocks: their replica mean (rank order) and its sum of squares (0.3 MB per rank)
   fa.g = l->grads; fa.n = conv_n; fa.part = l->norm_part + zp.slots + hp.slots; fa.nparts = c_slots;
+  fa.blocks = f + l->fact_off[5]; fa.bstride = l->fact_stride; fa.world = l->world; fa.scale = 1.0f / (float)l->world;
   RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads, dim3((unsigned)(fa.z_n + fa.h_n + c_slots)), dim3(256), stream, fa);
   RB_LAUNCH_CHECK();
   l->norm_slots = zp.slots + hp.slots + c_slots;

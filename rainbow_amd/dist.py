@@ -11,12 +11,12 @@ Two exchanges (RAINBOW_AMD_EXCHANGE):
   factored (default) — xGMI is point-to-point (7 links per GPU, a ring all-reduce of the 27.5 MB
       flat gradient pushes 2 x 7/8 x 27.5 = 48 MB through every GPU's links: longer than the
       whole 0.2 ms step).  But 94 % of those bytes are the noisy-linear weight gradients, rank-B
-      products dW = dY^T X.  So the replicas ALL-GATHER THE FACTORS (dlogits, h, dh, feat rows of
-      their batch — 0.71 MB per rank at the canonical shape) on a side stream, overlapped with
-      the rest of the backward, all-reduce only the conv gradients (0.3 MB), and every replica
-      computes the mean FC gradient of the global batch from the gathered rows with the same
-      kernel (rb_learner_finish_grads).  39x fewer bytes on the wire, no re-read of the gradient
-      for the norm (the finishing kernels produce the sum-of-squares partials).
+      products dW = dY^T X.  So the replicas ALL-GATHER ONE BLOCK per rank — the factors (dlogits,
+      h, dh, feat rows of their batch), their noise vectors and their conv gradients, 1.0 MB at
+      the canonical shape — and every replica computes the mean gradient of the global batch from
+      the gathered blocks with the same kernel (rb_learner_finish_grads).  One collective per
+      step on the learn call's stream, no event, no side stream, 27x fewer bytes on the wire, no
+      re-read of the gradient for the norm (the finishing kernel produces the partials).
   allreduce — one all-reduce (mean) of the flat gradient buffer, then the library re-derives
       the norm (rb_learner_grads_modified).  Kept as the reference point.
 """
@@ -84,16 +84,12 @@ class FactoredExchange:
         dev = flat_grads.device
         self.cuda = dev.type == "cuda"
         self.local = torch.zeros(f.value, dtype=torch.float32, device=dev)
-        self.all = torch.zeros(self.world * f.value, dtype=torch.float32, device=dev)
-        self.small = flat_grads.detach()[off.value:off.value + n.value]
-        self.side = torch.cuda.Stream(device=dev) if self.cuda else None
         # a one-rank group (RAINBOW_AMD_FORCE_DIST) still runs the deferred-gradient path: the library needs world >= 2 to
         # defer, so the lone rank's block is presented twice and the mean of two equal halves is the gradient itself
         self.lib_world = max(self.world, 2)
-        if self.lib_world != self.world:
-            self.all = torch.zeros(self.lib_world * f.value, dtype=torch.float32, device=dev)
+        self.all = torch.zeros(self.lib_world * f.value, dtype=torch.float32, device=dev)
         L.check(lib, lib.rb_learner_set_exchange(handle, self.lib_world, self.local.data_ptr(), self.all.data_ptr()))
-        self.bytes_per_step = 4 * (f.value + n.value)
+        self.bytes_per_step = 4 * f.value
 
     def close(self):
         if self.h:
@@ -101,27 +97,14 @@ class FactoredExchange:
             self.h = None
 
     def run(self, stream_handle=None):
-        """Call right after rb_learner_learn*: all-gather the factor blocks (side stream, as soon as the local block is
-        complete), all-reduce the conv gradients, then let the library finish the FC gradients of the global batch."""
-        lib = self.lib
+        """Call right after rb_learner_learn*: ONE all-gather of the per-rank blocks on the current stream (it follows the
+        learn call's launches in stream order), then the library finishes the gradients of the global batch."""
         if self.cuda:
-            main = torch.cuda.current_stream(self.local.device)
-            L.check(lib, lib.rb_learner_wait_factors(self.h, self.side.cuda_stream))
-            with torch.cuda.stream(self.side):
-                self._gather()
-            _mean_reduce(self.small)          # main stream: waits for the conv gradients by stream order
-            main.wait_stream(self.side)
-            stream_handle = main.cuda_stream
-        else:
-            L.check(lib, lib.rb_learner_wait_factors(self.h, None))
-            self._gather()
-            _mean_reduce(self.small)
-        L.check(lib, lib.rb_learner_finish_grads(self.h, stream_handle))
-
-    def _gather(self):
+            stream_handle = torch.cuda.current_stream(self.local.device).cuda_stream
         if self.lib_world != self.world:      # one-rank plumbing run
             n = self.local.numel()
             dist.all_gather_into_tensor(self.all[:n], self.local)
             self.all[n:2 * n].copy_(self.all[:n])
         else:
             dist.all_gather_into_tensor(self.all, self.local)
+        L.check(self.lib, self.lib.rb_learner_finish_grads(self.h, stream_handle))

@@ -1,6 +1,6 @@
 """GPU parity of BASELINE config 5's exchange kernels on ONE device (no RCCL needed): two learner handles stand for two
 replicas (own batch, own noise, identical parameters); the collectives are replaced by device-side copies — a torch.cat
-for the all-gather of the factor blocks, an elementwise mean for the all-reduce — so that what runs on the GPU is exactly
+for the all-gather of the per-rank blocks, an elementwise mean for the flat all-reduce — so that what runs on the GPU is exactly
 rb_learner_learn with the exchange armed (k_pack_factors, deferred FC weight gradients), rb_learner_finish_grads
 (k_finish_grads) and, in the 'allreduce' mode, rb_learner_grads_modified -> k_sumsq, followed by the one-pass clip + Adam.
 Insert point in the reference: between agent.py:96 (backward) and agent.py:97 (clip_grad_norm_).
@@ -45,14 +45,9 @@ class PairFactoredExchange:
     def run(self):
         L, lib = self.L, self.lib
         stream = self.ads[0].mem.stream
-        for ad in self.ads:
-            L.check(lib, lib.rb_learner_wait_factors(ad.h, stream))
-        gathered = torch.cat(self.local)                       # the all-gather
-        small = [ad.grads[self.off:self.off + self.n] for ad in self.ads]
-        mean = (small[0] + small[1]) / 2                       # the all-reduce (mean) of the conv range
-        for ad, al, sm in zip(self.ads, self.all, small):
+        gathered = torch.cat(self.local)                       # the all-gather (FC factors, noise AND conv gradients of every rank)
+        for ad, al in zip(self.ads, self.all):
             al.copy_(gathered)
-            sm.copy_(mean)
             L.check(lib, lib.rb_learner_finish_grads(ad.h, stream))
 
     def close(self):
