@@ -383,3 +383,45 @@ def test_trajectory_tracks_reference_for_30_steps(emu):
     assert any(k.startswith("s29_param/") for k in trace)
     assert_learn_trace_matches(trace, {k: golden[k] for k in trace}, label="emu/k200[:30]")
     ad.close()
+
+
+def test_large_batch_fc_backward_variants_match_oracle(emu, monkeypatch):
+    """Batch 64 on the data-efficient stack with hidden 64 (F = 576, 2H = 128: multiples of 64): the LDS-shared 64 x 64-tile
+    weight-gradient kernel of the hidden layer (k_nl_dw_wide, RB_DW_WIDE=1) and the transposed-dh operand of its input
+    gradient (dhT, default) against the oracle — loss and every gradient (the GPU runs the same check at batch 64 / 256)."""
+    monkeypatch.setenv("RB_DW_WIDE", "1")
+    cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=64, multi_step=3, hidden=64)
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, "wide64", cfgd)
+    cfg = O.Config(**cfgd)
+    ad = CAbiLearnAdapter(emu, NumpyMem(), "wide64")
+    online, target = O.init_params(cfg, 277), O.init_params(cfg, 278)
+    ad.load(online, target)
+    rs = np.random.RandomState(25)
+    draws = O.noise_draw_count(cfg)
+    raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+    ad.reset_noise_online(raw_on)
+    batch = scenarios.make_batch(cfgd, 421)
+    got = ad.learn_step(batch, raw_tg)
+    want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+    total, clipped = O.clip_grads(want["grads"], scenarios.LEARN_HYPER["norm_clip"])
+    np.testing.assert_allclose(got["loss"], want["loss"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["grad_norm"], total, rtol=5e-5)
+    for k, g in clipped.items():
+        scale = float(np.max(np.abs(g))) if g.size else 0.0
+        np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
+    ad.close()
+
+
+@pytest.mark.parametrize("mode", ["1", "3"])
+def test_chained_conv_launch_matches_golden(emu, monkeypatch, mode):
+    """RB_CONV_CHAIN (opt-in): the conv stack of the learn step as ONE dataflow launch — block ranges per layer, per-image
+    arrival counters, epoch-based waits (mode 1: fences; 3: write-through stores + coherent loads, first layer as its own
+    launch).  Two consecutive steps (the counters are monotonic across launches) against the reference's golden vectors;
+    the bounded waits must not expire (CAbiLearnAdapter.finish_step asserts the error word)."""
+    monkeypatch.setenv("RB_CONV_CHAIN", mode)
+    name = "dataeff"
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    trace = scenarios.learn_scenario(ad, name, O, steps=2)
+    golden = load_golden("learn_%s.npz" % name)
+    assert_learn_trace_matches(trace, {k: golden[k] for k in trace}, label="emu-chain%s/%s" % (mode, name))
+    ad.close()

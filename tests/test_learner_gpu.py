@@ -546,3 +546,40 @@ def test_update_target_net_copies_noise_buffers_too(hip):
     torch.cuda.synchronize()
     assert torch.equal(agent.target_noise, agent.noise) and float(agent.noise.abs().sum()) > 0
     assert torch.equal(agent.target_params, agent.params.detach())
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+def test_chained_conv_launch_matches_oracle_at_baseline_shape(hip, monkeypatch, mode):
+    """RB_CONV_CHAIN=1/2/3 (opt-in dataflow launch of the conv stack, conv_lds.h k_conv_fwd_chain) at BASELINE cfg 2's
+    shape: three consecutive steps (monotonic arrival counters), loss / gradients / parameters against the oracle; the
+    bounded in-launch waits must not expire."""
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    monkeypatch.setenv("RB_CONV_CHAIN", mode)
+    shape = "cfg2-canonical-h512-b32-a6"
+    cfgd = BASELINE_SHAPES[shape]
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
+    cfg = O.Config(**cfgd)
+    hy = scenarios.LEARN_HYPER
+    ad = CAbiLearnAdapter(hip, TorchMem(), shape)
+    online, target = O.init_params(cfg, 911), O.init_params(cfg, 912)
+    ad.load(online, target)
+    adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
+    draws = O.noise_draw_count(cfg)
+    rs = np.random.RandomState(56)
+    got_t, want_t = {}, {}
+    for k in range(3):
+        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+        ad.reset_noise_online(raw_on)
+        batch = scenarios.make_batch(cfgd, 800 + k)
+        got = ad.learn_step(batch, raw_tg)
+        want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+        total, clipped = O.clip_grads(want["grads"], hy["norm_clip"])
+        online = adam.step(clipped)
+        got_t["s%d_loss" % k], want_t["s%d_loss" % k] = got["loss"], want["loss"]
+        for name in clipped:
+            got_t["s%d_grad/%s" % (k, name)], want_t["s%d_grad/%s" % (k, name)] = got["grads"][name], clipped[name]
+    for name, p in ad.params().items():
+        got_t["s2_param/%s" % name], want_t["s2_param/%s" % name] = p, online[name]
+    assert_learn_trace_matches(got_t, want_t, label="hip-chain%s/%s" % (mode, shape))
+    assert int(ad.debug(5, (1,), np.int32)[0]) == 0
+    ad.close()
