@@ -178,6 +178,7 @@ struct rb_learner {
   unsigned* chain_ctr;
   unsigned chain_epoch_fwd, chain_epoch_bwd;
   int opt_chain;        // RB_CONV_CHAIN (A/B switch, read once): 0 = one launch per layer
+  int opt_dw_wide, opt_dx_wide;   // RB_DW_WIDE / RB_DX_WIDE: the large-batch hidden-layer backward kernels (opt-in)
   int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
@@ -1450,6 +1451,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     l->opt_conv_full = (e = getenv("RB_CONV_FULL")) ? (e[0] != '0') : 1;
     l->opt_dx_ipb = (e = getenv("RB_DX_IPB")) ? atoi(e) : 0;
     l->opt_dx_wt = (e = getenv("RB_DX_WT")) ? atoi(e) : 0;      // measured slower (batch 256: 45 -> 53 us): off
+    l->opt_dw_wide = (e = getenv("RB_DW_WIDE")) ? (e[0] == '1') : 0;
+    l->opt_dx_wide = (e = getenv("RB_DX_WIDE")) ? (e[0] == '1') : 0;
     l->opt_chain = (e = getenv("RB_CONV_CHAIN")) ? atoi(e) : 0;      // measured: 3 = -1.5 us per step, 2 = equal, 1 = +13 us (profiles/round3_chain_*): opt-in
   }
   if (l->fast_fc) {
@@ -1804,7 +1807,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     // Measured at batch 256 (profiles/round3_fc_bwd_b256_ab.txt): 26.2 us for the gradient alone (0.40 of f32 MFMA, against
     // 0.31 for the fused launch as a whole) but the input-gradient part then runs alone for 45.5 us — 71.7 us in sequence
     // against 67.4 us fused, where the two overlap.  Opt-in until the input-gradient part is rebuilt the same way.
-    static const bool wide_off = !(getenv("RB_DW_WIDE") && getenv("RB_DW_WIDE")[0] == '1');
+    const bool wide_off = !l->opt_dw_wide;
     const bool h_wide = !pipe && !side && !exch && !wide_off && B >= 64 && L.F % 64 == 0 && L.H % 64 == 0;
     const int h_ct = pipe ? (ct_env >= 0 ? ct_env : 4) : (h_wide ? -1 : 0);
     FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
@@ -1884,9 +1887,18 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         RB_LAUNCH_T("fc_h_dw:k_nl_dw_wide", k_nl_dw_wide, dim3((unsigned)(hg.dw_x * hg.dw_y)), dim3(256), stream, hw_, hg.dw_x);
         hg.dw_x = 0; hg.dw_y = 0;
       }
-      RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd,
-                  dim3((unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled && !up_in_z) ? 1 : 0))), dim3(256),
-                  stream, hw_, hx, hg, up_in_z ? none : up);
+      // batch >= 128, RB_DX_WIDE=1: the input gradient on the weight-stationary kernel (noisy_linear.h k_nl_dx_wide).
+      // Measured at batch 256: 34.9 us on its own (0.30 of f32 MFMA, against 0.23 for the per-m-chunk body alone) and the
+      // rest of the fused launch 41.4 us -> 76 us in sequence against 67.4 us fused: opt-in, like RB_DW_WIDE.
+      if (l->opt_dx_wide && hx.dyT && B >= 128 && B % 4 == 0 && L.F % 64 == 0 && hx.rows_per_split % 16 == 0) {
+        RB_LAUNCH_T("fc_h_dx:k_nl_dx_wide", k_nl_dx_wide, dim3((unsigned)(L.F / 64), (unsigned)hsplits, (unsigned)rb_div_up(B, 256)), dim3(256),
+                    stream, hx);
+        hg.dx_x = 0; hg.dx_y = 0; hg.dx_z = 0;
+      }
+      const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled && !up_in_z) ? 1 : 0));
+      if (h_blocks > 0) {    // (0: both parts ran as launches of their own and there is no priority write-back to host)
+        RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up_in_z ? none : up);
+      }
     }
     l->sink_done = (up.enabled && !side) ? 1 : 0;
     RB_LAUNCH_CHECK();

@@ -565,6 +565,135 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
     }
   }
 }
+// Large batches (M >= 128; the hidden layer at batch 256): dx[m][k] = sum_n dy[m][n] W[n][k] with the weights of a
+// 64-column tile streamed ONCE per row split and shared by the whole batch.  The body above gives every 64-row m-chunk a
+// workgroup of its own (the 25.7 MB of mu | sigma are streamed four times at batch 256 and every lane group gathers dy
+// across 4 KB-strided rows): 45.5 us for 1.64 GFLOP, 0.23 of f32 MFMA, 3.6x the algorithmic HBM bytes at the counters.
+// Here a workgroup owns (64 columns, one row split, up to 256 samples): wave w keeps samples [64 w, 64 w + 64) in its
+// accumulators for the WHOLE row range — no cross-wave reduction — and the four waves share each 16-row chunk of noisy
+// weights (formed once, by the thread that loads mu and sigma) and of dY^T (from the transposed copy dyT, 16-byte loads)
+// through LDS; the next chunk's loads are in flight under the current chunk's 64 MFMAs per wave.
+// grid = (K / 64, row splits, ceil(M / 256)).  Requires dyT, K % 64 == 0, rows_per_split % 16 == 0, M % 4 == 0.
+#define RB_NL_DXW_DY_LD 272        // row stride (floats) of the dY^T chunk: the (q, c) lanes of an operand read hit distinct banks
+#define RB_NL_DXW_W_LD 68
+#define RB_NL_DXW_RC 32            // weight rows per chunk: 128 MFMAs per wave (1.7 us) cover the next chunk's memory round trip
+#define RB_NL_DXW_LDS (2 * RB_NL_DXW_RC * (RB_NL_DXW_DY_LD + RB_NL_DXW_W_LD))
+__global__ __launch_bounds__(256, 1) void k_nl_dx_wide(NlDxArgs a) {
+  constexpr int RC = RB_NL_DXW_RC, RU = RC / 16;                // rows per thread in the staging pattern
+  __shared__ __attribute__((aligned(16))) float lds[RB_NL_DXW_LDS];
+  float* s_dy = lds;                                            // [2][RC][RB_NL_DXW_DY_LD]
+  float* s_w = lds + 2 * RC * RB_NL_DXW_DY_LD;                  // [2][RC][RB_NL_DXW_W_LD]
+  const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
+  const NlDxProblem pr = a.prob[0];
+  const int kt = (int)blockIdx.x * 64;
+  const int by = (int)blockIdx.y;
+  const int mbase = (int)blockIdx.z * 256;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  const int rb = pr.row_begin + by * a.rows_per_split;
+  int re = rb + a.rows_per_split;
+  if (re > row_end) re = row_end;
+  if (rb >= re) return;                                         // block-uniform
+  const int c = lane & 15, q = lane >> 4;
+  const int m0 = mbase + 64 * wave;                             // this wave's 64 samples
+  const bool wave_on = m0 < a.M;
+  int mt_cnt = wave_on ? (a.M - m0 + 15) / 16 : 0;
+  if (mt_cnt > 4) mt_cnt = 4;
+  // staging coordinates: rows sr + 16 u of the chunk; weights — float4 column sc; dY^T — 4 float4 per row along m
+  const int sr = t >> 4, sc = t & 15;
+  const float4 e0 = rb_ld4(a.w.ein + pr.ein_off0 + kt + 4 * sc);
+  const float4 e1 = rb_ld4(a.w.ein + pr.ein_off1 + kt + 4 * sc);
+  rb_f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][j][e] = 0.0f;
+  float4 p_mu[RU], p_sg[RU], p_dy[RU][4];
+  float p_eo[RU];
+  int p_n0 = 0;
+  auto issue = [&](int nb) {
+    p_n0 = nb;
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      const int n = nb + sr + 16 * r;
+      const int nc = n < re ? n : re - 1;
+      p_mu[r] = rb_ld4(a.w.mu + (int64_t)nc * a.K + kt + 4 * sc);
+      p_sg[r] = rb_ld4(a.w.sigma + (int64_t)nc * a.K + kt + 4 * sc);
+      p_eo[r] = a.w.eout[nc];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = mbase + 4 * (sc + 16 * u);
+        p_dy[r][u] = m + 3 < a.M ? rb_ld4(a.dyT + (int64_t)nc * a.ldyT + m) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      const int n = p_n0 + sr + 16 * r;
+      const bool nv = n < re;                                   // rows beyond the split contribute zeros
+      float4 wv = rb_noisy4(p_mu[r], p_sg[r], p_eo[r], n >= pr.ein_split_row ? e1 : e0);
+      if (!nv) wv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      rb_st4(s_w + (buf * RC + sr + 16 * r) * RB_NL_DXW_W_LD + 4 * sc, wv);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        rb_st4(s_dy + (buf * RC + sr + 16 * r) * RB_NL_DXW_DY_LD + 4 * (sc + 16 * u), nv ? p_dy[r][u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    }
+  };
+  issue(rb);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int nb = rb; nb < re; nb += RC) {
+    const bool more = nb + RC < re;
+    if (more) issue(nb + RC);
+    const float* dyb = s_dy + buf * RC * RB_NL_DXW_DY_LD + 64 * wave;
+    const float* wb = s_w + buf * RC * RB_NL_DXW_W_LD;
+    if (wave_on) {                                              // wave-uniform
+#pragma unroll
+      for (int st = 0; st < RC / 4; ++st) {
+        if (nb + 4 * st < re) {                                 // uniform (the chunk's tail rows are zeros anyway)
+          const float4 w4 = rb_ld4(wb + (4 * st + q) * RB_NL_DXW_W_LD + 4 * c);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            if (mt < mt_cnt) {
+              const float av = dyb[(4 * st + q) * RB_NL_DXW_DY_LD + 16 * mt + c];
+              acc[mt][0] = rb_mfma16(av, w4.x, acc[mt][0]);
+              acc[mt][1] = rb_mfma16(av, w4.y, acc[mt][1]);
+              acc[mt][2] = rb_mfma16(av, w4.z, acc[mt][2]);
+              acc[mt][3] = rb_mfma16(av, w4.w, acc[mt][3]);
+            }
+          }
+        }
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (!wave_on) return;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < mt_cnt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + 16 * mt + 4 * q + e;
+        if (m < a.M) {
+          float4 v;
+          v.x = acc[mt][0][e]; v.y = acc[mt][1][e]; v.z = acc[mt][2][e]; v.w = acc[mt][3][e];
+          const int64_t o = ((int64_t)by * a.M + m) * a.ld_out + pr.out_off + kt + 4 * c;
+          if (a.mask_src) {
+            const float4 ms = rb_ld4(a.mask_src + o);
+            v.x = ms.x > 0.0f ? v.x : 0.0f; v.y = ms.y > 0.0f ? v.y : 0.0f; v.z = ms.z > 0.0f ? v.z : 0.0f; v.w = ms.w > 0.0f ? v.w : 0.0f;
+          }
+          rb_st4(a.out + o, v);
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
   __shared__ float lds[RB_NL_DX_LDS];
   rb_nl_dx_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);

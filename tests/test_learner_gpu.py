@@ -561,16 +561,16 @@ def test_chained_conv_launch_matches_oracle_at_baseline_shape(hip, monkeypatch, 
     cfg = O.Config(**cfgd)
     hy = scenarios.LEARN_HYPER
     ad = CAbiLearnAdapter(hip, TorchMem(), shape)
-    online, target = O.init_params(cfg, 911), O.init_params(cfg, 912)
+    online, target = O.init_params(cfg, 901), O.init_params(cfg, 902)     # (the inputs of the unchained BASELINE-shape test)
     ad.load(online, target)
     adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
     draws = O.noise_draw_count(cfg)
-    rs = np.random.RandomState(56)
+    rs = np.random.RandomState(55)
     got_t, want_t = {}, {}
     for k in range(3):
         raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
         ad.reset_noise_online(raw_on)
-        batch = scenarios.make_batch(cfgd, 800 + k)
+        batch = scenarios.make_batch(cfgd, 700 + k)
         got = ad.learn_step(batch, raw_tg)
         want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
         total, clipped = O.clip_grads(want["grads"], hy["norm_clip"])
@@ -582,4 +582,36 @@ def test_chained_conv_launch_matches_oracle_at_baseline_shape(hip, monkeypatch, 
         got_t["s2_param/%s" % name], want_t["s2_param/%s" % name] = p, online[name]
     assert_learn_trace_matches(got_t, want_t, label="hip-chain%s/%s" % (mode, shape))
     assert int(ad.debug(5, (1,), np.int32)[0]) == 0
+    ad.close()
+
+
+@pytest.mark.parametrize("env", [{"RB_DW_WIDE": "1"}, {"RB_DX_WIDE": "1"}, {"RB_DW_WIDE": "1", "RB_DX_WIDE": "1"}],
+                         ids=["dw-wide", "dx-wide", "both-wide"])
+def test_large_batch_hidden_layer_backward_kernels_match_oracle(hip, monkeypatch, env):
+    """The opt-in large-batch kernels of the hidden layer's backward (k_nl_dw_wide: LDS-shared 64 x 64 gradient tiles;
+    k_nl_dx_wide: weight-stationary input gradient on the transposed dh) at BASELINE cfg 3's shape (batch 256): loss, norm
+    and every gradient against the oracle."""
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    shape = "cfg3-canonical-h512-b256-a4"
+    cfgd = BASELINE_SHAPES[shape]
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
+    cfg = O.Config(**cfgd)
+    ad = CAbiLearnAdapter(hip, TorchMem(), shape)
+    online, target = O.init_params(cfg, 921), O.init_params(cfg, 922)
+    ad.load(online, target)
+    rs = np.random.RandomState(57)
+    draws = O.noise_draw_count(cfg)
+    raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+    ad.reset_noise_online(raw_on)
+    batch = scenarios.make_batch(cfgd, 900)
+    got = ad.learn_step(batch, raw_tg)
+    want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+    total, clipped = O.clip_grads(want["grads"], scenarios.LEARN_HYPER["norm_clip"])
+    np.testing.assert_allclose(got["loss"], want["loss"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["grad_norm"], total, rtol=5e-5)
+    for k, g in clipped.items():
+        scale = float(np.max(np.abs(g))) if g.size else 0.0
+        np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
     ad.close()
