@@ -1883,6 +1883,15 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         RB_LAUNCH_CHECK();
         l->exch_pending = 1;
       }
+      const bool dx_wide_ok = hx.dyT && B >= 128 && B % 4 == 0 && L.F % 64 == 0 && hx.rows_per_split % 16 == 0;
+      if (h_wide && l->opt_dx_wide && dx_wide_ok) {
+        // both wide bodies + the priority write-back as block ranges of ONE launch (noisy_linear.h k_nl_bwd_wide)
+        const int n_dw = hg.dw_x * hg.dw_y, n_dx = (L.F / 64) * hsplits * (int)rb_div_up(B, 256);
+        RB_LAUNCH_T("fc_h_bwd:k_nl_bwd_wide", k_nl_bwd_wide, dim3((unsigned)(n_dw + n_dx + ((up.enabled && !up_in_z) ? 1 : 0))), dim3(256),
+                    stream, hw_, hg.dw_x, n_dw, hx, L.F / 64, hsplits, up_in_z ? none : up);
+        hg.dw_x = 0; hg.dw_y = 0; hg.dx_x = 0; hg.dx_y = 0; hg.dx_z = 0;
+        if (!up_in_z && up.enabled) up.enabled = 2;                            // (2: done above — no block left for k_nl_bwd)
+      } else {
       if (h_wide) {        // batch >= 64: the weight gradient as a launch of its own (noisy_linear.h k_nl_dw_wide)
         RB_LAUNCH_T("fc_h_dw:k_nl_dw_wide", k_nl_dw_wide, dim3((unsigned)(hg.dw_x * hg.dw_y)), dim3(256), stream, hw_, hg.dw_x);
         hg.dw_x = 0; hg.dw_y = 0;
@@ -1890,12 +1899,13 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
       // batch >= 128, RB_DX_WIDE=1: the input gradient on the weight-stationary kernel (noisy_linear.h k_nl_dx_wide).
       // Measured at batch 256: 34.9 us on its own (0.30 of f32 MFMA, against 0.23 for the per-m-chunk body alone) and the
       // rest of the fused launch 41.4 us -> 76 us in sequence against 67.4 us fused: opt-in, like RB_DW_WIDE.
-      if (l->opt_dx_wide && hx.dyT && B >= 128 && B % 4 == 0 && L.F % 64 == 0 && hx.rows_per_split % 16 == 0) {
+      if (l->opt_dx_wide && dx_wide_ok) {
         RB_LAUNCH_T("fc_h_dx:k_nl_dx_wide", k_nl_dx_wide, dim3((unsigned)(L.F / 64), (unsigned)hsplits, (unsigned)rb_div_up(B, 256)), dim3(256),
                     stream, hx);
         hg.dx_x = 0; hg.dx_y = 0; hg.dx_z = 0;
       }
-      const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled && !up_in_z) ? 1 : 0));
+      }
+      const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled == 1 && !up_in_z) ? 1 : 0));
       if (h_blocks > 0) {    // (0: both parts ran as launches of their own and there is no priority write-back to host)
         RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up_in_z ? none : up);
       }

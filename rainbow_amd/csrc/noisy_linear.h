@@ -576,18 +576,17 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
 // grid = (K / 64, row splits, ceil(M / 256)).  Requires dyT, K % 64 == 0, rows_per_split % 16 == 0, M % 4 == 0.
 #define RB_NL_DXW_DY_LD 272        // row stride (floats) of the dY^T chunk: the (q, c) lanes of an operand read hit distinct banks
 #define RB_NL_DXW_W_LD 68
-#define RB_NL_DXW_RC 32            // weight rows per chunk: 128 MFMAs per wave (1.7 us) cover the next chunk's memory round trip
-#define RB_NL_DXW_LDS (2 * RB_NL_DXW_RC * (RB_NL_DXW_DY_LD + RB_NL_DXW_W_LD))
-__global__ __launch_bounds__(256, 1) void k_nl_dx_wide(NlDxArgs a) {
-  constexpr int RC = RB_NL_DXW_RC, RU = RC / 16;                // rows per thread in the staging pattern
-  __shared__ __attribute__((aligned(16))) float lds[RB_NL_DXW_LDS];
+// RC = weight rows per chunk (16: 43 KB of LDS, three workgroups per CU; 32: 87 KB, one — measured equal)
+#define RB_NL_DXW_LDS(RC) (2 * (RC) * (RB_NL_DXW_DY_LD + RB_NL_DXW_W_LD))
+template <int RC>
+__device__ __forceinline__ void rb_nl_dx_body_wide(const NlDxArgs& a, int bx, int by, int bz, float* lds) {
+  constexpr int RU = RC / 16;                                   // rows per thread in the staging pattern
   float* s_dy = lds;                                            // [2][RC][RB_NL_DXW_DY_LD]
   float* s_w = lds + 2 * RC * RB_NL_DXW_DY_LD;                  // [2][RC][RB_NL_DXW_W_LD]
   const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
   const NlDxProblem pr = a.prob[0];
-  const int kt = (int)blockIdx.x * 64;
-  const int by = (int)blockIdx.y;
-  const int mbase = (int)blockIdx.z * 256;
+  const int kt = bx * 64;
+  const int mbase = bz * 256;
   const int row_end = pr.row_begin + pr.row_cnt;
   const int rb = pr.row_begin + by * a.rows_per_split;
   int re = rb + a.rows_per_split;
@@ -694,6 +693,10 @@ __global__ __launch_bounds__(256, 1) void k_nl_dx_wide(NlDxArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256, 1) void k_nl_dx_wide(NlDxArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[RB_NL_DXW_LDS(32)];
+  rb_nl_dx_body_wide<32>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
+}
 __global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
   __shared__ float lds[RB_NL_DX_LDS];
   rb_nl_dx_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
@@ -1196,4 +1199,21 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     RB_SPAN_END(sb + 2);
   }
+}
+
+// Large batches: the hidden layer's whole backward on the two wide bodies in ONE launch — block ranges [priority
+// write-back | 64 x 64 weight-gradient tiles | weight-stationary input-gradient workgroups] — so that the three overlap on
+// the chip as they do in k_nl_bwd (either wide body as a launch of its own lost more to the sequence than it gained).
+__global__ __launch_bounds__(256, 3) void k_nl_bwd_wide(NlDwArgs dw, int dw_x, int n_dw, NlDxArgs dx, int dx_x, int dx_y, NlPriorityUpdate up) {
+  constexpr int L0 = RB_NL_DXW_LDS(16) > RB_NL_DWW_LDS ? RB_NL_DXW_LDS(16) : RB_NL_DWW_LDS;
+  constexpr int LDSW = L0 > UpdateLds<512, 256>::WORDS ? L0 : UpdateLds<512, 256>::WORDS;
+  __shared__ __attribute__((aligned(16))) float lds[LDSW];
+  int b = (int)blockIdx.x;
+  if (up.enabled) {
+    if (b == 0) { rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds); return; }
+    b -= 1;
+  }
+  if (b < n_dw) { rb_nl_dw_body_wide(dw, b % dw_x, b / dw_x, 4 * b, lds); return; }
+  b -= n_dw;
+  rb_nl_dx_body_wide<16>(dx, b % dx_x, (b / dx_x) % dx_y, b / (dx_x * dx_y), lds);
 }

@@ -385,12 +385,15 @@ def test_trajectory_tracks_reference_for_30_steps(emu):
     ad.close()
 
 
-def test_large_batch_fc_backward_variants_match_oracle(emu, monkeypatch):
-    """Batch 64 on the data-efficient stack with hidden 64 (F = 576, 2H = 128: multiples of 64): the LDS-shared 64 x 64-tile
-    weight-gradient kernel of the hidden layer (k_nl_dw_wide, RB_DW_WIDE=1) and the transposed-dh operand of its input
-    gradient (dhT, default) against the oracle — loss and every gradient (the GPU runs the same check at batch 64 / 256)."""
+@pytest.mark.parametrize("nbatch,dx_wide", [(64, "0"), (128, "1")], ids=["b64-dw", "b128-fused"])
+def test_large_batch_fc_backward_variants_match_oracle(emu, monkeypatch, nbatch, dx_wide):
+    """Batch 64 / 128 on the data-efficient stack with hidden 64 (F = 576, 2H = 128: multiples of 64): the LDS-shared
+    64 x 64-tile weight-gradient kernel of the hidden layer (k_nl_dw_wide, RB_DW_WIDE=1), the transposed-dh operand of its
+    input gradient (dhT, default) and — batch 128, RB_DX_WIDE=1 — both wide bodies plus the priority write-back as block
+    ranges of one launch (k_nl_bwd_wide) against the oracle: loss and every gradient (the GPU runs the same check at 256)."""
     monkeypatch.setenv("RB_DW_WIDE", "1")
-    cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=64, multi_step=3, hidden=64)
+    monkeypatch.setenv("RB_DX_WIDE", dx_wide)
+    cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=nbatch, multi_step=3, hidden=64)
     monkeypatch.setitem(scenarios.LEARN_CONFIGS, "wide64", cfgd)
     cfg = O.Config(**cfgd)
     ad = CAbiLearnAdapter(emu, NumpyMem(), "wide64")
