@@ -97,7 +97,7 @@ CONV_GEOM = {   # (cin, cout, kernel, stride, in, out) per layer, model.py:55-63
 }
 
 
-def kernel_table(cfg, n_params):
+def kernel_table(cfg, n_params, hosted_update=False):
     """Algorithmic work per launch of the kernels that can dominate a step, with the roofline that bounds
     each: the streamed hidden layer and the optimiser pass are HBM-bound, the conv kernels f32-MFMA-bound.
     Keys are the profiling tags of the launches (RB_LAUNCH_T in csrc/learner.hip)."""
@@ -135,6 +135,11 @@ def kernel_table(cfg, n_params):
     # the longest launch of the step (latency-bound)
     L = (cfg["capacity"] - 1).bit_length()
     t["sample"] = dict(bound="hbm", work=B * (4 * L + 4 * (4 + cfg["multi_step"]) + 4 * cfg["multi_step"] + 12), unit="GB/s")
+    if hosted_update:
+        # RAINBOW_AMD_DEFER_UPDATE (default): the previous step's clip + Adam pass runs as extra workgroups of the sampler
+        # launch (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE) — ONE launch carries both, there is no clip_adam launch
+        t["sample"]["work"] += t.pop("clip_adam")["work"]
+        t["sample"]["hosts"] = "clip_adam"
     return t
 
 
@@ -308,17 +313,23 @@ def main():
         lib.rb_profile_select(tag.encode())
         for _ in range(n):
             step()
-        torch.cuda.synchronize(dev)
+        drain()
         ms, cnt = C.c_double(0), C.c_int64(0)
         lib.rb_profile_read(C.byref(ms), C.byref(cnt))
         lib.rb_profile_select(None)
         return (ms.value / cnt.value * 1e-3, cnt.value) if cnt.value > 0 else (None, 0)
 
+    def drain():
+        """End of a timed region: the optimiser pass the last learn() left pending (it would ride in the NEXT step's sampler
+        launch) runs now, inside the region — K steps = K optimiser passes — then the device is drained."""
+        agent.flush()
+        torch.cuda.synchronize(dev)
+
     for _ in range(opt.warmup):
         step()
-    torch.cuda.synchronize(dev)
+    drain()
 
-    ktab = kernel_table(cfg, int(agent.params.numel()))
+    ktab = kernel_table(cfg, int(agent.params.numel()), hosted_update=agent._defer_update)
     # the kernel the roofline object reports = the step's DOMINANT kernel by time, found by a short bracketed pass over
     # every candidate before the timed region (or forced with --roofline-kernel)
     if opt.no_profile:
@@ -339,7 +350,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         step()
-    torch.cuda.synchronize(dev)
+    drain()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
@@ -356,7 +367,7 @@ def main():
     t_plain = time.perf_counter()
     for _ in range(min(opt.steps, 500)):
         step()
-    torch.cuda.synchronize(dev)
+    drain()
     plain_ms = (time.perf_counter() - t_plain) / min(opt.steps, 500) * 1e3
     # every other candidate, each timed the same way in a short pass of its own AFTER the timed region
     others = {}
@@ -433,7 +444,8 @@ def main():
             net = max(seconds - ev_us * 1e-6, 1e-9)
             return {"kernel": name, "bound": k["bound"], "achieved": ach, "peak": peak, "unit": k["unit"], "frac": ach / peak,
                     "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"), "avg_us": seconds * 1e6, "launches": n,
-                    "algorithmic_work_per_launch": k["work"], "avg_us_net": net * 1e6, "frac_net": achieved(k, net)[0] / peak}
+                    "algorithmic_work_per_launch": k["work"], "avg_us_net": net * 1e6, "frac_net": achieved(k, net)[0] / peak,
+                    **({"hosts": k["hosts"]} if "hosts" in k else {})}
 
         if launches.value > 0:
             out["roofline"] = roof(kname, tot_ms.value / launches.value * 1e-3, launches.value)

@@ -336,10 +336,22 @@ int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t
  *   call on the handle after rb_learner_learn* must be rb_learner_clip_adam (clip_grad / grads_modified refuse), and
  *   grads_dev does not hold the hidden layer's weight gradient afterwards ...
  * RB_LEARNER_WRITE_FUSED_GRADS: ... unless this flag is set as well: the fused pass then also stores the tiles it
- *   computed (as clip_grad_norm_ leaves them), which is how the parity tests read the product path's gradient.        */
+ *   computed (as clip_grad_norm_ leaves them), which is how the parity tests read the product path's gradient.
+ * RB_LEARNER_DEFER_UPDATE: rb_learner_train_step (called with step = 0: a device step counter is required) leaves its
+ *   clip + Adam pass (agent.py:97-98) PENDING instead of launching it.  The next rb_learner_train_step hosts it as extra
+ *   workgroups of its sampler launch: the optimiser pass of learn call k does not depend on the sampling of call k + 1 nor
+ *   the other way round (the priorities were written back in call k's backward), so 30 us of pure HBM streaming run
+ *   beside the sampler's one latency-bound workgroup instead of in front of it.  Same arithmetic in the same order: the
+ *   parameters are bit-identical to the undeferred ones.  EVERY other learner entry point that touches parameters,
+ *   moments, gradients or the norm (act, act_batch, learn*, clip_*, sync_target, finish_grads, debug_read) first runs the
+ *   pending pass as a launch of its own, on the stream it is given — use ONE stream per handle.  A caller that reads the
+ *   borrowed buffers itself (params_dev, exp_avg, exp_avg_sq, grads_dev, norm_dev) calls rb_learner_flush first.       */
 #define RB_LEARNER_FUSE_FC_H_DW 1
 #define RB_LEARNER_WRITE_FUSED_GRADS 2
+#define RB_LEARNER_DEFER_UPDATE 4
 int rb_learner_set_flags(rb_learner_t* l, int32_t flags);
+/* Run the pending optimiser pass, if any (RB_LEARNER_DEFER_UPDATE), on `stream`.  No-op otherwise.                    */
+int rb_learner_flush(rb_learner_t* l, rb_stream_t stream);
 
 /* hipGraph replay with the fused optimiser pass: a captured launch cannot take a new `step` by value.  With a counter set
  * (caller-owned i64 on the device), every rb_learner_learn* increments it on the device, and rb_learner_clip_adam called

@@ -106,6 +106,7 @@ SIGNATURES = {
                                      c_int64, c_void_p, c_void_p]),
     "rb_learner_train_step": (c_int, [c_void_p, C.POINTER(TrainStep), c_void_p]),
     "rb_learner_set_flags": (c_int, [c_void_p, c_int32]),
+    "rb_learner_flush": (c_int, [c_void_p, c_void_p]),
     "rb_learner_set_step_counter": (c_int, [c_void_p, c_void_p]),
     "rb_learner_set_priority_sink": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rb_learner_priority_written": (c_int, [c_void_p]),
@@ -137,7 +138,7 @@ def declare(lib, strict=True):
     return lib
 
 
-LEARNER_FUSE_FC_H_DW, LEARNER_WRITE_FUSED_GRADS = 1, 2
+LEARNER_FUSE_FC_H_DW, LEARNER_WRITE_FUSED_GRADS, LEARNER_DEFER_UPDATE = 1, 2, 4
 
 
 class RainbowError(RuntimeError):

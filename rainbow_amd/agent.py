@@ -76,9 +76,9 @@ class _FlatAdam(torch.optim.Adam):
     one-pass kernel (rb_learner_clip_adam), optionally with clip_grad_norm_ folded in (max_norm)."""
 
     def __init__(self, agent, **kw):
-        super().__init__([agent.params], **kw)
+        super().__init__([agent._params], **kw)
         self._agent = weakref.ref(agent)
-        p = agent.params
+        p = agent._params
         self.state[p] = dict(step=torch.tensor(0.0, dtype=torch.float32),
                              exp_avg=torch.zeros_like(p, memory_format=torch.preserve_format),
                              exp_avg_sq=torch.zeros_like(p, memory_format=torch.preserve_format))
@@ -86,8 +86,17 @@ class _FlatAdam(torch.optim.Adam):
     def state_dict(self):
         ag = self._agent()
         if ag is not None:
+            ag.flush()               # a deferred optimiser pass writes the moments
             ag._sync_step()          # graph replay counts steps on the device: refresh the host mirror first
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        ag = self._agent()
+        if ag is not None:
+            ag.flush()
+        super().load_state_dict(state_dict)
+        if ag is not None and ag._step_dev is not None:      # the device-resident step number follows the loaded one
+            ag._step_dev.fill_(int(float(self.state[ag._params]["step"])))
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=float("inf")):
@@ -116,7 +125,7 @@ class _FlatAdam(torch.optim.Adam):
         rc = ag._lib.rb_learner_clip_adam(
             ag._h, float(max_norm), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1),
             float(b2), float(g["eps"]), step,
-            ag._norm.data_ptr() if math.isfinite(max_norm) else None, ag._stream() if stream is None else stream)
+            ag._norm_buf.data_ptr() if math.isfinite(max_norm) else None, ag._stream() if stream is None else stream)
         if rc != 0:
             L.check(ag._lib, rc)
 
@@ -144,22 +153,24 @@ class Agent:
                                     history=int(args.history_length), hidden=int(args.hidden_size),
                                     architecture=0 if arch == "canonical" else 1, multi_step=int(args.multi_step),
                                     v_min=float(args.V_min), v_max=float(args.V_max), discount=float(args.discount))
+        self._defer_update = False
+        self._update_pending = False
         n_params, n_noise = C.c_int64(0), C.c_int64(0)
         L.check(self._lib, self._lib.rb_learner_sizes(C.byref(self._cfg), C.byref(n_params), C.byref(n_noise)))
         self._layout = _query_layout(self._lib, self._cfg, self._lib.rb_learner_param_layout)
         self._noise_layout = _query_layout(self._lib, self._cfg, self._lib.rb_learner_noise_layout)
         d = self.device
-        self.params = torch.zeros(n_params.value, dtype=torch.float32, device=d)          # online, flat
+        self._params = torch.zeros(n_params.value, dtype=torch.float32, device=d)          # online, flat
         self.target_params = torch.zeros(n_params.value, dtype=torch.float32, device=d)
-        self.grads = torch.zeros(n_params.value, dtype=torch.float32, device=d)
+        self._grads = torch.zeros(n_params.value, dtype=torch.float32, device=d)
         self.noise = torch.zeros(n_noise.value, dtype=torch.float32, device=d)
         self.target_noise = torch.zeros(n_noise.value, dtype=torch.float32, device=d)
         self._h = C.c_void_p()
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         with torch.cuda.device(d):
             L.check(self._lib, self._lib.rb_learner_create(
-                C.byref(self._h), C.byref(self._cfg), self.params.data_ptr(), self.target_params.data_ptr(),
-                self.grads.data_ptr(), self.noise.data_ptr(), self.target_noise.data_ptr(), seed))
+                C.byref(self._h), C.byref(self._cfg), self._params.data_ptr(), self.target_params.data_ptr(),
+                self._grads.data_ptr(), self.noise.data_ptr(), self.target_noise.data_ptr(), seed))
 
         self._init_parameters(float(getattr(args, "noisy_std", 0.1)))
         self._noise_pending = False
@@ -174,8 +185,8 @@ class Agent:
                 raise FileNotFoundError(args.model)
         self.update_target_net()                                     # agent.py:41
 
-        self.params.requires_grad_(True)
-        self.params.grad = self.grads
+        self._params.requires_grad_(True)
+        self._params.grad = self._grads
         # hipGraph replay of the whole step is opt-in (RAINBOW_AMD_GRAPH=1).  The captured step runs the library's own
         # one-pass clip + Adam too: the optimiser's step number is then a device-resident counter the learn call increments
         # and the kernel reads (rb_learner_set_step_counter), since a by-value argument would freeze at capture time.
@@ -186,11 +197,18 @@ class Agent:
             if self._use_graph:
                 kw["capturable"] = True
             try:
-                self.optimiser = torch.optim.Adam([self.params], fused=True, **kw)
+                self.optimiser = torch.optim.Adam([self._params], fused=True, **kw)
             except (TypeError, RuntimeError):
-                self.optimiser = torch.optim.Adam([self.params], **kw)
+                self.optimiser = torch.optim.Adam([self._params], **kw)
         else:
-            if self._use_graph:
+            # RAINBOW_AMD_DEFER_UPDATE (default on; eager one-call path only): learn() leaves its clip + Adam pass pending
+            # and the NEXT learn()'s sampler launch hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE) — anything
+            # else that touches the parameters runs it first (the library's entry points do so themselves; the public
+            # tensors `params`, `grads`, `_norm` and the optimiser state go through flush()).  Needs the device-resident
+            # step number, like graph replay.
+            self._defer_update = (os.environ.get("RAINBOW_AMD_DEFER_UPDATE", "1") == "1" and not self._use_graph
+                                  and rdist.world_size() == 1)
+            if self._use_graph or self._defer_update:
                 self._step_dev = torch.zeros(1, dtype=torch.int64, device=d)
                 L.check(self._lib, self._lib.rb_learner_set_step_counter(self._h, self._step_dev.data_ptr()))
             self.optimiser = _FlatAdam(self, **kw)                   # agent.py:46
@@ -208,7 +226,7 @@ class Agent:
         # priority write-back as one extra workgroup of the learner's backward launch (see rb_learner_set_priority_sink)
         self._fuse_update = os.environ.get("RAINBOW_AMD_FUSED_UPDATE", "1") == "1"
         self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
-        self._norm = torch.zeros(1, dtype=torch.float32, device=d)
+        self._norm_buf = torch.zeros(1, dtype=torch.float32, device=d)
         self._act_pin = torch.zeros(2 * self.batch_size, dtype=torch.int32).pin_memory()     # written by the device
         self._q_pin = torch.zeros(2 * self.batch_size, dtype=torch.float32).pin_memory()
         self._act_np, self._q_np = self._act_pin.numpy(), self._q_pin.numpy()
@@ -219,19 +237,45 @@ class Agent:
         self._dist = rdist.active()
         self._exchange = None
         if self._dist:        # identical replicas: rank 0's initial parameters everywhere
-            rdist.broadcast_parameters(self.params.detach(), 0)
+            rdist.broadcast_parameters(self._params.detach(), 0)
             self.update_target_net()
             if rdist.mode() == "factored" and isinstance(self.optimiser, _FlatAdam):
-                self._exchange = rdist.FactoredExchange(self._lib, self._h, self.grads)
+                self._exchange = rdist.FactoredExchange(self._lib, self._h, self._grads)
         # RAINBOW_AMD_FUSED_DW=1 (single device + the library's own Adam): the hidden layer's weight gradient (93 % of the
         # gradient bytes) is never written to HBM — the backward computes it for the norm only, the clip + Adam pass
         # recomputes each tile while it streams that tile's parameters (include/rainbow_hip.h RB_LEARNER_FUSE_FC_H_DW);
-        # self.grads then holds every OTHER gradient after learn().  51 MB less HBM traffic per step at the canonical
+        # self._grads then holds every OTHER gradient after learn().  51 MB less HBM traffic per step at the canonical
         # shape, measured 216.7 -> 215.3 us per step on MI355X: an opt-in, the default materialises every gradient as the
         # reference does.
         self._fused_dw = (isinstance(self.optimiser, _FlatAdam) and not self._dist
                           and os.environ.get("RAINBOW_AMD_FUSED_DW", "0") == "1")
-        L.check(self._lib, self._lib.rb_learner_set_flags(self._h, L.LEARNER_FUSE_FC_H_DW if self._fused_dw else 0))
+        if self._fused_dw or self._dist:
+            self._defer_update = False
+        L.check(self._lib, self._lib.rb_learner_set_flags(
+            self._h, (L.LEARNER_FUSE_FC_H_DW if self._fused_dw else 0) | (L.LEARNER_DEFER_UPDATE if self._defer_update else 0)))
+
+    # The flat tensors the library borrows.  With a deferred optimiser pass pending they are one update behind: reading them
+    # through these names runs the pass first.
+    @property
+    def params(self):
+        self.flush()
+        return self._params
+
+    @property
+    def grads(self):
+        self.flush()
+        return self._grads
+
+    @property
+    def _norm(self):
+        self.flush()
+        return self._norm_buf
+
+    def flush(self):
+        """Run the optimiser pass the last learn() left pending (RAINBOW_AMD_DEFER_UPDATE), if any."""
+        if self._update_pending:
+            self._update_pending = False
+            L.check(self._lib, self._lib.rb_learner_flush(self._h, self._stream()))
 
     # ------------------------------------------------------------------ plumbing
     def __del__(self):
@@ -259,7 +303,7 @@ class Agent:
 
     def _init_parameters(self, noisy_std):
         with torch.no_grad():
-            self.params.copy_(init_parameters_flat(self._layout, self.params.numel(), noisy_std))
+            self._params.copy_(init_parameters_flat(self._layout, self._params.numel(), noisy_std))
 
     # ------------------------------------------------------------------ reference API
     def reset_noise(self, raw_normals=None):
@@ -394,7 +438,7 @@ class Agent:
         if not failed:
             return
         if isinstance(self.optimiser, _FlatAdam) and getattr(self, "_sink_mem", None) is mem:
-            st = self.optimiser.state[self.params]
+            st = self.optimiser.state[self._params]
             st["step"] -= float(min(failed, int(st["step"].item())))
         mem.reset_failed_samples()
         raise RuntimeError("ReplayMemory: %d sampler launch(es) found no valid batch in %d attempts (replay too small for "
@@ -404,7 +448,7 @@ class Agent:
     def _sync_step(self):
         """Host mirror of the optimiser's step number after graph replays (state_dict / checkpoint read it)."""
         if self._step_dev is not None and isinstance(self.optimiser, _FlatAdam):
-            self.optimiser.state[self.params]["step"].fill_(float(self._step_dev.item()))
+            self.optimiser.state[self._params]["step"].fill_(float(self._step_dev.item()))
 
     def _capture(self, mem):
         dev = self.device
@@ -435,7 +479,7 @@ class Agent:
                              tree_idx_dev=o["tree_idxs"].data_ptr(), actions_dev=o["actions"].data_ptr(),
                              returns_dev=o["returns"].data_ptr(), nonterminals_dev=o["nonterminals"].data_ptr(),
                              weights_dev=o["weights"].data_ptr(), frames_dev=frames, windows_dev=windows,
-                             loss_dev=self._loss.data_ptr(), norm_dev=self._norm.data_ptr())
+                             loss_dev=self._loss.data_ptr(), norm_dev=self._norm_buf.data_ptr())
             self._ts, self._ts_mem, self._ts_out = ts, mem, o
         if float(mem.priority_weight) != mem._neg_beta_val:
             mem._sync_beta()
@@ -447,7 +491,7 @@ class Agent:
             L.check(self._lib, self._lib.rb_learner_noise_job(self._h, which, C.byref(job)))
             self._noise_jobs[which] = job
         g = self.optimiser.param_groups[0]
-        st = self.optimiser.state[self.params]        # looked up every step: load_state_dict replaces these tensors
+        st = self.optimiser.state[self._params]        # looked up every step: load_state_dict replaces these tensors
         st["step"] += 1
         ts.exp_avg_dev, ts.exp_avg_sq_dev = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
         ts.priority_weight = float(mem.priority_weight)
@@ -458,6 +502,7 @@ class Agent:
         rc = self._lib.rb_learner_train_step(self._h, C.byref(ts), stream)
         if rc != 0:
             L.check(self._lib, rc)
+        self._update_pending = self._defer_update
         if not self._lib.rb_learner_priority_written(self._h):       # (cannot happen with a sink set; keeps agent.py:100)
             mem.update_priorities(self._ts_out["tree_idxs"], self._loss)
 
@@ -542,12 +587,12 @@ class Agent:
             # backward), all-reduce the conv gradients (0.3 MB), finish the FC gradients of the global batch on device
             self._exchange.run()
         elif self._dist:      # replicas, plain exchange: one RCCL all-reduce of the flat gradient (4*P bytes)
-            rdist.average_gradients(self.grads)
+            rdist.average_gradients(self._grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         if isinstance(self.optimiser, _FlatAdam):
             self.optimiser.step_direct(float(self.norm_clip), stream)                      # agent.py:97-98, one pass
         else:
-            L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm.data_ptr(),
+            L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm_buf.data_ptr(),
                                                               stream))                    # agent.py:97
             self.optimiser.step()                                                          # agent.py:98
         if overlap:
@@ -602,9 +647,10 @@ class Agent:
     def state_dict(self):
         """Reference-compatible keys: convs.{0,2,4}.{weight,bias}, fc_*.{weight,bias}_{mu,sigma,epsilon}."""
         self._flush_noise()
+        self.flush()
         sd = {}
         for name, _off, _shape in self._layout:
-            sd[name] = self._view(self.params, name).clone()
+            sd[name] = self._view(self._params, name).clone()
         for layer in _LAYERS:
             e_in = self._noise_view(self.noise, layer + ".eps_in")
             e_out = self._noise_view(self.noise, layer + ".eps_out")
@@ -623,6 +669,7 @@ class Agent:
         """nn.Module.load_state_dict of the reference's DQN (agent.py:33): STRICT by default — missing or unexpected keys
         raise, as the reference's call does.  The [out, in] weight_epsilon buffers are rank-1 (model.py:39); the
         factorised vectors are recovered EXACTLY (see _recover_eps_in), so save -> load -> save is bit-identical."""
+        self.flush()
         sd = dict(state_dict)
         if "conv1.weight" in sd:                                                           # agent.py:29-32
             for old, new in (("conv1.weight", "convs.0.weight"), ("conv1.bias", "convs.0.bias"),
@@ -645,7 +692,7 @@ class Agent:
                 t = sd[name]
                 if tuple(t.shape) != tuple(shape):
                     raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(t.shape), shape))
-                self._view(self.params, name).copy_(t.to(self.device, torch.float32))
+                self._view(self._params, name).copy_(t.to(self.device, torch.float32))
             for layer in _LAYERS:
                 if layer + ".bias_epsilon" not in sd or layer + ".weight_epsilon" not in sd:
                     continue
@@ -684,11 +731,12 @@ class Agent:
         (main.py has no such thing: it restarts the optimiser).  Returns the dict; writes it with torch.save if `path`."""
         if not isinstance(self.optimiser, _FlatAdam):
             raise NotImplementedError("checkpoint() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1, no graph)")
+        self.flush()
         self._sync_step()
         seed, epoch = C.c_uint64(0), C.c_uint64(0)
         L.check(self._lib, self._lib.rb_learner_get_rng(self._h, C.byref(seed), C.byref(epoch), self._stream()))
-        st = self.optimiser.state[self.params]
-        ck = dict(version=1, config=bytes(self._cfg), params=self.params.detach().cpu(), target_params=self.target_params.cpu(),
+        st = self.optimiser.state[self._params]
+        ck = dict(version=1, config=bytes(self._cfg), params=self._params.detach().cpu(), target_params=self.target_params.cpu(),
                   noise=self.noise.cpu(), target_noise=self.target_noise.cpu(), exp_avg=st["exp_avg"].cpu(),
                   exp_avg_sq=st["exp_avg_sq"].cpu(), adam_step=float(st["step"]), rng_seed=int(seed.value),
                   rng_epoch=int(epoch.value), noise_pending=bool(self._noise_pending), training=bool(self.training))
@@ -700,16 +748,17 @@ class Agent:
         """Inverse of checkpoint(): `ck` is the dict or a path."""
         if not isinstance(self.optimiser, _FlatAdam):     # before anything is overwritten
             raise NotImplementedError("restore() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1)")
+        self.flush()
         if not isinstance(ck, dict):
             ck = torch.load(ck, map_location="cpu")
         if ck.get("version") != 1 or ck["config"] != bytes(self._cfg):
             raise RuntimeError("checkpoint does not match this Agent's configuration")
         with torch.no_grad():
-            self.params.copy_(ck["params"])
+            self._params.copy_(ck["params"])
             self.target_params.copy_(ck["target_params"])
             self.noise.copy_(ck["noise"])
             self.target_noise.copy_(ck["target_noise"])
-            st = self.optimiser.state[self.params]
+            st = self.optimiser.state[self._params]
             st["exp_avg"].copy_(ck["exp_avg"])
             st["exp_avg_sq"].copy_(ck["exp_avg_sq"])
             st["step"].fill_(ck["adam_step"])

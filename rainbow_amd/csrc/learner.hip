@@ -15,6 +15,7 @@
 // is the contract).  gemm_core.h + learner_problems.h remain the generic fallback for shapes the fast kernels refuse.
 #include "conv_lds.h"
 #include "noise_body.h"
+#include "adam_body.h"
 #include "learner_problems.h"
 #include "noisy_linear.h"
 #include "act_path.h"
@@ -208,9 +209,24 @@ struct rb_learner {
   int flags;                // RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS (rb_learner_set_flags)
   int dw_deferred;          // the last learn call computed the hidden layer's weight gradient for its norm only: the
                             // optimiser pass (rb_learner_clip_adam) recomputes the tiles while it streams the parameters
+  // RB_LEARNER_DEFER_UPDATE: rb_learner_train_step leaves its optimiser pass PENDING; the next train_step's sampler launch
+  // hosts it as extra workgroups (adam_body.h), every other entry point that touches parameters, moments, gradients or
+  // the norm runs it first as a launch of its own (flush_update)
+  ClipAdamArgs* adam_args_dev;   // the pending pass's arguments in device memory (rewritten only when they change)
+  ClipAdamArgs adam_args_host;   // ... and what that memory holds
+  int adam_args_valid, adam_pending, adam_blocks;
+  int32_t* status_copy;     // this learn call's batch_status, copied by its head kernel: the hosted pass shares a launch with
+                            // the NEXT call's sampler, which overwrites the replay header's word
   float gamma_n;        // float32(discount ** n)        agent.py:79
   float delta_z;        // float32((Vmax - Vmin)/(Z-1))   agent.py:19,82
 };
+
+static int flush_update(rb_learner* l, hipStream_t stream);
+#define RB_FLUSH_UPDATE(l, stream)                                  \
+  do {                                                              \
+    const int rcf_ = flush_update((l), (hipStream_t)(stream));      \
+    if (rcf_ != RB_OK) return rcf_;                                 \
+  } while (0)
 
 // ------------------------------------------------------------------------ noise --
 // f(x) = sign(x) * sqrt(|x|)  (model.py:32-34).  raw == NULL: N(0,1) from Philox + Box-Muller.
@@ -421,7 +437,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
                                                int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr,
-                                               const int32_t* batch_status) {
+                                               const int32_t* batch_status, int32_t* status_copy) {
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
   __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
@@ -470,7 +486,11 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   }
   if (t == 0) a_star_out[b] = a_star;
   // this learn call's optimiser step number (1-based); a batch the sampler gave up on does not count (no update follows)
-  if (step_ctr && b == 0 && t == 0 && !(batch_status && *batch_status != 0)) *step_ctr = *step_ctr + 1;
+  if (b == 0 && t == 0) {
+    const int32_t st = batch_status ? *batch_status : 0;
+    if (status_copy) *status_copy = st;
+    if (step_ctr && st == 0) *step_ctr = *step_ctr + 1;
+  }
 
   if (wave == 0) {
     // ---------------- target(next_states)[a*] probabilities      agent.py:75-76, projection inputs agent.py:79-86
@@ -660,47 +680,7 @@ __global__ __launch_bounds__(256) void k_clip_scale(float* g, int64_t n, const f
       g[i] *= coef;
 }
 
-// clip_grad_norm_ + Adam in ONE pass over the flat buffers (agent.py:97-98).  Every block re-sums the partial list in the
-// same fixed order (so all blocks agree on the clip coefficient) while its first parameter/gradient/moment loads are
-// already in flight, then applies torch.optim.Adam's single-tensor update:
-//   g' = g * clamp(max_norm / (norm + 1e-6), max=1)                       (clip_grad_norm_)
-//   m  = lerp(m, g', 1-b1);  v = v*b2 + (1-b2)*g'*g'
-//   p += -(lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
-// The scaled gradient is stored back only when the clip actually bites (the reference leaves .grad scaled).
-struct ClipAdamArgs {
-  float* p; float* g; float* m; float* v;
-  int64_t n;
-  const float* part; int nparts;
-  float max_norm; float* norm_out;
-  float w1, b2, w2, neg_step_size, bc2_sqrt, eps;
-  // hipGraph replay: the step number lives on the device (rb_learner_set_step_counter; incremented by the head kernel of
-  // every learn call), and the bias corrections 1 - beta^t are formed here, in double like the host path, by one thread
-  // per block — by-value scalars would freeze at capture time
-  const long long* step_dev;
-  double lr, beta1, beta2;
-  // FUSED: elements [skip_lo, skip_lo + skip_len) (the hidden layer's mu | sigma weight arrays) are not touched by the
-  // elementwise part: the tile part below updates them from gradients it recomputes on the fly
-  int64_t skip_lo4, skip_len4;        // in float4 units
-  // non-NULL and non-zero on the device: the batch behind this gradient was not a legal one (the sampler gave up; its
-  // importance weights are zero and so is the gradient) — the whole update is skipped instead of letting Adam's momentum
-  // move the parameters on a step the reference would never have taken
-  const int32_t* batch_status;
-};
-// (IEEE sqrt and divisions, as torch computes them: hardware rcp / approximate sqrt measured 1.5 us faster per launch
-// and stay far inside the test tolerance, but the update would no longer be the reference's formula rounding for rounding)
-__device__ __forceinline__ void rb_adam_elem(float& p, float& g, float& m, float& v, float coef, const ClipAdamArgs& a) {
-  g = g * coef;
-  m = fmaf(a.w1, g - m, m);
-  v = v * a.b2 + a.w2 * g * g;
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  p = p + a.neg_step_size * (m / denom);
-}
-__device__ __forceinline__ void rb_adam_quad(float4& P, float4& G, float4& M, float4& V, float coef, const ClipAdamArgs& a) {
-  rb_adam_elem(P.x, G.x, M.x, V.x, coef, a);
-  rb_adam_elem(P.y, G.y, M.y, V.y, coef, a);
-  rb_adam_elem(P.z, G.z, M.z, V.z, coef, a);
-  rb_adam_elem(P.w, G.w, M.w, V.w, coef, a);
-}
+// (ClipAdamArgs, rb_adam_elem / rb_adam_quad and the hosted form of the pass: adam_body.h)
 // Tile part of the fused optimiser pass (batch <= 32).  The hidden layer's weight gradient is a rank-B product,
 // g_mu = dY^T X  (dY [B][2H], X [B][F], both L2-resident: 0.5 MB), g_sigma = g_mu * (eps_out x eps_in).  Writing it in the
 // backward and reading it back here costs 2 x 25.7 MB of HBM traffic per step; instead a wave recomputes its 16 x 64
@@ -1405,6 +1385,8 @@ int rb_learner_destroy(rb_learner_t* l) {
   if (l->noise_ctr) rb_dev_free(l->noise_ctr);
   if (l->chain_ctr) rb_dev_free(l->chain_ctr);
   if (l->job_dev) rb_dev_free(l->job_dev);
+  if (l->status_copy) rb_dev_free(l->status_copy);
+  if (l->adam_args_dev) rb_dev_free(l->adam_args_dev);
   if (l->use_side) {
     for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
     for (int i = 0; i < 8; ++i) if (l->ev[i]) (void)hipEventDestroy(l->ev[i]);
@@ -1508,10 +1490,13 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->zero_noise, L.n_noise);
   RB_ALLOC(l->norm_part, 16384);
   RB_ALLOC(l->noise_ctr, 4);
+  RB_ALLOC(l->status_copy, 4);
+  RB_ALLOC(l->adam_args_dev, (sizeof(ClipAdamArgs) + 3) / 4);
   RB_ALLOC(l->chain_ctr, (int64_t)RB_CHAIN_ARRAYS * NI + 64);
 #undef RB_ALLOC
   RB_HIP_TRY(hipMemset(l->chain_ctr, 0, ((size_t)RB_CHAIN_ARRAYS * NI + 64) * 4));
   RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
+  RB_HIP_TRY(hipMemset(l->status_copy, 0, 16));
   {
     // measured on MI355X (gpurun_out/ab.log, round 1): cross-stream fork/join costs more than the overlap buys at
     // batch 32 (eager 357 -> 380 us, graph 364 -> 430 us), so the side streams are opt-in.
@@ -1552,6 +1537,7 @@ static NoiseJob make_noise_job(rb_learner* l, int which) {
   j.seed = l->seed; j.ctr = l->noise_ctr;
   j.nblk = (int)rb_div_up(j.map.seg_begin[8], 256); j.nets = which == 2 ? 2 : 1;
   j.dev = l->job_dev + which;
+  j.adam_dev = nullptr; j.adam_blocks = 0;
   return j;
 }
 // device copies of the three job variants (a hosting kernel reads them through NoiseJob::dev): at creation and whenever the
@@ -1629,6 +1615,7 @@ static int act_forward_single(rb_learner* l, const float* state_dev, const NetPt
 int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_dev, float* q_dev,
                    rb_stream_t stream) {
   RB_REQUIRE(l && state_dev, "rb_learner_act: NULL argument");
+  RB_FLUSH_UPDATE(l, stream);
   const Layout& L = l->L;
   ImgSrc src;
   memset(&src, 0, sizeof(src));
@@ -1672,6 +1659,7 @@ static int ensure_rows(rb_learner* l, int rows) {
 int rb_learner_act_batch(rb_learner_t* l, const float* states_dev, int32_t n, int32_t noisy, int32_t* actions_dev,
                          float* q_dev, rb_stream_t stream) {
   RB_REQUIRE(l && states_dev, "rb_learner_act_batch: NULL argument");
+  RB_FLUSH_UPDATE(l, stream);
   const Layout& L = l->L;
   RB_REQUIRE(n >= 1 && n <= 4096, "rb_learner_act_batch: n must be in [1, 4096]");
   {
@@ -1739,6 +1727,7 @@ int rb_learner_learn(rb_learner_t* l, const uint8_t* states_dev, const uint8_t* 
                      const float* weights_dev, float* loss_dev, rb_stream_t stream_) {
   RB_REQUIRE(l && states_dev && next_states_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev && loss_dev,
              "rb_learner_learn: NULL argument");
+  RB_FLUSH_UPDATE(l, stream_);
   ImgSrc src;
   memset(&src, 0, sizeof(src));
   src.u8_states = states_dev; src.u8_next = next_states_dev; src.B = l->L.B;
@@ -1750,6 +1739,7 @@ int rb_learner_learn_windows(rb_learner_t* l, const uint8_t* frames_dev, const i
                              const float* weights_dev, float* loss_dev, rb_stream_t stream_) {
   RB_REQUIRE(l && frames_dev && windows_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev && loss_dev,
              "rb_learner_learn_windows: NULL argument");
+  RB_FLUSH_UPDATE(l, stream_);
   RB_REQUIRE(window_len == l->L.hist + l->cfg.multi_step, "rb_learner_learn_windows: window_len must be history + multi_step");
   if (!l->fast_conv) {
     rb_set_error("rb_learner_learn_windows: zero-copy frames need the LDS conv kernels (history <= 4); gather the stacks and "
@@ -1774,7 +1764,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head, dim3((unsigned)B), dim3(RB_HEAD_THREADS), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status);
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status, l->status_copy);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
@@ -2001,21 +1991,59 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   return RB_OK;
 }
 
+static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                          double eps, int64_t step, float* norm_dev, hipStream_t stream, bool defer);
+
+// The pending optimiser pass (RB_LEARNER_DEFER_UPDATE) as a launch of its own: every entry point that reads or writes
+// parameters, moments, gradients or the norm calls this first — only the next rb_learner_train_step hosts it instead.
+static int flush_update(rb_learner* l, hipStream_t stream) {
+  if (!l->adam_pending) return RB_OK;
+  FusedDwAdamArgs f;
+  memset(&f, 0, sizeof(f));
+  RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3((unsigned)l->adam_blocks), dim3(256), stream, l->adam_args_host, f);
+  RB_LAUNCH_CHECK();
+  l->adam_pending = 0;
+  return RB_OK;
+}
+
+int rb_learner_flush(rb_learner_t* l, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_flush: NULL handle");
+  return flush_update(l, (hipStream_t)stream);
+}
+
 int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr && a != nullptr && a->replay != nullptr, "rb_learner_train_step: NULL argument");
+  // the previous call's optimiser pass, if it was left pending, rides in this call's sampler launch (adam_body.h)
+  rb_noise_job_t hosted_job;
+  const rb_noise_job_t* job = a->noise_job;
+  bool hosted = false;
+  if (l->adam_pending) {
+    if (job != nullptr && a->batch <= 256) {
+      memcpy(&hosted_job, job, sizeof(hosted_job));
+      NoiseJob* nj = reinterpret_cast<NoiseJob*>(&hosted_job);
+      nj->adam_dev = l->adam_args_dev; nj->adam_blocks = l->adam_blocks;
+      job = &hosted_job;
+      hosted = true;
+    } else {
+      const int rc = flush_update(l, (hipStream_t)stream);
+      if (rc != RB_OK) return rc;
+    }
+  }
   int rc = rb_replay_sample_fused_noise(a->replay, a->batch, a->priority_weight, nullptr, a->max_attempts, a->tree_idx_dev, nullptr,
                                         nullptr, a->actions_dev, a->returns_dev, a->nonterminals_dev, a->weights_dev,
-                                        a->noise_job, stream);
+                                        job, stream);
   if (rc != RB_OK) return rc;
+  if (hosted) l->adam_pending = 0;
   rc = rb_learner_learn_windows(l, a->frames_dev, a->windows_dev, a->window_len, a->actions_dev, a->returns_dev,
                                 a->nonterminals_dev, a->weights_dev, a->loss_dev, stream);
   if (rc != RB_OK) return rc;
-  return rb_learner_clip_adam(l, a->max_norm, a->exp_avg_dev, a->exp_avg_sq_dev, a->lr, a->beta1, a->beta2, a->eps, a->step,
-                              a->norm_dev, stream);
+  return clip_adam_impl(l, a->max_norm, a->exp_avg_dev, a->exp_avg_sq_dev, a->lr, a->beta1, a->beta2, a->eps, a->step,
+                        a->norm_dev, (hipStream_t)stream, (l->flags & RB_LEARNER_DEFER_UPDATE) != 0);
 }
 
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_clip_grad: NULL handle");
+  RB_FLUSH_UPDATE(l, stream);
   if (l->dw_deferred) {
     rb_set_error("rb_learner_clip_grad: the last learn call left the hidden layer's weight gradient to the fused optimiser "
                  "pass (RB_LEARNER_FUSE_FC_H_DW); call rb_learner_clip_adam, or clear the flag before learning");
@@ -2041,9 +2069,20 @@ int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_st
   return RB_OK;
 }
 
+__global__ void k_store_adam_args(ClipAdamArgs a, ClipAdamArgs* dst) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dst = a;
+}
+
 int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                          double beta2, double eps, int64_t step, float* norm_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_clip_adam: NULL handle");
+  const int rc = flush_update(l, (hipStream_t)stream);
+  if (rc != RB_OK) return rc;
+  return clip_adam_impl(l, max_norm, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, norm_dev, (hipStream_t)stream, false);
+}
+
+static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                          double eps, int64_t step, float* norm_dev, hipStream_t stream, bool defer) {
   RB_REQUIRE(exp_avg != nullptr && exp_avg_sq != nullptr, "rb_learner_clip_adam: NULL moment buffer");
   RB_REQUIRE(step >= 1 || (step == 0 && l->step_ctr), "rb_learner_clip_adam: step is 1-based (0 = take it from the device counter set "
              "with rb_learner_set_step_counter)");
@@ -2059,6 +2098,7 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
   }
   l->norm_slots = 0;   // consumed
   ClipAdamArgs a;
+  memset(&a, 0, sizeof(a));
   a.p = l->p_online; a.g = l->grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
   a.part = l->norm_part; a.nparts = nparts; a.max_norm = max_norm; a.norm_out = norm_dev;
   // scalars exactly as torch.optim.adam._single_tensor_adam forms them (python doubles, rounded once to f32 by the op)
@@ -2066,7 +2106,7 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
   a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2);
   a.neg_step_size = (float)(-(lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)eps;
   a.step_dev = step == 0 ? l->step_ctr : nullptr; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
-  a.batch_status = l->batch_status;
+  a.batch_status = l->status_copy;        // (k_head's copy of l->batch_status: see status_copy)
   const int64_t n4 = n >> 2;
   // 4 quadruples per thread: measured best of {2, 4, 8} on MI355X (254.3 / 255.6 / 256.6 us per step)
   // write-through stores: same-box A/B 253.7 -> 250.8 us per step (RB_ADAM_WT=0 restores plain stores)
@@ -2090,6 +2130,19 @@ int rb_learner_clip_adam(rb_learner_t* l, float max_norm, float* exp_avg, float*
     l->dw_deferred = 0;
   } else {
     const unsigned grid = (unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4);
+    if (defer && wt && a.step_dev != nullptr && a.nparts > 0 && l->adam_args_dev != nullptr) {
+      // left pending: the next train_step's sampler launch hosts these workgroups (or flush_update launches them).  The
+      // arguments are all step-invariant (the step number and the norm partials live on the device): uploaded on change only
+      if (!l->adam_args_valid || memcmp(&a, &l->adam_args_host, sizeof(a)) != 0) {
+        RB_LAUNCH(k_store_adam_args, dim3(1), dim3(64), stream, a, l->adam_args_dev);
+        RB_LAUNCH_CHECK();
+        memcpy(&l->adam_args_host, &a, sizeof(a));
+        l->adam_args_valid = 1;
+      }
+      l->adam_pending = 1;
+      l->adam_blocks = (int)grid;
+      return RB_OK;
+    }
     if (wt) { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3(grid), dim3(256), stream, a, f); }
     else { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false, false>), dim3(grid), dim3(256), stream, a, f); }
   }
@@ -2105,7 +2158,8 @@ int rb_learner_set_step_counter(rb_learner_t* l, int64_t* step_dev) {
 
 int rb_learner_set_flags(rb_learner_t* l, int32_t flags) {
   RB_REQUIRE(l != nullptr, "rb_learner_set_flags: NULL handle");
-  RB_REQUIRE((flags & ~(RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS)) == 0, "rb_learner_set_flags: unknown flag bits");
+  RB_REQUIRE((flags & ~(RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS | RB_LEARNER_DEFER_UPDATE)) == 0,
+             "rb_learner_set_flags: unknown flag bits");
   l->flags = flags;
   return RB_OK;
 }
@@ -2142,6 +2196,7 @@ int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream) {
 int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   RB_REQUIRE(l != nullptr, "rb_learner_finish_grads: NULL handle");
   RB_REQUIRE(l->exch_pending, "rb_learner_finish_grads: no learn call with a pending exchange");
+  RB_FLUSH_UPDATE(l, stream_);
   hipStream_t stream = (hipStream_t)stream_;
   const Layout& L = l->L;
   const NetPtrs on = net_ptrs(L, l->p_online, l->n_online);
@@ -2227,6 +2282,7 @@ int rb_learner_grads_modified(rb_learner_t* l) {
 
 int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_sync_target: NULL handle");
+  RB_FLUSH_UPDATE(l, stream);
   // load_state_dict copies parameters AND the epsilon buffers (agent.py:102-103)
   RB_HIP_TRY(hipMemcpyAsync(l->p_target, l->p_online, (size_t)l->L.n_params * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   RB_HIP_TRY(hipMemcpyAsync(l->n_target, l->n_online, (size_t)l->L.n_noise * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -2235,6 +2291,7 @@ int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream) {
 
 int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream) {
   RB_REQUIRE(l && out_dev, "rb_learner_debug_read: NULL argument");
+  RB_FLUSH_UPDATE(l, stream);
   const Layout& L = l->L;
   const void* src = nullptr;
   size_t bytes = 0;

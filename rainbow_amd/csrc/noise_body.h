@@ -62,4 +62,8 @@ struct NoiseJob {
   int nblk, nets;
   const NoiseJob* dev;    // device-resident copy of this struct: a hosting kernel takes this pointer (8 bytes of kernel
                           // arguments instead of 120) and reads the fields inside its noise branch only
+  // a second tenant for the same launch (adam_body.h): the previous learn call's deferred optimiser pass — device-resident
+  // ClipAdamArgs and the number of 256-thread workgroups it needs (0 = none).  Filled in by rb_learner_train_step only.
+  const void* adam_dev;
+  int adam_blocks;
 };

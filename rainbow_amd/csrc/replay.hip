@@ -14,6 +14,7 @@
 // gather moves (h+n)·7056 B in and 2h·7056 B out per sample with 16-byte lanes, the tree
 // search is L dependent 4-byte loads per sample.
 #include "noise_body.h"
+#include "adam_body.h"
 #include "replay_internal.h"
 
 #include <stdlib.h>
@@ -442,13 +443,24 @@ __device__ long long g_stamp[32];
 // MAXT = 256 for batches up to 256 (the learn step's shapes): the register budget of a 4-wave workgroup lets a thread hold
 // a six-level subtree; MAXT = 1024 (batches up to 1024) keeps to four levels per trip and 128 registers.  NO variant may
 // spill: a kernel with a scratch segment slowed every kernel of the step on MI355X (214 -> 283 us per step, measured).
-template <int MAXT>
+// AU = float4 quadruples per thread of the hosted optimiser workgroups (adam_body.h): they inherit this kernel's register
+// allocation, i.e. 2 waves per SIMD under the 256-thread variant's 205 VGPRs (needs AU = 8 to keep enough bytes in flight:
+// 42 us per hosted launch against 46 with AU = 4) and 4 under the 1024-thread variant's 127 (AU = 4)
+template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
                                                   const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
                                                   float* weights_out, const NoiseJob* job_dev, float* job_noise, float* job_noise2,
-                                                  unsigned long long* job_ctr, int32_t* fail_count, int32_t lds_top) {
+                                                  unsigned long long* job_ctr, int32_t* fail_count, int32_t lds_top,
+                                                  int32_t noise_blocks, const ClipAdamArgs* adam_dev) {
+  if ((int)blockIdx.x > noise_blocks) {
+    // co-tenant workgroups behind the noise ones: the previous learn call's optimiser pass (adam_body.h) — independent of
+    // this batch's sampling, and 30 us of pure streaming that now runs beside the sampler's serial chain, not before it
+    __shared__ float s_adam[16];
+    rb_adam_hosted_block<AU>(adam_dev, (int)blockIdx.x - 1 - noise_blocks, (int)gridDim.x - 1 - noise_blocks, s_adam);
+    return;
+  }
   if (blockIdx.x > 0) {   // co-tenant workgroups: the learner's noise resample (no dependency on the sampler)
     // the job's SCALARS are read here, from device memory: as a by-value kernel argument its 30 SGPRs were live across the
     // sampler path as well, 17 SGPRs spilled and the kernel carried a private segment (no kernel of the step may: DESIGN.md
@@ -895,17 +907,30 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
     RB_REQUIRE(job.noise && job.ctr && job.nblk > 0 && job.nets >= 1 && job.dev, "rb_replay_sample_fused_noise: empty noise job");
     blocks += (unsigned)(job.nblk * job.nets);
   }
+  const int noise_blocks = (int)blocks - 1;
+  const ClipAdamArgs* adam_dev = nullptr;
+  int host_mode = 0;
+  if (noise_job && job.adam_dev && job.adam_blocks > 0) {
+    RB_REQUIRE(threads == 256, "rb_replay_sample_fused_noise: the hosted optimiser pass needs a 256-thread sampler launch (batch <= 256)");
+    adam_dev = static_cast<const ClipAdamArgs*>(job.adam_dev);
+    // RB_ADAM_HOST=deep: the 256-thread sampler variant with 8 quadruples per hosted thread; default: the 1024-thread
+    // variant (four tree levels per trip, 127 VGPRs -> twice the resident waves) with 4 — job.adam_blocks counts blocks of
+    // 4 quadruples per thread
+    static const bool deep = getenv("RB_ADAM_HOST") && !strcmp(getenv("RB_ADAM_HOST"), "deep");
+    host_mode = deep ? 2 : 1;
+    blocks += (unsigned)(deep ? (job.adam_blocks + 1) / 2 : job.adam_blocks);
+  }
   // RB_SAMPLER=global searches without the LDS-staged tree top (A/B switch).  Measured on MI355X, back-to-back launches,
   // B = 32 / 1M leaves: 11.1 us (LDS top, 11 LDS steps + 2 trips) vs 11.6 (4 trips); n = 20 / 100k: 14.3 vs 16.1;
   // B = 256: 20.0 vs 24.4 — a trip costs ~1.3 us of ISSUE (62 loads + select chain), more than the staging it replaces.
   static const int lds_top = (getenv("RB_SAMPLER") && !strcmp(getenv("RB_SAMPLER"), "global")) ? 0 : 1;
-  if (threads <= 256) {
-    RB_LAUNCH_T("sample:k_sample", k_sample<256>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top);
+  if (threads <= 256 && host_mode != 1) {
+    RB_LAUNCH_T("sample:k_sample", (k_sample<256, 8>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
   } else {
     RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: batch > 256 supports history + multi_step <= 24");
-    RB_LAUNCH_T("sample:k_sample", k_sample<1024>, dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top);
+    RB_LAUNCH_T("sample:k_sample", (k_sample<1024, 4>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
   }
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {

@@ -279,55 +279,68 @@ def test_projection_known_answers(emu, monkeypatch):
     ad.close()
 
 
+def _ts_build(emu, name):
+    """A filled replay, a learner with a priority sink into it and the buffers of one rb_learner_train_step call."""
+    import ctypes as C
+    from cabi_adapter import CAbiReplayAdapter
+    from rainbow_amd import _lib as L
+    c = scenarios.LEARN_CONFIGS[name]
+    B, h, n = c["batch"], c["history"], c["multi_step"]
+    mem = NumpyMem()
+    rp = CAbiReplayAdapter(emu, mem, 512, h, n, c["discount"], 0.5)
+    rs = np.random.RandomState(5)
+    for _ in range(600):
+        rp.append(scenarios.synth_state(rs, h, 0), int(rs.randint(0, c["actions"])), float(rs.choice([-1.0, 0.0, 1.0])),
+                  bool(rs.random_sample() < 0.05))
+    ad = CAbiLearnAdapter(emu, mem, name)
+    cfg = O.Config(**c)
+    ad.load(O.init_params(cfg, 1), O.init_params(cfg, 2))
+    ad.reset_noise_online(rs.randn(O.noise_draw_count(cfg)).astype(np.float32))
+    out = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
+               nonterm=mem.empty((B,), np.float32), weights=mem.empty((B,), np.float32), loss=mem.empty((B,), np.float32),
+               norm=mem.empty((1,), np.float32))
+    L.check(emu, emu.rb_learner_set_priority_sink(ad.h, rp.h, mem.ptr(out["tree_idx"])))
+    job = L.NoiseJob()
+    L.check(emu, emu.rb_learner_noise_job(ad.h, 1, C.byref(job)))
+    return mem, rp, ad, out, job
+
+
+def _ts_snapshot(mem, rp, ad, out):
+    return dict(idx=mem.download(out["tree_idx"]).copy(), loss=mem.download(out["loss"]).copy(),
+                w=mem.download(out["weights"]).copy(), params=mem.download(ad.p_on).copy(),
+                m=mem.download(ad.adam_m).copy(), v=mem.download(ad.adam_v).copy(), noise=mem.download(ad.z_tg).copy(),
+                tree=rp.tree().copy(), norm=mem.download(out["norm"]).copy(), grads=mem.download(ad.grads).copy())
+
+
+def _ts_args(name, mem, rp, ad, o, job, beta, step):
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    hy = scenarios.LEARN_HYPER
+    return L.TrainStep(replay=rp.h, batch=scenarios.LEARN_CONFIGS[name]["batch"], max_attempts=64, window_len=rp.bufs.window_len,
+                       priority_weight=beta, tree_idx_dev=mem.ptr(o["tree_idx"]), actions_dev=mem.ptr(o["actions"]),
+                       returns_dev=mem.ptr(o["returns"]), nonterminals_dev=mem.ptr(o["nonterm"]), weights_dev=mem.ptr(o["weights"]),
+                       noise_job=C.addressof(job), frames_dev=rp.bufs.frames_dev, windows_dev=rp.bufs.window_dev,
+                       loss_dev=mem.ptr(o["loss"]), exp_avg_dev=mem.ptr(ad.adam_m), exp_avg_sq_dev=mem.ptr(ad.adam_v),
+                       norm_dev=mem.ptr(o["norm"]), lr=hy["lr"], beta1=0.9, beta2=0.999, eps=hy["adam_eps"], step=step,
+                       max_norm=hy["norm_clip"])
+
+
 def test_train_step_entry_point_equals_its_three_calls(emu):
     """rb_learner_train_step (what Agent.learn calls: sampler + noise tenant, zero-copy learn, clip + Adam, priority
     write-back through the sink) against the same three entry points issued one by one on a twin replay / twin learner:
     three consecutive steps, device RNG for the sampler and the noise, everything bit-identical — batch, loss, parameters,
     Adam moments, noise buffers and the sum-tree."""
     import ctypes as C
-    from cabi_adapter import CAbiReplayAdapter
     from rainbow_amd import _lib as L
     name = "dataeff"
     c = scenarios.LEARN_CONFIGS[name]
-    B, h, n = c["batch"], c["history"], c["multi_step"]
+    B = c["batch"]
     hy = scenarios.LEARN_HYPER
-
-    def build():
-        mem = NumpyMem()
-        rp = CAbiReplayAdapter(emu, mem, 512, h, n, c["discount"], 0.5)
-        rs = np.random.RandomState(5)
-        for _ in range(600):
-            rp.append(scenarios.synth_state(rs, h, 0), int(rs.randint(0, c["actions"])), float(rs.choice([-1.0, 0.0, 1.0])),
-                      bool(rs.random_sample() < 0.05))
-        ad = CAbiLearnAdapter(emu, mem, name)
-        cfg = O.Config(**c)
-        ad.load(O.init_params(cfg, 1), O.init_params(cfg, 2))
-        ad.reset_noise_online(rs.randn(O.noise_draw_count(cfg)).astype(np.float32))
-        out = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
-                   nonterm=mem.empty((B,), np.float32), weights=mem.empty((B,), np.float32), loss=mem.empty((B,), np.float32),
-                   norm=mem.empty((1,), np.float32))
-        L.check(emu, emu.rb_learner_set_priority_sink(ad.h, rp.h, mem.ptr(out["tree_idx"])))
-        job = L.NoiseJob()
-        L.check(emu, emu.rb_learner_noise_job(ad.h, 1, C.byref(job)))
-        return mem, rp, ad, out, job
-
-    def snapshot(mem, rp, ad, out):
-        return dict(idx=mem.download(out["tree_idx"]).copy(), loss=mem.download(out["loss"]).copy(),
-                    w=mem.download(out["weights"]).copy(), params=mem.download(ad.p_on).copy(),
-                    m=mem.download(ad.adam_m).copy(), v=mem.download(ad.adam_v).copy(), noise=mem.download(ad.z_tg).copy(),
-                    tree=rp.tree().copy(), norm=mem.download(out["norm"]).copy())
-
-    mem1, rp1, ad1, o1, job1 = build()
-    mem2, rp2, ad2, o2, job2 = build()
+    mem1, rp1, ad1, o1, job1 = _ts_build(emu, name)
+    mem2, rp2, ad2, o2, job2 = _ts_build(emu, name)
     for step in range(1, 4):
         beta = 0.4 + 0.1 * step
-        ts = L.TrainStep(replay=rp1.h, batch=B, max_attempts=64, window_len=rp1.bufs.window_len, priority_weight=beta,
-                         tree_idx_dev=mem1.ptr(o1["tree_idx"]), actions_dev=mem1.ptr(o1["actions"]), returns_dev=mem1.ptr(o1["returns"]),
-                         nonterminals_dev=mem1.ptr(o1["nonterm"]), weights_dev=mem1.ptr(o1["weights"]),
-                         noise_job=C.addressof(job1), frames_dev=rp1.bufs.frames_dev, windows_dev=rp1.bufs.window_dev,
-                         loss_dev=mem1.ptr(o1["loss"]), exp_avg_dev=mem1.ptr(ad1.adam_m), exp_avg_sq_dev=mem1.ptr(ad1.adam_v),
-                         norm_dev=mem1.ptr(o1["norm"]), lr=hy["lr"], beta1=0.9, beta2=0.999, eps=hy["adam_eps"], step=step,
-                         max_norm=hy["norm_clip"])
+        ts = _ts_args(name, mem1, rp1, ad1, o1, job1, beta, step)
         L.check(emu, emu.rb_learner_train_step(ad1.h, C.byref(ts), None))
         assert emu.rb_learner_priority_written(ad1.h) == 1
         # twin: the three entry points, one by one
@@ -339,12 +352,69 @@ def test_train_step_entry_point_equals_its_three_calls(emu):
                                                   mem2.ptr(o2["weights"]), mem2.ptr(o2["loss"]), None))
         L.check(emu, emu.rb_learner_clip_adam(ad2.h, hy["norm_clip"], mem2.ptr(ad2.adam_m), mem2.ptr(ad2.adam_v), hy["lr"], 0.9,
                                               0.999, hy["adam_eps"], step, mem2.ptr(o2["norm"]), None))
-        a, b = snapshot(mem1, rp1, ad1, o1), snapshot(mem2, rp2, ad2, o2)
+        a, b = _ts_snapshot(mem1, rp1, ad1, o1), _ts_snapshot(mem2, rp2, ad2, o2)
         for k in a:
             assert np.array_equal(a[k], b[k]), (step, k)
         assert rp1.raw_header().last_status == 0
     assert not np.array_equal(a["params"], ad1._flat(O.init_params(O.Config(**c), 1))), "the online net must have moved"
     ad1.close(); ad2.close(); rp1.close(); rp2.close()
+
+
+def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
+    """RB_LEARNER_DEFER_UPDATE: rb_learner_train_step leaves clip + Adam (agent.py:97-98) pending and the NEXT train_step's
+    sampler launch carries it as extra workgroups (adam_body.h).  Against a twin without the flag, five steps with the
+    device-resident step number: after every train_step the deferred handle's parameters are exactly ONE update behind;
+    rb_learner_act (any entry point that reads parameters) runs the pending pass first and returns the twin's action; after
+    rb_learner_flush everything — parameters, both moments, the stored gradient, the norm, the sum-tree, the sampled
+    batches along the way — is bit-identical."""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    name = "dataeff"
+    c = scenarios.LEARN_CONFIGS[name]
+    h1 = _ts_build(emu, name)
+    h2 = _ts_build(emu, name)
+    ctrs = []
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ctr = mem.upload(np.zeros(1, np.int64))
+        L.check(emu, emu.rb_learner_set_step_counter(ad.h, mem.ptr(ctr)))
+        ctrs.append(ctr)
+    L.check(emu, emu.rb_learner_set_flags(h1[2].h, L.LEARNER_DEFER_UPDATE))
+    state = h1[0].upload(scenarios.synth_state(np.random.RandomState(9), c["history"], 0).astype(np.float32) / 255.0)
+    state2 = h2[0].upload(h1[0].download(state).copy())
+    prev_twin = None
+    for step in range(1, 6):
+        beta = 0.4 + 0.05 * step
+        snaps = []
+        for (mem, rp, ad, o, job) in (h1, h2):
+            ts = _ts_args(name, mem, rp, ad, o, job, beta, 0)
+            L.check(emu, emu.rb_learner_train_step(ad.h, C.byref(ts), None))
+            snaps.append(_ts_snapshot(mem, rp, ad, o))
+        a, b = snaps
+        for k in ("idx", "loss", "w", "noise", "tree"):             # the step itself never waits for the pending pass' results
+            assert np.array_equal(a[k], b[k]), (step, k)            # ... because it has run by then (same launch as the sampler)
+        if prev_twin is not None:                                   # one update behind, exactly
+            for k in ("params", "m", "v"):
+                assert np.array_equal(a[k], prev_twin[k]), (step, k)
+        assert not np.array_equal(a["params"], b["params"])
+        if step == 3:     # a reader of the parameters in between: the pending pass runs first, as a launch of its own
+            outs = []
+            for (mem, rp, ad, o, job), st in ((h1, state), (h2, state2)):
+                act, q = mem.empty((1,), np.int32), mem.empty((1,), np.float32)
+                L.check(emu, emu.rb_learner_act(ad.h, mem.ptr(st), 1, mem.ptr(act), mem.ptr(q), None))
+                outs.append((int(mem.download(act)[0]), float(mem.download(q)[0])))
+            assert outs[0] == outs[1]
+            a = _ts_snapshot(*h1[:4])
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (step, k)
+        prev_twin = b
+    L.check(emu, emu.rb_learner_flush(h1[2].h, None))
+    L.check(emu, emu.rb_learner_flush(h1[2].h, None))               # idempotent
+    a, b = _ts_snapshot(*h1[:4]), _ts_snapshot(*h2[:4])
+    for k in a:
+        assert np.array_equal(a[k], b[k]), ("final", k)
+    assert int(h1[0].download(ctrs[0])[0]) == 5 and int(h2[0].download(ctrs[1])[0]) == 5
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ad.close(); rp.close()
 
 
 def test_sync_target_copies_parameters_and_noise(emu):

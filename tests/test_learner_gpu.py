@@ -427,6 +427,74 @@ def test_batched_evaluation_of_validation_memory(hip):
     assert qs.shape == (cap,) and np.all(np.isfinite(qs))
 
 
+def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch):
+    """RAINBOW_AMD_DEFER_UPDATE (default on): Agent.learn leaves clip + Adam pending and the next learn's sampler launch
+    hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE).  Against an agent with the switch off (same device-resident
+    step number): 8 steps with acting, a target sync and a state_dict() in between — per-step losses, actions, parameters,
+    target parameters, Adam moments, the norm and the sum-tree bit-identical; the deferred agent really deferred."""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+    args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
+    env = types.SimpleNamespace(action_space=lambda: 4)
+
+    def fresh(defer):
+        monkeypatch.setenv("RAINBOW_AMD_DEFER_UPDATE", defer)
+        torch.manual_seed(77)
+        np.random.seed(77)
+        agent = Agent(args, env)
+        if agent._step_dev is None:      # the twin forms its bias corrections on the device as well
+            agent._step_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+            L.check(agent._lib, agent._lib.rb_learner_set_step_counter(agent._h, agent._step_dev.data_ptr()))
+        mem = ReplayMemory(args, 2048, seed=5)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        rs = np.random.RandomState(3)
+        for _ in range(2):
+            mem.append_batch(torch.randint(0, 256, (1500, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
+                             rs.randint(0, 4, 1500), rs.choice([-1.0, 0.0, 1.0], size=1500), rs.random_sample(1500) < 0.01)
+        return agent, mem
+
+    def run(agent, mem):
+        g = torch.Generator(device="cuda").manual_seed(11)
+        trace, pend = [], []
+        for k in range(8):
+            mem.priority_weight = min(1.0, 0.4 + 0.05 * k)
+            agent.reset_noise()
+            agent.learn(mem)
+            pend.append(bool(agent._update_pending))
+            trace.append(agent._loss.clone())
+            if k in (2, 3):
+                st = torch.rand(4, 84, 84, device="cuda", generator=g)
+                trace.append(torch.tensor([float(agent.act(st)), agent.evaluate_q(st)], device="cuda"))
+            if k == 4:
+                agent.update_target_net()
+            if k == 5:
+                trace.append(agent.state_dict()["fc_h_v.weight_mu"].flatten()[:64].clone())
+            if k == 6:
+                trace.append(agent._norm.clone())
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in trace], pend
+
+    a1, m1 = fresh("1")
+    a2, m2 = fresh("0")
+    assert a1._defer_update and not a2._defer_update
+    t1, p1 = run(a1, m1)
+    t2, p2 = run(a2, m2)
+    assert all(p1) and not any(p2)
+    assert len(t1) == len(t2)
+    for i, (x, y) in enumerate(zip(t1, t2)):
+        assert np.array_equal(x, y), i
+    assert a1._update_pending                                        # ... and the accessors below run it
+    assert torch.equal(a1.params.detach(), a2.params.detach()) and torch.equal(a1.target_params, a2.target_params)
+    assert not a1._update_pending
+    s1, s2 = a1.optimiser.state[a1.params], a2.optimiser.state[a2.params]
+    assert torch.equal(s1["exp_avg"], s2["exp_avg"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
+    assert torch.equal(a1.grads, a2.grads) and torch.equal(a1._norm, a2._norm)
+    assert int(a1._step_dev.item()) == int(a2._step_dev.item()) == 8
+    assert np.array_equal(m1._grab("tree"), m2._grab("tree"))
+
+
 def test_checkpoint_restore_resumes_bit_exactly(hip, tmp_path):
     """SURVEY 8f row 3 'exact resume': run 6 steps, checkpoint agent + replay after step 3, restore both into FRESH
     objects and run steps 4-6 again: parameters, Adam moments, noise, per-sample losses and the sum-tree must come out

@@ -13,8 +13,9 @@ python - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/gaps/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# the timed region: the last 60 k_clip_adam launches delimit steps
-idx = [i for i, r in enumerate(rows) if "k_clip_adam" in r["Kernel_Name"]]
+# the timed region: the last 40 k_head launches delimit steps (one per learn call; the optimiser pass may be hosted by the
+# sampler launch, RB_LEARNER_DEFER_UPDATE, so k_clip_adam is not a per-step launch any more)
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_head(")]
 lo, hi = idx[-41], idx[-1]
 dur = collections.defaultdict(list); gap = collections.defaultdict(list)
 for i in range(lo + 1, hi + 1):

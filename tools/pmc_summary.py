@@ -54,6 +54,8 @@ def main():
         tag = tag_of(key[0], key[1], biggest)
         if tag is None or len(fetch[key]) < 5:
             continue
+        if tag in res and res[tag]["grid_size"] > key[1]:
+            continue      # e.g. "sample": the learn step's launch (it hosts the optimiser pass) over the PER-only phase's
         f = sum(fetch[key]) / len(fetch[key])
         w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
         res[tag] = {"kernel": key[0].split("(")[0][:80], "grid_size": key[1], "launches": len(fetch[key]), "FETCH_SIZE_KiB": f,
