@@ -352,6 +352,17 @@ int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t
 int rb_learner_set_flags(rb_learner_t* l, int32_t flags);
 /* Run the pending optimiser pass, if any (RB_LEARNER_DEFER_UPDATE), on `stream`.  No-op otherwise.                    */
 int rb_learner_flush(rb_learner_t* l, rb_stream_t stream);
+/* The same deferral for a caller that issues a step's entry points one by one (rainbow_amd.Agent's eager path; the replica
+ * exchange of SURVEY 8(e), where finish_grads sits between the backward and the optimiser pass, agent.py:96-97):
+ *   rb_learner_clip_adam_deferred = rb_learner_clip_adam, but the pass is left pending when the flag is set and it can be
+ *     (step = 0 with a device step counter; otherwise it runs at once);
+ *   rb_learner_attach_pending(l, job_in, batch, job_out): job_out = job_in (from rb_learner_noise_job) plus the pending pass;
+ *     returns 1 if one was attached, 0 if job_out is a plain copy, < 0 on error.  Pass job_out to
+ *     rb_replay_sample_fused_noise, then call rb_learner_pending_launched(l).  No other call on the handle in between.  */
+int rb_learner_clip_adam_deferred(rb_learner_t* l, float max_norm, float* exp_avg_dev, float* exp_avg_sq_dev, double lr,
+                                  double beta1, double beta2, double eps, int64_t step, float* norm_dev, rb_stream_t stream);
+int rb_learner_attach_pending(rb_learner_t* l, const rb_noise_job_t* job_in, int32_t batch, rb_noise_job_t* job_out);
+int rb_learner_pending_launched(rb_learner_t* l);
 
 /* hipGraph replay with the fused optimiser pass: a captured launch cannot take a new `step` by value.  With a counter set
  * (caller-owned i64 on the device), every rb_learner_learn* increments it on the device, and rb_learner_clip_adam called

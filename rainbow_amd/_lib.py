@@ -104,6 +104,10 @@ SIGNATURES = {
     "rb_learner_clip_grad": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rb_learner_clip_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                      c_int64, c_void_p, c_void_p]),
+    "rb_learner_clip_adam_deferred": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
+                                              c_int64, c_void_p, c_void_p]),
+    "rb_learner_attach_pending": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "rb_learner_pending_launched": (c_int, [c_void_p]),
     "rb_learner_train_step": (c_int, [c_void_p, C.POINTER(TrainStep), c_void_p]),
     "rb_learner_set_flags": (c_int, [c_void_p, c_int32]),
     "rb_learner_flush": (c_int, [c_void_p, c_void_p]),

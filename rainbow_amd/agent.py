@@ -107,7 +107,7 @@ class _FlatAdam(torch.optim.Adam):
         self.step_direct(max_norm)
         return loss
 
-    def step_direct(self, max_norm=float("inf"), stream=None):
+    def step_direct(self, max_norm=float("inf"), stream=None, defer=False):
         """What step() does, callable without torch.optim's step wrapper (profiler record + hook dispatch: ~20 us per call,
         a tenth of a batch-32 learn step's host time).  Agent.learn uses this; step() stays for API compatibility."""
         ag = self._agent()
@@ -122,7 +122,8 @@ class _FlatAdam(torch.optim.Adam):
         # device-resident step counter (hipGraph replay): step = 0 tells the kernel to read it and form the bias
         # corrections itself; the host copy above only mirrors it (Agent._sync_step refreshes it after replays)
         step = 0 if ag._step_dev is not None else int(st["step"].item())
-        rc = ag._lib.rb_learner_clip_adam(
+        fn = ag._lib.rb_learner_clip_adam_deferred if defer else ag._lib.rb_learner_clip_adam
+        rc = fn(
             ag._h, float(max_norm), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1),
             float(b2), float(g["eps"]), step,
             ag._norm_buf.data_ptr() if math.isfinite(max_norm) else None, ag._stream() if stream is None else stream)
@@ -155,6 +156,7 @@ class Agent:
                                     v_min=float(args.V_min), v_max=float(args.V_max), discount=float(args.discount))
         self._defer_update = False
         self._update_pending = False
+        self._hosted_job = L.NoiseJob()
         n_params, n_noise = C.c_int64(0), C.c_int64(0)
         L.check(self._lib, self._lib.rb_learner_sizes(C.byref(self._cfg), C.byref(n_params), C.byref(n_noise)))
         self._layout = _query_layout(self._lib, self._cfg, self._lib.rb_learner_param_layout)
@@ -201,13 +203,12 @@ class Agent:
             except (TypeError, RuntimeError):
                 self.optimiser = torch.optim.Adam([self._params], **kw)
         else:
-            # RAINBOW_AMD_DEFER_UPDATE (default on; eager one-call path only): learn() leaves its clip + Adam pass pending
+            # RAINBOW_AMD_DEFER_UPDATE (default on; not under graph replay): learn() leaves its clip + Adam pass pending
             # and the NEXT learn()'s sampler launch hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE) — anything
             # else that touches the parameters runs it first (the library's entry points do so themselves; the public
             # tensors `params`, `grads`, `_norm` and the optimiser state go through flush()).  Needs the device-resident
             # step number, like graph replay.
-            self._defer_update = (os.environ.get("RAINBOW_AMD_DEFER_UPDATE", "1") == "1" and not self._use_graph
-                                  and rdist.world_size() == 1)
+            self._defer_update = os.environ.get("RAINBOW_AMD_DEFER_UPDATE", "1") == "1" and not self._use_graph
             if self._use_graph or self._defer_update:
                 self._step_dev = torch.zeros(1, dtype=torch.int64, device=d)
                 L.check(self._lib, self._lib.rb_learner_set_step_counter(self._h, self._step_dev.data_ptr()))
@@ -249,7 +250,7 @@ class Agent:
         # reference does.
         self._fused_dw = (isinstance(self.optimiser, _FlatAdam) and not self._dist
                           and os.environ.get("RAINBOW_AMD_FUSED_DW", "0") == "1")
-        if self._fused_dw or self._dist:
+        if self._fused_dw:
             self._defer_update = False
         L.check(self._lib, self._lib.rb_learner_set_flags(
             self._h, (L.LEARNER_FUSE_FC_H_DW if self._fused_dw else 0) | (L.LEARNER_DEFER_UPDATE if self._defer_update else 0)))
@@ -532,7 +533,17 @@ class Agent:
                 L.check(self._lib, self._lib.rb_learner_noise_job(self._h, which, C.byref(noise_job)))
                 self._noise_jobs[which] = noise_job
         if device_mem:
-            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy, noise_job=noise_job, stream=stream)   # agent.py:63
+            hosted = 0
+            if noise_job is not None and self._update_pending:
+                # the previous call's clip + Adam pass rides in this sampler launch (RB_LEARNER_DEFER_UPDATE)
+                hosted = self._lib.rb_learner_attach_pending(self._h, C.byref(noise_job), B, C.byref(self._hosted_job))
+                if hosted < 0:
+                    L.check(self._lib, hosted)
+            o = mem.sample_device(B, _unit_uniforms, gather=not zero_copy,
+                                  noise_job=self._hosted_job if hosted == 1 else noise_job, stream=stream)   # agent.py:63
+            if hosted == 1:
+                L.check(self._lib, self._lib.rb_learner_pending_launched(self._h))
+                self._update_pending = False
             idxs, states, next_states = o["tree_idxs"], o["states"], o["next_states"]
             actions, returns, nonterminals, weights = o["actions"], o["returns"], o["nonterminals"], o["weights"]
         else:   # foreign replay with the reference's API: float32 /255 states come back; re-quantise (exact for k/255)
@@ -590,7 +601,10 @@ class Agent:
             rdist.average_gradients(self._grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         if isinstance(self.optimiser, _FlatAdam):
-            self.optimiser.step_direct(float(self.norm_clip), stream)                      # agent.py:97-98, one pass
+            defer = self._defer_update and device_mem and not overlap
+            self.optimiser.step_direct(float(self.norm_clip), stream, defer=defer)         # agent.py:97-98, one pass
+            if defer:
+                self._update_pending = True      # (the library decides; flush() is a no-op when it ran at once)
         else:
             L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm_buf.data_ptr(),
                                                               stream))                    # agent.py:97

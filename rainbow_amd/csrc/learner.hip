@@ -2011,6 +2011,33 @@ int rb_learner_flush(rb_learner_t* l, rb_stream_t stream) {
   return flush_update(l, (hipStream_t)stream);
 }
 
+// The same hosting for a caller that issues the step's entry points one by one (Agent's eager path, the replica exchange):
+// attach fills `job_out` = `job_in` + the pending pass (returns 1) or leaves it a plain copy (0); the caller passes job_out
+// to rb_replay_sample_fused_noise and, once that launch is in the stream, calls rb_learner_pending_launched.
+int rb_learner_attach_pending(rb_learner_t* l, const rb_noise_job_t* job_in, int32_t batch, rb_noise_job_t* job_out) {
+  if (!l || !job_in || !job_out) { rb_set_error("rb_learner_attach_pending: NULL argument"); return RB_ERR_INVALID; }
+  memcpy(job_out, job_in, sizeof(*job_out));
+  if (!l->adam_pending || batch > 256) return 0;
+  NoiseJob* nj = reinterpret_cast<NoiseJob*>(job_out);
+  nj->adam_dev = l->adam_args_dev; nj->adam_blocks = l->adam_blocks;
+  return 1;
+}
+int rb_learner_pending_launched(rb_learner_t* l) {
+  RB_REQUIRE(l != nullptr, "rb_learner_pending_launched: NULL handle");
+  l->adam_pending = 0;
+  return RB_OK;
+}
+// rb_learner_clip_adam that leaves the pass pending when the handle's flags say so (RB_LEARNER_DEFER_UPDATE) and it can
+// (step = 0 with a device step counter, norm partials from the learn call); otherwise exactly rb_learner_clip_adam.
+int rb_learner_clip_adam_deferred(rb_learner_t* l, float max_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                                  double beta2, double eps, int64_t step, float* norm_dev, rb_stream_t stream) {
+  RB_REQUIRE(l != nullptr, "rb_learner_clip_adam_deferred: NULL handle");
+  const int rc = flush_update(l, (hipStream_t)stream);
+  if (rc != RB_OK) return rc;
+  return clip_adam_impl(l, max_norm, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, norm_dev, (hipStream_t)stream,
+                        (l->flags & RB_LEARNER_DEFER_UPDATE) != 0);
+}
+
 int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr && a != nullptr && a->replay != nullptr, "rb_learner_train_step: NULL argument");
   // the previous call's optimiser pass, if it was left pending, rides in this call's sampler launch (adam_body.h)

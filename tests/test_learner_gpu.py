@@ -427,7 +427,8 @@ def test_batched_evaluation_of_validation_memory(hip):
     assert qs.shape == (cap,) and np.all(np.isfinite(qs))
 
 
-def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch):
+@pytest.mark.parametrize("one_call", ["1", "0"], ids=["train_step", "three-calls"])
+def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch, one_call):
     """RAINBOW_AMD_DEFER_UPDATE (default on): Agent.learn leaves clip + Adam pending and the next learn's sampler launch
     hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE).  Against an agent with the switch off (same device-resident
     step number): 8 steps with acting, a target sync and a state_dict() in between — per-step losses, actions, parameters,
@@ -441,6 +442,9 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
 
     def fresh(defer):
         monkeypatch.setenv("RAINBOW_AMD_DEFER_UPDATE", defer)
+        # the deferring agent through rb_learner_train_step or through the step's entry points one by one
+        # (rb_learner_attach_pending / rb_learner_clip_adam_deferred: the path the replica exchange uses as well)
+        monkeypatch.setenv("RAINBOW_AMD_ONE_CALL", one_call if defer == "1" else "1")
         torch.manual_seed(77)
         np.random.seed(77)
         agent = Agent(args, env)

@@ -11,7 +11,7 @@ python - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/d1trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_clip_adam" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_head(")]
 lo, hi = idx[-41], idx[-1]
 dur = collections.defaultdict(list); gap = collections.defaultdict(list); order = []
 for i in range(lo + 1, hi + 1):
