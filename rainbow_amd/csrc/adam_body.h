@@ -55,12 +55,19 @@ __device__ __forceinline__ void rb_adam_quad(float4& P, float4& G, float4& M, fl
 // pointers — every access goes through a buffer descriptor instead (no flat instructions; 32-bit byte offsets: the caller
 // guarantees 4 n < 2^31).  Requires a.step_dev (the step number cannot be a launch-time scalar here).
 template <int UNROLL>
-__device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int eb, int nblk, float* s_red16) {
+__device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int eb, int nblk, float* s_red16 /* [18] */) {
   ClipAdamArgs a = *ad;
   const unsigned T = blockDim.x;
   const unsigned n4 = (unsigned)(a.n >> 2);
   const unsigned base = (unsigned)eb * (T * UNROLL) + threadIdx.x;
   const rb_buf bp = rb_make_buf(a.p), bg = rb_make_buf(a.g), bm = rb_make_buf(a.m), bv = rb_make_buf(a.v);
+  // the step number first (one lane): its bias corrections — two double pow — are formed while the block's parameter loads
+  // are in flight, not behind the norm's barrier
+  unsigned st_lo = 0, st_hi = 0;
+  if (threadIdx.x == 0) {
+    const rb_buf bs = rb_make_buf(a.step_dev);
+    st_lo = __builtin_bit_cast(unsigned, rb_ld1_buf(bs, 0, 0)); st_hi = __builtin_bit_cast(unsigned, rb_ld1_buf(bs, 4, 0));
+  }
   float4 P[UNROLL], G[UNROLL], M[UNROLL], V[UNROLL];
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
@@ -75,26 +82,33 @@ __device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int
   }
   float acc = 0.0f;
   {
+    // 16 partials in flight per trip, added in index order (a loop of single loads is one L2 round trip per iteration)
     const rb_buf bpart = rb_make_buf(a.part);
-    for (int i = (int)threadIdx.x; i < a.nparts; i += (int)T) acc += rb_ld1_buf(bpart, 4u * (unsigned)i, 0);
+    for (int i0 = (int)threadIdx.x; i0 < a.nparts; i0 += 16 * (int)T) {
+      float pv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = i0 + u * (int)T;
+        pv[u] = rb_ld1_buf(bpart, 4u * (unsigned)(i < a.nparts ? i : a.nparts - 1), 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (i0 + u * (int)T < a.nparts) acc += pv[u];
+    }
+  }
+  if (threadIdx.x == 0) {
+    const double t = (double)(long long)(((unsigned long long)st_hi << 32) | st_lo);
+    const double bc1 = 1.0 - pow(a.beta1, t), bc2 = 1.0 - pow(a.beta2, t);
+    s_red16[16] = (float)(-(a.lr / bc1));
+    s_red16[17] = (float)sqrt(bc2);
   }
   acc = rb_block_sum(acc, s_red16);
   const float total = sqrtf(acc);
   float coef = a.max_norm / (total + 1e-6f);
   if (coef > 1.0f) coef = 1.0f;                                    // clamp(max=1.0)
   if (eb == 0 && threadIdx.x == 0 && a.norm_out) rb_st1_wt(a.norm_out, 0, total);
-  __syncthreads();                                                 // s_red16 is reused below
-  if (threadIdx.x == 0) {
-    const rb_buf bs = rb_make_buf(a.step_dev);
-    const unsigned lo = __builtin_bit_cast(unsigned, rb_ld1_buf(bs, 0, 0)), hi = __builtin_bit_cast(unsigned, rb_ld1_buf(bs, 4, 0));
-    const double t = (double)(long long)(((unsigned long long)hi << 32) | lo);
-    const double bc1 = 1.0 - pow(a.beta1, t), bc2 = 1.0 - pow(a.beta2, t);
-    s_red16[0] = (float)(-(a.lr / bc1));
-    s_red16[1] = (float)sqrt(bc2);
-  }
-  __syncthreads();
-  a.neg_step_size = s_red16[0];
-  a.bc2_sqrt = s_red16[1];
+  a.neg_step_size = s_red16[16];                                   // (written before rb_block_sum's barriers)
+  a.bc2_sqrt = s_red16[17];
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const unsigned i = base + u * T;

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
   if ((int)blockIdx.x > noise_blocks) {
     // co-tenant workgroups behind the noise ones: the previous learn call's optimiser pass (adam_body.h) — independent of
     // this batch's sampling, and 30 us of pure streaming that now runs beside the sampler's serial chain, not before it
-    __shared__ float s_adam[16];
+    __shared__ float s_adam[18];
     rb_adam_hosted_block<AU>(adam_dev, (int)blockIdx.x - 1 - noise_blocks, (int)gridDim.x - 1 - noise_blocks, s_adam);
     return;
   }
