@@ -153,6 +153,7 @@ struct rb_learner {
   float *feat_b, *h_b;  // k-blocked copies of feat [NI][F] and h [NI][2H] for the streamed forward kernels
   float* logits;        // [NI][NZ]
   float* dlogits;       // [B][NZ]
+  float* dlogitsT;      // [NZ][B] (RB_Z_DYT=0: not written)
   float* dh;            // [B][2H]
   float* dhT;           // [2H][B]: the same, transposed (the hidden layer's input gradient reads its dY operand from it)
   float* dfeat_part;    // [xs][B][F]
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
                                                int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr,
-                                               const int32_t* batch_status, int32_t* status_copy) {
+                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT) {
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
   __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
@@ -580,6 +581,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     if (i < Z) o = g;
     else o = ((i - Z) / Z == act ? g : 0.0f) - g / (float)A;
     dl[i] = o;
+    if (dlogitsT) dlogitsT[(int64_t)i * B + b] = o;      // [NZ][B]: the output layer's input gradient reads 16 consecutive samples of a row
   }
   RB_WGT(7, b, 6);
 }
@@ -1377,7 +1379,7 @@ int64_t rb_learner_noise_draws(const rb_learner_config_t* cfg) {
 int rb_learner_destroy(rb_learner_t* l) {
   if (!l) return RB_OK;
   float** owned[] = {&l->feat_b, &l->h_b, &l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
-                     &l->logits, &l->dlogits, &l->dh, &l->dhT, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
+                     &l->logits, &l->dlogits, &l->dlogitsT, &l->dh, &l->dhT, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
                      &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
   for (float** p : owned)
     if (*p) rb_dev_free(*p);
@@ -1479,6 +1481,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->h_b, (int64_t)NI * (2 * L.H + 16));
   RB_ALLOC(l->logits, (int64_t)NI * L.NZ);
   RB_ALLOC(l->dlogits, (int64_t)B * L.NZ);
+  if (!(getenv("RB_Z_DYT") && getenv("RB_Z_DYT")[0] == '0')) RB_ALLOC(l->dlogitsT, (int64_t)B * L.NZ);
   RB_ALLOC(l->dh, (int64_t)B * 2 * L.H);
   RB_ALLOC(l->dhT, (int64_t)B * 2 * L.H);
   RB_ALLOC(l->dfeat_part, (int64_t)l->xs * B * L.F);
@@ -1764,7 +1767,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head, dim3((unsigned)B), dim3(RB_HEAD_THREADS), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
             nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status, l->status_copy);
+            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status, l->status_copy, l->dlogitsT);
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
@@ -1823,7 +1826,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
     zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
     static const bool dyt_off = getenv("RB_DX_DYT") && getenv("RB_DX_DYT")[0] == '0';          // A/B switch
-    zx.dyT = nullptr; zx.ldyT = 0; zx.outT = dyt_off ? nullptr : l->dhT;
+    zx.dyT = l->dlogitsT; zx.ldyT = B; zx.outT = dyt_off ? nullptr : l->dhT;
     NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
     // ---- hidden layer
     NlDxArgs hx;
