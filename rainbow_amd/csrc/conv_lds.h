@@ -1022,11 +1022,16 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   // covers input rows no output touches when (OH-1)*S + KS < IH)
   constexpr int PAD = TMAX - 1, PADH = (G::IH + G::S - 1) / G::S - G::OH, PW = G::OH + PAD + PADH, PP = PW * PW;
   constexpr int RED = RB_CONV_WAVES * NT * 16 * 64;
-  constexpr int OPS = KPAD * 33 + COUT * PP;
+  // row stride of the [k'][c] weight slab.  The MFMA operand read (32 consecutive c of a row) is conflict-free at any stride;
+  // the stride-1 staging stores are not: a thread holds 4 consecutive elements of a (c, tap) run, lanes 4 elements apart, and
+  // with 33 the bank is (tap + c) mod 32 — 8.8 lanes per bank on average (SQ_LDS_BANK_CONFLICT: 61 % of the kernel's LDS
+  // cycles); 38 spreads them to 2.0 per bank
+  constexpr int WLD = (G::S == 1 && G::KK == 9) ? 38 : 33;
+  constexpr int OPS = KPAD * WLD + COUT * PP;
   constexpr int WSZ = MULTI ? OPS + RED : (OPS > RED ? OPS : RED);
   __shared__ __attribute__((aligned(16))) float s_all[WSZ];
   float* s_w = s_all;
-  float* s_dy = s_all + KPAD * 33;
+  float* s_dy = s_all + KPAD * WLD;
   float* s_red = MULTI ? s_all + OPS : s_all;
   __shared__ int s_koff[KPAD];      // co*PP - ty*PW - tx
 
@@ -1186,13 +1191,13 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
           if (co < a.cout) {
             const float vv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
             int m = (4 * f) / G::KK, tap = 4 * f - m * G::KK;                   // one division per quad, then carry
-            int adr = (co * G::KK + tap) * 33 + m;                              // phase 0 of stride 1: tap index == (ty, tx)
+            int adr = (co * G::KK + tap) * WLD + m;                              // phase 0 of stride 1: tap index == (ty, tx)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               s_w[adr] = vv[e];
               ++tap;
               const bool wrap = tap == G::KK;
-              adr += wrap ? 1 - (G::KK - 1) * 33 : 33;                          // next tap of this channel, or tap 0 of the next one
+              adr += wrap ? 1 - (G::KK - 1) * WLD : WLD;                          // next tap of this channel, or tap 0 of the next one
               tap = wrap ? 0 : tap;
             }
           }
@@ -1201,10 +1206,10 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
         for (int n = t; n < a.cout * cvalid * G::KK; n += RB_CONV_THREADS) {
           const int co = n / (cvalid * G::KK), r = n - co * (cvalid * G::KK);
           const int m = r / G::KK, tap = r - m * G::KK;
-          s_w[(co * taps + tap) * 33 + m] = a.w[((int64_t)co * a.cin + c0 + m) * G::KK + tap];
+          s_w[(co * taps + tap) * WLD + m] = a.w[((int64_t)co * a.cin + c0 + m) * G::KK + tap];
         }
         for (int n = t; n < a.cout * taps * (32 - cvalid); n += RB_CONV_THREADS)
-          s_w[(n / (32 - cvalid)) * 33 + cvalid + n % (32 - cvalid)] = 0.0f;
+          s_w[(n / (32 - cvalid)) * WLD + cvalid + n % (32 - cvalid)] = 0.0f;
       }
     } else if constexpr (G::S == 2 && G::KS == 4) {
       constexpr int NLD = (COUT * 64 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;     // (co, c, ty): one kernel row each
@@ -1221,8 +1226,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
         const int n = t + i * RB_CONV_THREADS;
         const int co = n >> 6, m = (n >> 1) & 31, ty = n & 1;
         if (co < a.cout) {                                 // (ntx == nty == 2 for every phase of this geometry)
-          s_w[(co * 4 + ty * 2 + 0) * 33 + m] = px ? v[i].y : v[i].x;
-          s_w[(co * 4 + ty * 2 + 1) * 33 + m] = px ? v[i].w : v[i].z;
+          s_w[(co * 4 + ty * 2 + 0) * WLD + m] = px ? v[i].y : v[i].x;
+          s_w[(co * 4 + ty * 2 + 1) * WLD + m] = px ? v[i].w : v[i].z;
         }
       }
     } else {
@@ -1248,10 +1253,10 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       for (int ty = 0; ty < TMAX; ++ty)
 #pragma unroll
         for (int tx = 0; tx < TMAX; ++tx)
-          if (co < a.cout && ty < nty && tx < ntx) s_w[(co * taps + ty * ntx + tx) * 33 + m] = v[it][ty * TMAX + tx];
+          if (co < a.cout && ty < nty && tx < ntx) s_w[(co * taps + ty * ntx + tx) * WLD + m] = v[it][ty * TMAX + tx];
     }
     }
-    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * 33 + (e & 31)] = 0.0f;
+    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * WLD + (e & 31)] = 0.0f;
   }
 
 #if defined(RB_STAMP) && defined(RB_STAMP_FINE)
@@ -1285,7 +1290,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 #pragma unroll
     for (int j = 0; j < KW / 2; ++j) {
-      const float av = s_w[(kb + 2 * j + kh) * 33 + ml];
+      const float av = s_w[(kb + 2 * j + kh) * WLD + ml];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_dy[kos[j] + noff[nt]], acc[nt]);
     }
