@@ -35,6 +35,8 @@ extern __device__ long long g_wgt[RB_WGT_KERNELS][RB_WGT_WGS][8];
 #define RB_WGT(kid, wg, slot) ((void)0)
 #define RB_WGT_HW(kid, wg) ((void)0)
 #endif
+// bank swizzle of the forward kernels' row-major weight slab (rb_conv_fwd_body): column k of row m
+__device__ __forceinline__ int rb_wswz(int m, int k) { return (k & ~3) | ((k & 3) ^ ((m >> 3) & 3)); }
 struct ConvLdsFwdArgs {
   int cin, cout;
   int n_on;                  // images [0,n_on) use net 0, the rest net 1
@@ -349,14 +351,24 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
 #pragma unroll
         for (int i = 0; i < WQ; ++i) {
           const int q = lane + 64 * i;
-          if (q < kq) rb_st4(s_w + m * WS + 4 * q, wv[r][i]);        // rows >= rows_valid were loaded as zeros
+          if (q < kq) {                                              // rows >= rows_valid were loaded as zeros
+            // bank swizzle (rb_wswz): inside its aligned group of four, column k of row m sits at (k & 3) ^ ((m >> 3) & 3) —
+            // m >> 3 == r here, a compile-time permutation of the float4
+            const float4 v = wv[r][i];
+            float4 o;
+            if ((r & 3) == 0) o = v;                                 // (r is an unrolled loop index: folded)
+            else if ((r & 3) == 1) o = make_float4(v.y, v.x, v.w, v.z);
+            else if ((r & 3) == 2) o = make_float4(v.z, v.w, v.x, v.y);
+            else o = make_float4(v.w, v.z, v.y, v.x);
+            rb_st4(s_w + m * WS + 4 * q, o);
+          }
         }
       }
     } else {                                           // odd history lengths: scalar staging
       for (int m = wave; m < 32; m += RB_CONV_WAVES)
-        for (int k = lane; k < K; k += 64) s_w[m * WS + k] = m < rows_valid_w ? a.w[net][(int64_t)(cout0 + m) * K + k] : 0.0f;
+        for (int k = lane; k < K; k += 64) s_w[m * WS + rb_wswz(m, k)] = m < rows_valid_w ? a.w[net][(int64_t)(cout0 + m) * K + k] : 0.0f;
     }
-    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(e & 31) * WS + K + (e >> 5)] = 0.0f;   // columns [K, KPAD)
+    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(e & 31) * WS + rb_wswz(e & 31, K + (e >> 5))] = 0.0f;   // columns [K, KPAD)
   }
   if constexpr (x_dw) {
     constexpr int DPR = G::IH / 4;                       // dwords per input row
@@ -480,11 +492,18 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   int kos[HW];
 #pragma unroll
   for (int j = 0; j < HW; ++j) kos[j] = s_koff[WREG ? kb + kh * HW + j : kb + 2 * j + kh];
+  // A operand: row ml, column k = kb + 2 j + kh of the row-major slab.  The row stride is a multiple of 4 (16-byte staging
+  // stores), so 32 lanes reading one column would meet in 8 banks, four deep; with the swizzle rows ml, ml + 8, ml + 16, ml + 24
+  // keep that column in four different words of its group: conflict-free.  kb % 4 == 0: two lane constants, immediate offsets.
+  // (k ranges per wave that are not 4-aligned — the data-efficient first layer, KW = 14 — compute the swizzle per step)
+  const int aswz = (ml >> 3) & 3;
+  const int a_even = ml * WS + kb + (kh ^ aswz), a_odd = ml * WS + kb + ((2 + kh) ^ aswz);
 #pragma unroll
   for (int j = 0; j < HW; ++j) {
     float av;
     if constexpr (WREG) av = areg[j];
-    else av = s_w[ml * WS + kb + 2 * j + kh];
+    else if constexpr (KW % 4 == 0) av = s_w[((j & 1) ? a_odd : a_even) + 4 * (j >> 1)];
+    else av = s_w[ml * WS + rb_wswz(ml, kb + 2 * j + kh)];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
   }
