@@ -417,6 +417,45 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
         ad.close(); rp.close()
 
 
+def test_deferred_pass_and_batches_the_sampler_gives_up_on(emu):
+    """The pending optimiser pass shares a launch with the NEXT call's sampler, which overwrites the replay header's
+    last_status — the pass must obey the status of ITS OWN batch (k_head's copy).  With max_attempts = 1 on a 512-slot ring
+    roughly a third of the draws are rejected (zero weights, no write-back, no optimiser update, no step number): eight
+    steps on a deferring handle and on its twin must see the same mix of good and failed batches and end bit-identical."""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    name = "dataeff"
+    h1 = _ts_build(emu, name)
+    h2 = _ts_build(emu, name)
+    ctrs = []
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ctr = mem.upload(np.zeros(1, np.int64))
+        L.check(emu, emu.rb_learner_set_step_counter(ad.h, mem.ptr(ctr)))
+        ctrs.append(ctr)
+    L.check(emu, emu.rb_learner_set_flags(h1[2].h, L.LEARNER_DEFER_UPDATE))
+    status = []
+    for step in range(8):
+        row = []
+        for (mem, rp, ad, o, job) in (h1, h2):
+            ts = _ts_args(name, mem, rp, ad, o, job, 0.5, 0)
+            ts.max_attempts = 1
+            L.check(emu, emu.rb_learner_train_step(ad.h, C.byref(ts), None))
+            row.append(int(rp.raw_header().last_status))
+        assert row[0] == row[1], step
+        status.append(row[0])
+    assert 0 in status and 1 in status, status                      # both kinds of step occurred
+    assert any(a == 0 and b == 1 for a, b in zip(status, status[1:])), status    # a good step's pass hosted by a failing sampler
+    L.check(emu, emu.rb_learner_flush(h1[2].h, None))
+    a, b = _ts_snapshot(*h1[:4]), _ts_snapshot(*h2[:4])
+    for k in a:
+        assert np.array_equal(a[k], b[k]), ("final", k)
+    good = status.count(0)
+    assert int(h1[0].download(ctrs[0])[0]) == good and int(h2[0].download(ctrs[1])[0]) == good
+    assert not np.array_equal(a["params"], h1[2]._flat(O.init_params(O.Config(**scenarios.LEARN_CONFIGS[name]), 1)))
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ad.close(); rp.close()
+
+
 def test_sync_target_copies_parameters_and_noise(emu):
     """Agent.update_target_net (agent.py:102-103) is load_state_dict(online.state_dict()): the registered epsilon BUFFERS
     travel with the parameters (model.py:19,22).  rb_learner_sync_target must therefore leave target == online for both
