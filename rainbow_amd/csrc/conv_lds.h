@@ -48,6 +48,7 @@ struct ConvLdsFwdArgs {
   float* out_blocked;        // optional second copy of the flattened output in the k-blocked layout of noisy_linear.h
   int rows_total;            //   ... with this many rows (images)
   int ipb;                   // k_conv_fwd_multi: images per workgroup
+  int img_fast;              // k_conv_fwd_lds: grid = (images, cout tiles, position chunks) — the image is the fastest block index
 };
 
 // ---- shared staging helpers ------------------------------------------------------------------
@@ -562,7 +563,11 @@ template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool
 __global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS * 4 <= 80 * 1024 && !F32SRC) ? 4 : 2) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS];
   const ChainLink none{nullptr, 0u, nullptr, nullptr};
-  rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG, 0, F32SRC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem, none);
+  // img_fast: workgroups are spread over the 8 XCDs by linear block index mod 8; with the image as the fastest index (and an
+  // image count that is a multiple of 8) every workgroup of image i, in every layer, runs on XCD i mod 8 — the next layer's
+  // input is then in that XCD's own L2 instead of behind the fabric
+  if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG, 0, F32SRC>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem, none);
+  else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG, 0, F32SRC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem, none);
 }
 
 // The whole conv stack of the learn step in ONE launch at small batches (<= 96 images): block ranges [layer 0 | layer 1 |
@@ -1025,6 +1030,7 @@ struct ConvLdsDxArgs {
   int dy_splits;
   int ipb, batch;        // MULTI instantiation: images per workgroup (grid z = ceil(batch / ipb)), image count
   int wt;                // write-through stores (strided phases: see rb_st1_wt)
+  int img_fast;          // grid = (image groups, channel tiles, phase x position groups): see k_conv_fwd_lds
 };
 
 // MULTI (batches of 64 and more): a workgroup keeps its weight slab and walks a.ipb images — per image only the dY tile
@@ -1061,10 +1067,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   RB_WGT(WK, wgi, 0);
   RB_WGT_HW(WK, wgi);
   const int ipb = MULTI ? a.ipb : 1;
-  const int img0 = (int)blockIdx.z * ipb;
+  const int bx_ = a.img_fast ? (int)blockIdx.z : (int)blockIdx.x, bz_ = a.img_fast ? (int)blockIdx.x : (int)blockIdx.z;
+  const int img0 = bz_ * ipb;
   const int c0 = (int)blockIdx.y * 32;
-  const int phase = (int)blockIdx.x % (G::S * G::S);
-  const int n0 = ((int)blockIdx.x / (G::S * G::S)) * (32 * NT);     // first position of this block inside the phase
+  const int phase = bx_ % (G::S * G::S);
+  const int n0 = (bx_ / (G::S * G::S)) * (32 * NT);                 // first position of this block inside the phase
   const int py = phase / G::S, px = phase % G::S;
   const int nty = (G::KS - py + G::S - 1) / G::S, ntx = (G::KS - px + G::S - 1) / G::S;
   const int nyy = (G::IH - py + G::S - 1) / G::S, nxx = (G::IH - px + G::S - 1) / G::S;
@@ -1607,6 +1614,8 @@ struct ConvDwAllArgs {
   int cotiles[3];
   int batch;
   int ipb;                 // images summed per workgroup
+  int img_fast;            // decode with the image group as the FASTEST index (see k_conv_fwd_lds): needs block ranges and group
+                           // counts that are multiples of 8
 };
 template <class G0, int RC0, class G1, int RC1, int K1, class G2, int RC2, int K2, int NL>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a) {
@@ -1619,18 +1628,30 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a
   int b = (int)blockIdx.x;
   if (b < a.nblocks[0]) {                              // decode: chunk fastest, then cout tile, then image
     constexpr int CH = (G0::OH + RC0 - 1) / RC0;
+    if (a.img_fast) {
+      const int ng = (a.batch + a.ipb - 1) / a.ipb, rest = b / ng;
+      rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], rest % CH, rest / CH, b % ng, CH, a.ipb, a.batch, smem);
+    } else
     rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], b % CH, (b / CH) % a.cotiles[0], b / (CH * a.cotiles[0]), CH, a.ipb, a.batch, smem);
     return;
   }
   b -= a.nblocks[0];
   if (b < a.nblocks[1]) {
     constexpr int CH = (G1::OH + RC1 - 1) / RC1;
+    if (a.img_fast) {
+      const int ng = (a.batch + a.ipb - 1) / a.ipb, rest = b / ng;
+      rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], rest % CH, rest / CH, b % ng, CH, a.ipb, a.batch, smem);
+    } else
     rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], b % CH, (b / CH) % a.cotiles[1], b / (CH * a.cotiles[1]), CH, a.ipb, a.batch, smem);
     return;
   }
   if (NL > 2) {
     b -= a.nblocks[1];
     constexpr int CH = (G2::OH + RC2 - 1) / RC2;
+    if (a.img_fast) {
+      const int ng = (a.batch + a.ipb - 1) / a.ipb, rest = b / ng;
+      rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], rest % CH, rest / CH, b % ng, CH, a.ipb, a.batch, smem);
+    } else
     rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], b % CH, (b / CH) % a.cotiles[2], b / (CH * a.cotiles[2]), CH, a.ipb, a.batch, smem);
   }
 }

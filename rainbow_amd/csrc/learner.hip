@@ -180,6 +180,7 @@ struct rb_learner {
   unsigned* chain_ctr;
   unsigned chain_epoch_fwd, chain_epoch_bwd;
   int opt_chain;        // RB_CONV_CHAIN (A/B switch, read once): 0 = one launch per layer
+  int opt_img_fast;     // RB_CONV_IMGFAST (A/B switch, read once)
   int opt_dw_wide, opt_dx_wide;   // RB_DW_WIDE / RB_DX_WIDE: the large-batch hidden-layer backward kernels (opt-in)
   int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
@@ -894,6 +895,7 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   a.out_blocked = (layer == l->L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
   a.rows_total = n_on + n_tg;
   a.ipb = 1;
+  a.img_fast = 0;
   static const char* const tags[3] = {"conv1_fwd:k_conv_fwd_lds", "conv2_fwd:k_conv_fwd_lds", "conv3_fwd:k_conv_fwd_lds"};
   // large batches: one round of workgroups, each keeping its weight slab for ipb images of one net (conv_lds.h)
   const bool multi_forced = l->opt_conv_multi >= 0;                      // RB_CONV_MULTI: images per workgroup (0 = off)
@@ -926,7 +928,11 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
       return RB_OK;
     }
   }
-  const dim3 grid1((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg));
+  dim3 grid1((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)(n_on + n_tg));
+  if (l->opt_img_fast && (n_on + n_tg) % 8 == 0) {     // RB_CONV_IMGFAST: image-fastest block order (XCD = image mod 8 in every layer)
+    a.img_fast = 1;
+    grid1 = dim3((unsigned)(n_on + n_tg), (unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(G::P, PCH));
+  }
   if (FIRST && src.f32) {       // float states (act / evaluate): an instantiation of its own (conv_lds.h F32SRC)
     RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG, FIRST>), grid1, dim3(RB_CONV_THREADS), stream, a);
   } else {
@@ -1004,7 +1010,7 @@ static int conv_fwd_chain(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, 
     a.w[0] = on.conv_w[i]; a.w[1] = tg.conv_w[i]; a.bias[0] = on.conv_b[i]; a.bias[1] = tg.conv_b[i];
     a.src = src; a.in_f = i > 0 ? l->act[i - 1] : nullptr; a.out = l->act[i];
     a.out_blocked = (i == L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
-    a.rows_total = NI; a.ipb = 1;
+    a.rows_total = NI; a.ipb = 1; a.img_fast = 0;
     c.cotiles[i] = (int)rb_div_up(cl.cout, 32);
     c.per_img[i] = (int)rb_div_up(cl.P(), pch[L.nconv == 3 ? 0 : 1][i]) * c.cotiles[i];
     c.nblocks[i] = c.per_img[i] * NI;
@@ -1213,7 +1219,12 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
       while (per_img * (int)rb_div_up(L.B, ipb) > 256) ++ipb;
     a.ipb = ipb; a.batch = L.B;
     a.wt = l->opt_dx_wt;
-    const dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
+    dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
+    a.img_fast = 0;
+    if (l->opt_img_fast == 1 && ipb == 1 && L.B % 8 == 0) {      // image-fastest block order: image i on XCD i mod 8 in every conv launch
+      a.img_fast = 1;
+      grid = dim3((unsigned)L.B, (unsigned)rb_div_up(c.cin, 32), (unsigned)(G::S * G::S) * groups);
+    }
     if (ipb > 1) {
       if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
       else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, false, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
@@ -1266,6 +1277,9 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
     total += (unsigned)a.nblocks[i];
   }
   for (int i = L.nconv; i < 3; ++i) { a.nblocks[i] = 0; a.cotiles[i] = 1; a.layer[i] = a.layer[0]; }
+  // image-fastest decode (an image group's workgroups of every layer on XCD group mod 8, where the input-gradient chain left
+  // its dY): block ranges and the group count must be multiples of 8
+  a.img_fast = (l->opt_img_fast == 1 && groups % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
   if (L.nconv == 3) {
     RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomC1, 7, GeomC2, 9, 512, GeomC3, 7, 576, 3>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
   } else {
@@ -1437,6 +1451,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     l->opt_dx_wt = (e = getenv("RB_DX_WT")) ? atoi(e) : 0;      // measured slower (batch 256: 45 -> 53 us): off
     l->opt_dw_wide = (e = getenv("RB_DW_WIDE")) ? (e[0] == '1') : 0;
     l->opt_dx_wide = (e = getenv("RB_DX_WIDE")) ? (e[0] == '1') : 0;
+    l->opt_img_fast = (e = getenv("RB_CONV_IMGFAST")) ? atoi(e) : 1;      // 0 off | 1 forward + input gradients | 2 forward only
     l->opt_chain = (e = getenv("RB_CONV_CHAIN")) ? atoi(e) : 0;      // measured: 3 = -1.5 us per step, 2 = equal, 1 = +13 us (profiles/round3_chain_*): opt-in
   }
   if (l->fast_fc) {
