@@ -658,10 +658,12 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_multi(ConvLdsFwdAr
 #endif
   RB_MSTAMP(48);
   // images [z * ipb, (z + 1) * ipb) of the whole list (net 0's first); a range that straddles the nets re-stages its slab
-  const int img0 = (int)blockIdx.z * a.ipb;
+  // (img_fast: grid = (image groups, cout tiles, position chunks) — a group's workgroups of consecutive layers with the same
+  // ipb share an XCD, see k_conv_fwd_lds)
+  const int img0 = (a.img_fast ? (int)blockIdx.x : (int)blockIdx.z) * a.ipb;
   const int img_end = img0 + a.ipb < a.rows_total ? img0 + a.ipb : a.rows_total;
   const int cout0 = (int)blockIdx.y * 32;
-  const int p0 = (int)blockIdx.x * PCH;
+  const int p0 = (a.img_fast ? (int)blockIdx.z : (int)blockIdx.x) * PCH;
   const int cin = a.cin;
   const int K = cin * G::KK;
   const int oy0 = p0 / G::OH;

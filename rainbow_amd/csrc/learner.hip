@@ -921,9 +921,13 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   if constexpr (ConvFwdMultiLds<G, PR, KMAX>::FITS) {
     if (ipb > 0 && !(FIRST && src.f32)) {
       a.ipb = ipb;
-      RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi<G, NT, PR, KMAX, FIRST, PCH>),
-                  dim3((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(n_on + n_tg, ipb)),
-                  dim3(RB_CONV_THREADS), stream, a);
+      const unsigned ngroups = (unsigned)rb_div_up(n_on + n_tg, ipb);
+      dim3 gridm((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), ngroups);
+      if (l->opt_img_fast && ngroups % 8 == 0) {     // image-group-fastest block order (layers 2 and 3 use the same ipb)
+        a.img_fast = 1;
+        gridm = dim3(ngroups, (unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(G::P, PCH));
+      }
+      RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi<G, NT, PR, KMAX, FIRST, PCH>), gridm, dim3(RB_CONV_THREADS), stream, a);
       RB_LAUNCH_CHECK();
       return RB_OK;
     }
@@ -1215,15 +1219,20 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     const int per_img = (G::S * G::S) * (int)groups * (int)rb_div_up(c.cin, 32);
     int ipb = 1;
     if (ipb_env > 0) ipb = ipb_env;
-    else if (L.B >= 64)                               // ONE round of workgroups (their LDS footprint allows one per CU)
+    else if (L.B >= 64) {                             // ONE round of workgroups (their LDS footprint allows one per CU)
       while (per_img * (int)rb_div_up(L.B, ipb) > 256) ++ipb;
+      // image-group-fastest order wants a group count that is a multiple of 8 — and the same groups as the next layer's launch and
+      // the weight-gradient launch (8 images each at batch 256), so that a group's dY stays in one XCD's L2 down the chain
+      if (l->opt_img_fast == 1)
+        while (ipb < L.B && (rb_div_up(L.B, ipb) % 8 != 0 || L.B % ipb != 0)) ++ipb;
+    }
     a.ipb = ipb; a.batch = L.B;
     a.wt = l->opt_dx_wt;
     dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
     a.img_fast = 0;
-    if (l->opt_img_fast == 1 && ipb == 1 && L.B % 8 == 0) {      // image-fastest block order: image i on XCD i mod 8 in every conv launch
+    if (l->opt_img_fast == 1 && L.B % ipb == 0 && (L.B / ipb) % 8 == 0) {      // image(-group)-fastest block order: image i on XCD i mod 8 in every conv launch
       a.img_fast = 1;
-      grid = dim3((unsigned)L.B, (unsigned)rb_div_up(c.cin, 32), (unsigned)(G::S * G::S) * groups);
+      grid = dim3((unsigned)(L.B / ipb), (unsigned)rb_div_up(c.cin, 32), (unsigned)(G::S * G::S) * groups);
     }
     if (ipb > 1) {
       if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
