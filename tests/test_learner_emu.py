@@ -47,6 +47,19 @@ def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
     ad.close()
 
 
+def test_chunk_fastest_conv_block_order_matches_golden(emu, monkeypatch):
+    """RB_CONV_IMGFAST=0: the (chunk, tile, image) block order of the conv launches — the fallback when the image count is
+    not a multiple of 8; the default image-fastest order is what every other test here runs (3B = 24 images on this fixture)."""
+    monkeypatch.setenv("RB_CONV_IMGFAST", "0")
+    name = "canon"
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    trace = scenarios.learn_scenario(ad, name, O, steps=1)
+    golden = load_golden("learn_%s.npz" % name)
+    assert_learn_trace_matches(trace, {k: v for k, v in golden.items() if k in trace}, label="emu-chunkfast/" + name)
+    assert any("_grad/convs" in k for k in trace)
+    ad.close()
+
+
 @pytest.mark.parametrize("name,steps,full", [("dataeff", None, "1"), ("canon", 1, "1"), ("canon", 1, "0")])
 def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, full):
     """Large batches run the conv forward and data-gradient kernels with one weight slab per workgroup and a loop over

@@ -248,6 +248,17 @@ BASELINE_SHAPES = {
 }
 
 
+@pytest.mark.parametrize("order", ["0", "2"], ids=["chunk-fastest", "image-fastest-forward-only"])
+@pytest.mark.parametrize("shape", ["cfg2-canonical-h512-b32-a6", "cfg3-canonical-h512-b256-a4"])
+def test_conv_block_orders_match_oracle(hip, monkeypatch, shape, order):
+    """The conv launches' block order is a placement decision (which XCD's L2 holds a layer's input), never a numerical one:
+    the (chunk, tile, image) order that remains the fallback when the image count is not a multiple of 8 (RB_CONV_IMGFAST=0)
+    and the forward-only variant (2) against the oracle at the shapes the bench times; the default (1) is what every other
+    test of this file runs."""
+    monkeypatch.setenv("RB_CONV_IMGFAST", order)
+    test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape, False)
+
+
 @pytest.mark.parametrize("fused_dw", [False, True], ids=["stored-dw", "fused-dw"])
 @pytest.mark.parametrize("shape", sorted(BASELINE_SHAPES))
 def test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape, fused_dw):
