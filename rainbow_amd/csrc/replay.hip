@@ -446,6 +446,9 @@ __device__ long long g_stamp[32];
 // AU = float4 quadruples per thread of the hosted optimiser workgroups (adam_body.h): they inherit this kernel's register
 // allocation, i.e. 2 waves per SIMD under the 256-thread variant's 205 VGPRs (needs AU = 8 to keep enough bytes in flight:
 // 42 us per hosted launch against 46 with AU = 4) and 4 under the 1024-thread variant's 127 (AU = 4)
+#ifndef RB_HOST_AU_WIDE
+#define RB_HOST_AU_WIDE 5      // quadruples per hosted thread under the 1024-thread variant (1 503 blocks of 4 -> 1 203 of 5)
+#endif
 template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
@@ -918,7 +921,7 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
     // 4 quadruples per thread
     static const bool deep = getenv("RB_ADAM_HOST") && !strcmp(getenv("RB_ADAM_HOST"), "deep");
     host_mode = deep ? 2 : 1;
-    blocks += (unsigned)(deep ? (job.adam_blocks + 1) / 2 : job.adam_blocks);
+    blocks += (unsigned)(deep ? (job.adam_blocks + 1) / 2 : (job.adam_blocks * 4 + RB_HOST_AU_WIDE - 1) / RB_HOST_AU_WIDE);
   }
   // RB_SAMPLER=global searches without the LDS-staged tree top (A/B switch).  Measured on MI355X, back-to-back launches,
   // B = 32 / 1M leaves: 11.1 us (LDS top, 11 LDS steps + 2 trips) vs 11.6 (4 trips); n = 20 / 100k: 14.3 vs 16.1;
@@ -929,7 +932,7 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
                 r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
   } else {
     RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: batch > 256 supports history + multi_step <= 24");
-    RB_LAUNCH_T("sample:k_sample", (k_sample<1024, 4>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
+    RB_LAUNCH_T("sample:k_sample", (k_sample<1024, RB_HOST_AU_WIDE>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
                 r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
   }
   RB_LAUNCH_CHECK();
