@@ -447,7 +447,7 @@ __device__ long long g_stamp[32];
 // allocation, i.e. 2 waves per SIMD under the 256-thread variant's 205 VGPRs (needs AU = 8 to keep enough bytes in flight:
 // 42 us per hosted launch against 46 with AU = 4) and 4 under the 1024-thread variant's 127 (AU = 4)
 #ifndef RB_HOST_AU_WIDE
-#define RB_HOST_AU_WIDE 5      // quadruples per hosted thread under the 1024-thread variant (1 503 blocks of 4 -> 1 203 of 5)
+#define RB_HOST_AU_WIDE 4      // quadruples per hosted thread under the 1024-thread variant (5 spills under its 128-register cap)
 #endif
 template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
