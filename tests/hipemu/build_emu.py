@@ -32,8 +32,10 @@ def build(force=False):
            "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-I", HERE, "-I", CSRC]
     for s in sources():
         cmd += ["-x", "c++", s]
-    cmd += ["-x", "c++", os.path.join(HERE, "hipemu.cpp"), "-o", OUT]
+    tmp = "%s.%d.tmp" % (OUT, os.getpid())           # atomic: a concurrent loader never sees a half-written library
+    cmd += ["-x", "c++", os.path.join(HERE, "hipemu.cpp"), "-o", tmp]
     subprocess.check_call(cmd)
+    os.replace(tmp, OUT)
     return OUT
 
 

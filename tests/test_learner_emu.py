@@ -1,5 +1,7 @@
 """Kernel-logic tests of the learn step on the host interpreter (CPU): the same kernel sources as
 librainbow_hip.so, against the REAL reference's golden vectors (tests/golden/learn_*.npz)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -507,12 +509,14 @@ def test_trajectory_tracks_reference_for_30_steps(emu):
     ad.close()
 
 
-@pytest.mark.parametrize("nbatch,dx_wide", [(64, "0"), (128, "1")], ids=["b64-dw", "b128-fused"])
+@pytest.mark.parametrize("nbatch,dx_wide", [(64, "0")] + ([(128, "1")] if os.environ.get("RB_TEST_FULL") == "1" else []),
+                         ids=lambda v: str(v))
 def test_large_batch_fc_backward_variants_match_oracle(emu, monkeypatch, nbatch, dx_wide):
     """Batch 64 / 128 on the data-efficient stack with hidden 64 (F = 576, 2H = 128: multiples of 64): the LDS-shared
     64 x 64-tile weight-gradient kernel of the hidden layer (k_nl_dw_wide, RB_DW_WIDE=1), the transposed-dh operand of its
     input gradient (dhT, default) and — batch 128, RB_DX_WIDE=1 — both wide bodies plus the priority write-back as block
-    ranges of one launch (k_nl_bwd_wide) against the oracle: loss and every gradient (the GPU runs the same check at 256)."""
+    ranges of one launch (k_nl_bwd_wide) against the oracle: loss and every gradient (the GPU runs the same check at 256; the
+    batch-128 case takes 80 s on the interpreter and runs with RB_TEST_FULL=1 only — the kernel is opt-in and GPU-tested)."""
     monkeypatch.setenv("RB_DW_WIDE", "1")
     monkeypatch.setenv("RB_DX_WIDE", dx_wide)
     cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=nbatch, multi_step=3, hidden=64)
