@@ -59,7 +59,10 @@ def _worker(rank, world, port, outdir, mode="allreduce"):
 @pytest.mark.parametrize("mode", ["factored", "allreduce"])
 def test_two_replicas_stay_identical(tmp_path, mode):
     world = 2
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == "factored" else 0)
+    import socket
+    with socket.socket() as sk:                      # a free port (the two modes may run in parallel pytest-xdist workers)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
