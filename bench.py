@@ -25,7 +25,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                     learner) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
   library_source_hash — hash of the sources the loaded librainbow_hip.so was built from; must equal the tree's
 --no-profile: no HIP-event bracket anywhere (the run a rocprofv3 kernel trace should see).
-With --steps < 200 every launch of the dominant kernel is bracketed (else 1 in 8).
+Runs shorter than 80 steps bracket 1 launch in (steps // 10) of the dominant kernel (at least 10 samples; else 1 in 8).
 """
 import argparse
 import ctypes as C
@@ -340,9 +340,9 @@ def main():
         probe = {k: bracketed(k, 30)[0] for k in ktab}
         kname = max((k for k in probe if probe[k] is not None), key=lambda k: probe[k])
     lib.rb_profile_select(kname.encode() if kname else None)
-    # 1 launch in 8 is bracketed inside a long timed region; a short one (the driver's 20-step run) brackets every launch,
-    # so that `roofline` is never a 2- or 3-sample mean
-    stride = PROFILE_STRIDE if opt.steps >= 200 else 1
+    # 1 launch in 8 is bracketed inside a long timed region; a short one keeps at least 10 bracketed launches (a 20-step run:
+    # every second launch), so that `roofline` is never a 2- or 3-sample mean and `value` is not charged an event pair per step
+    stride = max(1, min(PROFILE_STRIDE, opt.steps // 10))      # >= 10 bracketed launches in any run of >= 10 steps (20 steps: every 2nd)
     lib.rb_profile_stride(stride)
     if world > 1 or force_dist:
         torch.distributed.barrier()
@@ -451,7 +451,7 @@ def main():
             out["roofline"] = roof(kname, tot_ms.value / launches.value * 1e-3, launches.value)
             out["roofline"]["event_pair_overhead_us"] = ev_us
             out["roofline"]["traffic_source"] = os.path.basename(pmc_files[-1]) if pmc_files else None
-            out["roofline"]["bracketed"] = "every %s launch of the timed region" % ("%dth" % stride if stride > 1 else "single")
+            out["roofline"]["bracketed"] = "every %s launch of the timed region" % ({1: "single", 2: "2nd", 3: "3rd"}.get(stride, "%dth" % stride))
             out["roofline"]["selected"] = "forced" if opt.roofline_kernel in ktab else "largest mean launch time of a 30-step probe"
             out["roofline_others"] = [roof(o, t, n) for o, (t, n) in sorted(others.items(), key=lambda kv: -kv[1][0])]
         flops, nbytes = step_work(cfg, int(agent.params.numel()))
