@@ -259,12 +259,8 @@ def main():
                          "bracketed launch (tools/gpu_trace_gaps.sh)")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
     ap.add_argument("--extra-tags", default="", help="comma-separated extra profiling tags to time (bytes unknown: time only)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the learn step as one captured hipGraph (no per-kernel HIP-event timing then; measured "
-                         "within 2%% of eager on MI355X, profiles/round1_launch_ab.txt)")
     opt = ap.parse_args()
 
-    os.environ["RAINBOW_AMD_GRAPH"] = "1" if opt.graph else "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(opt)          # does not return

@@ -87,7 +87,7 @@ class _FlatAdam(torch.optim.Adam):
         ag = self._agent()
         if ag is not None:
             ag.flush()               # a deferred optimiser pass writes the moments
-            ag._sync_step()          # graph replay counts steps on the device: refresh the host mirror first
+            ag._sync_step()          # the device counts the steps (deferred pass): refresh the host mirror first
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
@@ -119,8 +119,8 @@ class _FlatAdam(torch.optim.Adam):
         st = self.state[g["params"][0]]
         st["step"] += 1
         b1, b2 = g["betas"]
-        # device-resident step counter (hipGraph replay): step = 0 tells the kernel to read it and form the bias
-        # corrections itself; the host copy above only mirrors it (Agent._sync_step refreshes it after replays)
+        # device-resident step counter (deferred optimiser pass): step = 0 tells the kernel to read it and form the bias
+        # corrections itself; the host copy above only mirrors it (Agent._sync_step refreshes it)
         step = 0 if ag._step_dev is not None else int(st["step"].item())
         fn = ag._lib.rb_learner_clip_adam_deferred if defer else ag._lib.rb_learner_clip_adam
         rc = fn(
@@ -189,51 +189,39 @@ class Agent:
 
         self._params.requires_grad_(True)
         self._params.grad = self._grads
-        # hipGraph replay of the whole step is opt-in (RAINBOW_AMD_GRAPH=1).  The captured step runs the library's own
-        # one-pass clip + Adam too: the optimiser's step number is then a device-resident counter the learn call increments
-        # and the kernel reads (rb_learner_set_step_counter), since a by-value argument would freeze at capture time.
-        self._use_graph = os.environ.get("RAINBOW_AMD_GRAPH", "0") == "1"
+        # (hipGraph replay of the step was built in rounds 1-3 and measured 4.5 % SLOWER than eager launches on this platform
+        # at this launch count, DESIGN.md §6: removed)
         self._step_dev = None
         kw = dict(lr=args.learning_rate, eps=args.adam_eps)
-        if os.environ.get("RAINBOW_AMD_FUSED_ADAM", "1") != "1":     # A/B: k_clip_scale + PyTorch's fused Adam
-            if self._use_graph:
-                kw["capturable"] = True
+        if os.environ.get("RAINBOW_AMD_FUSED_ADAM", "1") != "1":     # k_clip_scale + PyTorch's own (fused) Adam
             try:
                 self.optimiser = torch.optim.Adam([self._params], fused=True, **kw)
             except (TypeError, RuntimeError):
                 self.optimiser = torch.optim.Adam([self._params], **kw)
         else:
-            # RAINBOW_AMD_DEFER_UPDATE (default on; not under graph replay): learn() leaves its clip + Adam pass pending
+            # RAINBOW_AMD_DEFER_UPDATE (default on): learn() leaves its clip + Adam pass pending
             # and the NEXT learn()'s sampler launch hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE) — anything
             # else that touches the parameters runs it first (the library's entry points do so themselves; the public
             # tensors `params`, `grads`, `_norm` and the optimiser state go through flush()).  Needs the device-resident
-            # step number, like graph replay.
-            self._defer_update = os.environ.get("RAINBOW_AMD_DEFER_UPDATE", "1") == "1" and not self._use_graph
-            if self._use_graph or self._defer_update:
+            # step number (rb_learner_set_step_counter: the learn call increments it, the pass reads it).
+            self._defer_update = os.environ.get("RAINBOW_AMD_DEFER_UPDATE", "1") == "1"
+            if self._defer_update:
                 self._step_dev = torch.zeros(1, dtype=torch.int64, device=d)
                 L.check(self._lib, self._lib.rb_learner_set_step_counter(self._h, self._step_dev.data_ptr()))
             self.optimiser = _FlatAdam(self, **kw)                   # agent.py:46
-        self._graph = None
-        self._graph_mem = None
-        self._eager_steps = 0
         self._noise_jobs = {}
         self._zero_copy_ok = None
         # the whole step as ONE C call (rb_learner_train_step) when nothing needs the interpreter in between
         self._one_call = os.environ.get("RAINBOW_AMD_ONE_CALL", "1") == "1"
         self._ts = self._ts_mem = self._ts_out = None
         self._sink_watched = set()
-        # priority write-back beside clip + Adam on a second stream (one fork/join per step)
-        self._overlap_update = os.environ.get("RAINBOW_AMD_UPDATE_OVERLAP", "0") == "1"
         # priority write-back as one extra workgroup of the learner's backward launch (see rb_learner_set_priority_sink)
-        self._fuse_update = os.environ.get("RAINBOW_AMD_FUSED_UPDATE", "1") == "1"
+        self._fuse_update = True
         self._loss = torch.zeros(self.batch_size, dtype=torch.float32, device=d)
         self._norm_buf = torch.zeros(1, dtype=torch.float32, device=d)
         self._act_pin = torch.zeros(2 * self.batch_size, dtype=torch.int32).pin_memory()     # written by the device
         self._q_pin = torch.zeros(2 * self.batch_size, dtype=torch.float32).pin_memory()
         self._act_np, self._q_np = self._act_pin.numpy(), self._q_pin.numpy()
-        self._side = torch.cuda.Stream(device=d)          # priority write-back overlaps clip + Adam
-        self._ev_loss = torch.cuda.Event()
-        self._ev_upd = torch.cuda.Event()
         self._world = rdist.world_size()
         self._dist = rdist.active()
         self._exchange = None
@@ -380,10 +368,6 @@ class Agent:
         n = int(st.shape[0])
         out = np.empty(n, dtype=np.float32)
         chunk = max(1, min(int(chunk), 4096))
-        if min(n, chunk) > 3 * self.batch_size and self._graph is not None:
-            # the library regrows its forward buffers for more than 3*batch rows: a captured learn step holds the old
-            # addresses, so it is dropped and re-captured after the next warm-up
-            self._graph, self._graph_mem, self._eager_steps = None, None, 0
         if self._q_pin.numel() < min(n, chunk):
             self._act_pin = torch.zeros(min(n, chunk), dtype=torch.int32).pin_memory()
             self._q_pin = torch.zeros(min(n, chunk), dtype=torch.float32).pin_memory()
@@ -408,25 +392,11 @@ class Agent:
             qs[lo:hi] = self.evaluate_q_batch(val_mem.states_at(torch.arange(lo, hi, device=self.device)), chunk)
         return qs
 
-    GRAPH_WARMUP = 3   # eager steps before the learn step is captured into a hipGraph
-
     def learn(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         """agent.py:61-100.  With a rainbow_amd ReplayMemory the whole step (sample .. priority update) is
-        device-resident and launched eagerly.  hipGraph replay is OPT-IN (RAINBOW_AMD_GRAPH=1): after GRAPH_WARMUP eager
-        calls the step is then captured once and replayed.  The injected-randomness arguments are parity-test hooks."""
-        injected = _target_raw_normals is not None or _unit_uniforms is not None
+        device-resident and launched eagerly.  The injected-randomness arguments are parity-test hooks."""
         if isinstance(mem, ReplayMemory):
             self._raise_on_failed_samples(mem)
-        if (self._use_graph and not injected and not self._dist and isinstance(mem, ReplayMemory)):
-            if self._graph is not None and self._graph_mem is mem:
-                self._flush_noise()
-                mem._sync_beta()
-                self._graph.replay()
-                return
-            if self._eager_steps >= self.GRAPH_WARMUP:
-                self._capture(mem)
-                return
-            self._eager_steps += 1
         self._learn_eager(mem, _target_raw_normals, _unit_uniforms)
 
     def _raise_on_failed_samples(self, mem):
@@ -435,6 +405,11 @@ class Agent:
         update and the device-resident step number are skipped when the header says so): here the host side is put back
         in step — the optimiser's step count is rolled back by the number of skipped updates, the counter is cleared —
         and the failure is raised.  The caller may append more transitions and call learn() again."""
+        if self._step_dev is None:
+            # by-value step numbers (RAINBOW_AMD_DEFER_UPDATE=0): the host's step count must be exact BEFORE the next
+            # optimiser pass is issued, so the sampler launches in flight are waited for here (the default mode counts the
+            # steps on the device and needs no such sync: a failure is then reported one learn() late, nothing else)
+            torch.cuda.current_stream(self.device).synchronize()
         failed = mem.failed_samples()
         if not failed:
             return
@@ -447,22 +422,9 @@ class Agent:
                            % (failed, mem.MAX_ATTEMPTS, self.batch_size))
 
     def _sync_step(self):
-        """Host mirror of the optimiser's step number after graph replays (state_dict / checkpoint read it)."""
+        """Host mirror of the device-resident optimiser step number (state_dict / checkpoint read it)."""
         if self._step_dev is not None and isinstance(self.optimiser, _FlatAdam):
             self.optimiser.state[self._params]["step"].fill_(float(self._step_dev.item()))
-
-    def _capture(self, mem):
-        dev = self.device
-        self._flush_noise()
-        mem._sync_beta()
-        torch.cuda.synchronize(dev)
-        self._gstream = torch.cuda.Stream(device=dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=self._gstream):
-            self._learn_eager(mem, None, None)
-        self._graph, self._graph_mem = graph, mem
-        torch.cuda.synchronize(dev)     # the capture itself does not execute the step
-        self._graph.replay()
 
     def _learn_one_call(self, mem, stream):
         """The whole step through rb_learner_train_step (one C call): same entry points, same arguments, same order as
@@ -515,7 +477,7 @@ class Agent:
             self._zero_copy_ok = bool(self._lib.rb_learner_zero_copy_ok(self._h))
         zero_copy = device_mem and self._zero_copy_ok and mem.history == self._cfg.history and mem.n == self.n
         if (zero_copy and self._one_call and _target_raw_normals is None and _unit_uniforms is None and self._fuse_update
-                and not self._overlap_update and self._exchange is None and not self._dist
+                and self._exchange is None and not self._dist
                 and isinstance(self.optimiser, _FlatAdam) and math.isfinite(float(self.norm_clip))):
             g = self.optimiser.param_groups[0]
             if not (g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"]):
@@ -583,25 +545,17 @@ class Agent:
                 self._h, states.data_ptr(), next_states.data_ptr(), actions.data_ptr(), returns.data_ptr(),
                 nonterminals.data_ptr(), weights.data_ptr(), self._loss.data_ptr(), stream))   # agent.py:66-96
         fused_update = device_mem and bool(self._lib.rb_learner_priority_written(self._h))
-        overlap = device_mem and self._overlap_update and not fused_update
-        if overlap:
-            # agent.py:100 without the D2H sync: the new priorities depend only on (idxs, loss), so the sum-tree
-            # update runs on a side stream next to clip + Adam; the main stream re-joins before the next sample.
-            main = torch.cuda.current_stream(self.device)
-            self._ev_loss.record(main)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(self._ev_loss)
-                mem.update_priorities(idxs, self._loss)
-                self._ev_upd.record(self._side)
         if self._exchange is not None:
-            # replicas, factored exchange: all-gather the FC gradient factors (0.7 MB, side stream, under the rest of the
-            # backward), all-reduce the conv gradients (0.3 MB), finish the FC gradients of the global batch on device
+            # replicas, factored exchange (the insert point between agent.py:96 and :97): ONE all-gather of every rank's
+            # block — the factors of its FC weight gradients (dY and X rows, its noise vectors) and its conv gradients,
+            # 1.0 MB — on this stream, then rb_learner_finish_grads forms the replica-mean gradient of the global batch
+            # on every replica (rainbow_amd/dist.py)
             self._exchange.run()
         elif self._dist:      # replicas, plain exchange: one RCCL all-reduce of the flat gradient (4*P bytes)
             rdist.average_gradients(self._grads)
             L.check(self._lib, self._lib.rb_learner_grads_modified(self._h))
         if isinstance(self.optimiser, _FlatAdam):
-            defer = self._defer_update and device_mem and not overlap
+            defer = self._defer_update and device_mem
             self.optimiser.step_direct(float(self.norm_clip), stream, defer=defer)         # agent.py:97-98, one pass
             if defer:
                 self._update_pending = True      # (the library decides; flush() is a no-op when it ran at once)
@@ -609,9 +563,7 @@ class Agent:
             L.check(self._lib, self._lib.rb_learner_clip_grad(self._h, float(self.norm_clip), self._norm_buf.data_ptr(),
                                                               stream))                    # agent.py:97
             self.optimiser.step()                                                          # agent.py:98
-        if overlap:
-            torch.cuda.current_stream(self.device).wait_event(self._ev_upd)
-        elif device_mem:
+        if device_mem:
             if not fused_update:
                 mem.update_priorities(idxs, self._loss)                                    # agent.py:100, no D2H
         else:
@@ -744,7 +696,7 @@ class Agent:
         save() (weights only, agent.py:106-107) stays what main.py:182 calls; this is the superset a resumable run needs
         (main.py has no such thing: it restarts the optimiser).  Returns the dict; writes it with torch.save if `path`."""
         if not isinstance(self.optimiser, _FlatAdam):
-            raise NotImplementedError("checkpoint() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1, no graph)")
+            raise NotImplementedError("checkpoint() covers the library's own Adam (RAINBOW_AMD_FUSED_ADAM=1)")
         self.flush()
         self._sync_step()
         seed, epoch = C.c_uint64(0), C.c_uint64(0)

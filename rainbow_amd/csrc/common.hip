@@ -116,6 +116,20 @@ void rb_dev_free(void* p) {
   (void)hipFree(p);
 }
 
+int rb_opt(const char* key, int dflt) {
+  const char* s = getenv("RB_OPTS");
+  if (!s || !key) return dflt;
+  const size_t kl = strlen(key);
+  while (*s) {
+    const char* e = strchr(s, ',');
+    const size_t n = e ? (size_t)(e - s) : strlen(s);
+    if (n > kl + 1 && strncmp(s, key, kl) == 0 && s[kl] == '=') return atoi(s + kl + 1);
+    if (!e) break;
+    s = e + 1;
+  }
+  return dflt;
+}
+
 void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nbytes);   // replay.hip
 
 extern "C" {

@@ -113,25 +113,11 @@ __device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, i
 #define RB_CONV_WAVES 8
 #define RB_CONV_THREADS (64 * RB_CONV_WAVES)
 // PCH = output positions per workgroup (<= 32 NT; a multiple of the row length keeps the patch at PR rows).
-// WREG: the weight operand never touches LDS.  A wave keeps its K-slice of the 32-channel slab in REGISTERS, loaded from
-// global memory straight in the MFMA layout: the reduction index is permuted so that lane (m = l & 31, half = l >> 5) owns
-// the KW/2 CONSECUTIVE weights k = kb + half * KW/2 + j of row m (whole float4 loads; KPAD is a multiple of 64 so every
-// wave's half-slice is a multiple of 4), and MFMA step j multiplies k-pair (kb + j, kb + KW/2 + j) — the same permutation
-// indexes the patch-offset table, a sum does not care.  That removes the transposing LDS stores (4- to 16-way bank
-// conflicts, 34-52 % of the LDS-active cycles of these kernels), one LDS read per MFMA step, and 34-76 KB of LDS per
-// workgroup: two workgroups share a CU and the staging of one runs under the MFMAs of the other.
-// In-launch dependency of one workgroup (rb_device.h rb_chain_*; all NULL = none): it may not read its INPUT IMAGE before
-// `wait_ctr` has reached `wait_target` (weights, tap table and everything else that does not depend on the producer are
-// staged before the wait), and it announces its own output on `done_ctr`.
-struct ChainLink {
-  const unsigned* wait_ctr;
-  unsigned wait_target;
-  unsigned* done_ctr;
-  unsigned* err;
-};
-template <class G, int NT, int PR, int KMAX, bool WREG = false>
+// T16 (the t16 variant below): no reduction scratch, no tap table; the channel planes of the patch are padded so that the four
+// k-slots of a 16x16x4 operand read (channel groups cin/4 apart) start 16 banks apart.
+template <class G, int NT, int PR, int KMAX, bool T16 = false>
 struct ConvFwdLdsSize {
-  static constexpr int KGRAN = WREG ? 8 * RB_CONV_WAVES : 2 * RB_CONV_WAVES;
+  static constexpr int KGRAN = 2 * RB_CONV_WAVES;
   static constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
   static constexpr int RED = RB_CONV_WAVES * 16 * 64;      // reduction scratch (floats) for ONE 32-position tile, overlays the operands
   // the weight slab keeps its GLOBAL orientation in LDS: 32 rows (output channels) of KPAD + 4 floats.  Staging is then
@@ -148,25 +134,51 @@ struct ConvFwdLdsSize {
   static constexpr int SUB = (G::IH + G::S - 1) / G::S;
   static constexpr int RP = G::S * SUB;                    // row pitch (>= IH)
   static_assert((G::OH - 1) + (G::KS - 1) / G::S < SUB, "a tap's positions stay inside their phase's sub-row");
-  static constexpr int OPS = (WREG ? 0 : 32 * WS) + (KMAX / G::KK) * PR * RP;     // [weights then] patch, contiguous
-  static constexpr int WSZ = OPS > RED ? OPS : RED;
-  static constexpr int FLOATS = WSZ + KPAD;                // + the tap table (ints)
+  static constexpr int CQ = (KMAX / G::KK) / 4;            // T16: channels per k-slot
+  static constexpr int rb_plane_pad() {
+    if (!T16 || CQ == 0) return 0;
+    for (int p = 0; p < 64; p += 2)
+      if ((CQ * (PR * RP + p)) % 32 == 16) return p;
+    return 0;
+  }
+  static constexpr int PLANE = PR * RP + rb_plane_pad();   // floats per channel in the patch
+  static constexpr int OPS = 32 * WS + (KMAX / G::KK) * PLANE;       // weights then patch, contiguous
+  static constexpr int WSZ = T16 ? OPS : (OPS > RED ? OPS : RED);
+  static constexpr int FLOATS = WSZ + (T16 ? 0 : KPAD);    // + the tap table (ints)
 };
 // body with explicit block coordinates and caller-provided LDS, so the layers of the stack can share one launch
-// COH bit 0: the input image was produced inside this launch — read it with agent-coherent (sc1) loads after the wait;
-// bit 1: the output is consumed inside this launch — store it write-through (sc1).  0 with a link: fences instead.
 // F32SRC (first layer only): the input is a.src.f32 (act / evaluate: float states) instead of the u8 frames.  The kind of
 // the input loads is a compile-time property so that only ONE staging register array exists (all three alive at once cost
 // the first layer its second workgroup per CU).
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false, int COH = 0, bool F32SRC = false>
-__device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx, int by, int img, float* smem, const ChainLink& link) {
-  typedef ConvFwdLdsSize<G, NT, PR, KMAX, WREG> SZ;
+// T16: the MFMA phase on v_mfma_f32_16x16x4_f32 with NO split of the reduction: the workgroup has one wave per 16-position x
+// 16-channel output tile (PT position tiles x 2 channel tiles = NWV waves), every wave runs the WHOLE K for its tile — no
+// cross-wave partial sums, no reduction barriers, the epilogue goes from the accumulators to memory (the cross-wave sum +
+// epilogue of the 8-way K split was 2.6 / 1.7 us of the second / third layer's 11.4 / 10.3 us workgroups, profiles/
+// round3_final_wg_timeline.txt).  Lane (x = l & 15, kq = l >> 4) owns the CONTIGUOUS quarter [kq K/4, (kq + 1) K/4) of the
+// reduction: its A operands are whole float4s of weight row x (one ds_read_b128 per four MFMAs), its B operands are patch
+// cells whose offsets are compile-time functions of the step (immediates: no tap table).  Needs cin * KK == KMAX, cin % 4 == 0,
+// KMAX % 16 == 0 (host-checked).
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, bool T16 = false>
+struct ConvFwdWaves {
+  static constexpr int PT = (PCH + 15) / 16;
+  static constexpr int NWV = T16 ? 2 * PT : RB_CONV_WAVES;
+};
+template <class G, int KMAX, int PLANE, int RP, int SUB>
+__device__ __forceinline__ constexpr int rb_t16_off(int j) {            // step j of a lane's K quarter -> offset in the patch
+  return (j / G::KK) * PLANE + ((j % G::KK) / G::KS) * RP + (((j % G::KK) % G::KS) % G::S) * SUB + ((j % G::KK) % G::KS) / G::S;
+}
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, bool T16 = false>
+__device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx, int by, int img, float* smem) {
+  typedef ConvFwdLdsSize<G, NT, PR, KMAX, T16> SZ;
+  constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, T16>::NWV;
+  constexpr int THREADS = 64 * NWV;
   constexpr int KPAD = SZ::KPAD;
   constexpr int SUB = SZ::SUB, RP = SZ::RP;
-  constexpr int PLANE = PR * RP;                    // floats per channel in the patch
+  constexpr int PLANE = SZ::PLANE;                  // floats per channel in the patch
   constexpr int CMAX = KMAX / G::KK;
+  static_assert(!T16 || (KMAX % 16 == 0 && CMAX % 4 == 0), "t16: whole float4s per k-slot");
   float* s_all = smem;
-  int* s_koff = reinterpret_cast<int*>(smem + SZ::WSZ);
+  int* s_koff = reinterpret_cast<int*>(smem + SZ::WSZ);    // (not T16: no table)
   constexpr int WS = SZ::WS;
   // patch cell of (channel c, element `off` of the channel's [rows][IH] patch)
   auto pcell = [&](int c, int off) -> int {
@@ -174,7 +186,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     return c * PLANE + r * RP + (x % G::S) * SUB + x / G::S;
   };
   float* s_w = s_all;
-  float* s_patch = s_all + (WREG ? 0 : 32 * WS);
+  float* s_patch = s_all + 32 * WS;
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int SB = G::KS == 8 ? 0 : G::KS == 4 ? 8 : 16;    // stamp slots per layer (RB_STAMP builds only)
@@ -188,7 +200,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
 #if !defined(RB_HOST_INTERP)
   // staging outranks the MFMA phase of a co-resident workgroup: two first-layer workgroups share a CU, and the one that
   // got there second spent 4.4 us converting and storing 7 KB of frames while the first ran its MFMA loop (0.9 us alone;
-  // tools/_fine_stage.py) — the wave scheduler favours the older waves.  Dropped again before this workgroup's own MFMAs.
+  // tools/stamp/fine_stage.py) — the wave scheduler favours the older waves.  Dropped again before this workgroup's own MFMAs.
   __builtin_amdgcn_s_setprio(3);
 #endif
   const int net = img < a.n_on ? 0 : 1;
@@ -205,15 +217,14 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   // Per-workgroup timeline (tools/wg_timeline.py): weights 1.8-2.3 us and input 1.9-3.8 us used to be two memory round
   // trips in sequence (load, store to LDS, load, store to LDS).  Now every global load of BOTH operands is issued before the
   // first LDS store — first-layer frames: the window-table entries first, they gate the frame addresses — and the LDS
-  // stores follow in issue order.  (Chain mode: the weight loads are in flight while the workgroup waits for its image.)
-  constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time: the MFMA loop is fully unrolled
+  // stores follow in issue order.
+  constexpr int KW = KPAD / RB_CONV_WAVES;            // even, compile-time: the MFMA loop is fully unrolled (not T16)
   constexpr int HW = KW / 2;
   const int rows_valid_w = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
-  float areg[WREG ? HW : 1];
   // weights: the fast path of rb_stage_weights_t split into issue (loads) and commit (transposing LDS stores)
-  constexpr int WR = 4, WQ = (KMAX + 255) / 256;      // 32 rows / 8 waves; K <= KMAX: quads of a row per lane
-  const bool w_fast = !WREG && (K & 3) == 0 && (K >> 2) <= 64 * WQ;
-  float4 wv[WREG ? 1 : WR][WREG ? 1 : WQ];
+  constexpr int WR = (32 + NWV - 1) / NWV, WQ = (KMAX + 255) / 256;      // 32 rows over the waves; K <= KMAX: quads of a row per lane
+  const bool w_fast = (K & 3) == 0 && (K >> 2) <= 64 * WQ;
+  float4 wv[WR][WQ];
   // input: one batch of loads per thread (every geometry of the two networks fits one batch; more: the loops after it)
   constexpr bool x_u8 = FIRST && !F32SRC;
   constexpr bool x_vec = !x_u8 && (G::IH % 4) == 0;   // then per_c, iy0 * IH and IP are multiples of 4 as well
@@ -221,7 +232,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   // phases of one de-interleaved index, so consecutive lanes store consecutive words of each phase's sub-row (conflict-free
   // scalar stores; 16-byte loads put 16-byte-strided lanes on 8 banks)
   constexpr bool x_dw = x_u8 && G::S == 4 && (G::IH % 4) == 0;
-  constexpr int XD = x_dw ? (CMAX * PR * G::IH / 4 + RB_CONV_THREADS - 1) / RB_CONV_THREADS : 1;
+  constexpr int XD = x_dw ? (CMAX * PR * G::IH / 4 + THREADS - 1) / THREADS : 1;
   constexpr int XU = (x_u8 && !x_dw) ? 2 : 1, XV = x_vec ? 8 : 1, XS = (!x_u8 && !x_vec) ? 12 : 1;
   const float* xbase = x_u8 ? nullptr : (FIRST ? a.src.f32 + (int64_t)img * cin * G::IP : a.in_f + (int64_t)img * cin * G::IP);
   const int per_c = rows * G::IH;                     // elements per channel of the patch (u8: bytes, a 16-byte multiple for the frame geometries)
@@ -236,12 +247,12 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   float xs[XS];
   // zero-copy frames: the window-table entries are REQUESTED here and turned into frame addresses only after the weight
   // loads have been issued (an address formed at once put the table's round trip in front of every other load: 1.5 us
-  // from workgroup start to the first weight load, tools/_fine_stage.py)
+  // from workgroup start to the first weight load, tools/stamp/fine_stage.py)
   int32_t widx[x_dw ? XD : XU];
   if constexpr (x_u8) {
 #pragma unroll
     for (int i = 0; i < (x_dw ? XD : XU); ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       const int c = x_dw ? e / dpc : e / v16;
       widx[i] = -1;
       if ((x_dw ? e < total_dw : e < total16) && a.src.ring) {
@@ -250,27 +261,11 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
       }
     }
   }
-  if constexpr (WREG) {
-    const int ml_ = lane & 31, kh_ = lane >> 5;
-    const float* wrow = a.w[net] + (int64_t)(cout0 + (ml_ < rows_valid_w ? ml_ : 0)) * K;
-    const int k0 = wave * KW + kh_ * HW;
-    if ((K & 3) == 0) {
-#pragma unroll
-      for (int j4 = 0; j4 < HW / 4; ++j4) {
-        const int k = k0 + 4 * j4;
-        float4 v4_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (k < K && ml_ < rows_valid_w) v4_ = rb_ld4(wrow + k);            // K % 4 == 0: a quad is inside or outside as a whole
-        areg[4 * j4 + 0] = v4_.x; areg[4 * j4 + 1] = v4_.y; areg[4 * j4 + 2] = v4_.z; areg[4 * j4 + 3] = v4_.w;
-      }
-    } else {                                           // odd history lengths
-#pragma unroll
-      for (int j = 0; j < HW; ++j) areg[j] = (k0 + j < K && ml_ < rows_valid_w) ? wrow[k0 + j] : 0.0f;
-    }
-  } else if (w_fast) {
+  if (w_fast) {
     const int kq = K >> 2;
 #pragma unroll
     for (int r = 0; r < WR; ++r) {
-      const int m = wave + r * RB_CONV_WAVES;
+      const int m = wave + r * NWV;
 #pragma unroll
       for (int i = 0; i < WQ; ++i) {
         const int q = lane + 64 * i;
@@ -280,12 +275,11 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     }
   }
   RB_WGT(WK, wgi, 1);
-  if (link.wait_ctr) rb_chain_wait<(COH & 1) != 0>(link.wait_ctr, link.wait_target, link.err);   // the input image is final from here on
   RB_WGT(WK, wgi, 2);
   if constexpr (x_u8) {
 #pragma unroll
     for (int i = 0; i < (x_dw ? XD : XU); ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       const int c = x_dw ? e / dpc : e / v16;
       fp[i] = nullptr;
       if (x_dw ? e < total_dw : e < total16) {
@@ -298,7 +292,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   if constexpr (x_dw) {
 #pragma unroll
     for (int i = 0; i < XD; ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       xd[i] = 0u;
       if (e < total_dw && fp[i]) xd[i] = *reinterpret_cast<const unsigned*>(fp[i] + iy0 * G::IH + 4 * (e - (e / dpc) * dpc));
     }
@@ -306,7 +300,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     if constexpr (FIRST) {
 #pragma unroll
       for (int i = 0; i < XU; ++i) {
-        const int e = i * RB_CONV_THREADS + t;
+        const int e = i * THREADS + t;
         xu[i] = make_uint4(0u, 0u, 0u, 0u);
         if (e < total16 && fp[i]) xu[i] = *reinterpret_cast<const uint4*>(fp[i] + iy0 * G::IH + (e - (e / v16) * v16) * 16);
       }
@@ -314,21 +308,19 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   } else if constexpr (x_vec) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       if (e < total4) {
         const int c = e / v4, q = e - c * v4;
-        if constexpr ((COH & 1) != 0) xv[i] = rb_ld4_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q * 4), 0u);
-        else xv[i] = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+        xv[i] = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
       }
     }
   } else {
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       if (e < total1) {
         const int c = e / per_c, q = e - c * per_c;
-        if constexpr ((COH & 1) != 0) xs[i] = rb_ld1_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q), 0u);
-        else xs[i] = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
+        xs[i] = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
       }
     }
   }
@@ -338,26 +330,28 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   RB_WGT(WK + 4, wgi, 1);                               // (fine: thread 0's loads have landed)
 #endif
   // ---- LDS: tap table (no memory operand), then the weights, then the input
-  for (int k = t; k < KPAD; k += RB_CONV_THREADS) {
-    const int kc = k < K ? k : K - 1;
-    const int c = kc / G::KK, r = kc % G::KK;
-    s_koff[k] = c * PLANE + (r / G::KS) * RP + ((r % G::KS) % G::S) * SUB + (r % G::KS) / G::S;
+  if constexpr (!T16) {
+    for (int k = t; k < KPAD; k += THREADS) {
+      const int kc = k < K ? k : K - 1;
+      const int c = kc / G::KK, r = kc % G::KK;
+      s_koff[k] = c * PLANE + (r / G::KS) * RP + ((r % G::KS) % G::S) * SUB + (r % G::KS) / G::S;
+    }
   }
-  if constexpr (!WREG) {
+  {
     if (w_fast) {
       const int kq = K >> 2;
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
-        const int m = wave + r * RB_CONV_WAVES;
+        const int m = wave + r * NWV;
 #pragma unroll
         for (int i = 0; i < WQ; ++i) {
           const int q = lane + 64 * i;
-          if (q < kq) {                                              // rows >= rows_valid were loaded as zeros
+          if (q < kq && m < 32) {                                    // rows >= rows_valid were loaded as zeros
             // bank swizzle (rb_wswz): inside its aligned group of four, column k of row m sits at (k & 3) ^ ((m >> 3) & 3) —
             // m >> 3 == r here, a compile-time permutation of the float4
             const float4 v = wv[r][i];
             float4 o;
-            if ((r & 3) == 0) o = v;                                 // (r is an unrolled loop index: folded)
+            if (T16 || (r & 3) == 0) o = v;                          // (r is an unrolled loop index: folded; T16: no swizzle)
             else if ((r & 3) == 1) o = make_float4(v.y, v.x, v.w, v.z);
             else if ((r & 3) == 2) o = make_float4(v.z, v.w, v.x, v.y);
             else o = make_float4(v.w, v.z, v.y, v.x);
@@ -366,16 +360,16 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
         }
       }
     } else {                                           // odd history lengths: scalar staging
-      for (int m = wave; m < 32; m += RB_CONV_WAVES)
-        for (int k = lane; k < K; k += 64) s_w[m * WS + rb_wswz(m, k)] = m < rows_valid_w ? a.w[net][(int64_t)(cout0 + m) * K + k] : 0.0f;
+      for (int m = wave; m < 32; m += NWV)
+        for (int k = lane; k < K; k += 64) s_w[m * WS + (T16 ? k : rb_wswz(m, k))] = m < rows_valid_w ? a.w[net][(int64_t)(cout0 + m) * K + k] : 0.0f;
     }
-    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(e & 31) * WS + rb_wswz(e & 31, K + (e >> 5))] = 0.0f;   // columns [K, KPAD)
+    for (int e = t; e < (KPAD - K) * 32; e += THREADS) s_w[(e & 31) * WS + rb_wswz(e & 31, K + (e >> 5))] = 0.0f;   // columns [K, KPAD)
   }
   if constexpr (x_dw) {
     constexpr int DPR = G::IH / 4;                       // dwords per input row
 #pragma unroll
     for (int i = 0; i < XD; ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       if (e < total_dw) {
         const int c = e / dpc, d = e - c * dpc;
         const int r = d / DPR, xi = d - r * DPR;        // bytes 4 xi .. 4 xi + 3 of row r: phases 0..3 of de-interleaved index xi
@@ -388,7 +382,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     if constexpr (FIRST) {
 #pragma unroll
       for (int i = 0; i < XU; ++i) {
-        const int e = i * RB_CONV_THREADS + t;
+        const int e = i * THREADS + t;
         if (e < total16) {
           const int c = e / v16, q = e - c * v16;
           const unsigned wds[4] = {xu[i].x, xu[i].y, xu[i].z, xu[i].w};
@@ -398,7 +392,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
             for (int b = 0; b < 4; ++b) s_patch[pcell(c, q * 16 + wd * 4 + b)] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
         }
       }
-      for (int e = XU * RB_CONV_THREADS + t; e < total16; e += RB_CONV_THREADS) {          // beyond one batch (not the frame geometries)
+      for (int e = XU * THREADS + t; e < total16; e += THREADS) {          // beyond one batch (not the frame geometries)
         const int c = e / v16, q = e - c * v16;
         const uint8_t* f = rb_frame_ptr(a.src, img, c, cin, G::IP);
         uint4 raw = make_uint4(0u, 0u, 0u, 0u);
@@ -409,7 +403,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
 #pragma unroll
           for (int b = 0; b < 4; ++b) s_patch[pcell(c, q * 16 + wd * 4 + b)] = rb_unit((uint8_t)((wds[wd] >> (8 * b)) & 0xFFu));
       }
-      for (int e = t; e < cin * (per_c & 15); e += RB_CONV_THREADS) {   // (no tail for 84-wide frames; kept for generality)
+      for (int e = t; e < cin * (per_c & 15); e += THREADS) {   // (no tail for 84-wide frames; kept for generality)
         const int c = e / (per_c & 15), q = (v16 << 4) + e % (per_c & 15);
         const uint8_t* f = rb_frame_ptr(a.src, img, c, cin, G::IP);
         s_patch[pcell(c, q)] = f ? rb_unit(f[iy0 * G::IH + q]) : 0.0f;
@@ -418,7 +412,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   } else if constexpr (x_vec) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       if (e < total4) {
         const int c = e / v4, q = e - c * v4;
         if constexpr (G::S == 1) { rb_st4(s_patch + c * PLANE + q * 4, xv[i]); }       // RP == IH: the quad stays a quad
@@ -434,25 +428,21 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
         }
       }
     }
-    for (int e = XV * RB_CONV_THREADS + t; e < total4; e += RB_CONV_THREADS) {               // beyond one batch
+    for (int e = XV * THREADS + t; e < total4; e += THREADS) {               // beyond one batch
       const int c = e / v4, q = e - c * v4;
-      float4 v;
-      if constexpr ((COH & 1) != 0) v = rb_ld4_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q * 4), 0u);
-      else v = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+      const float4 v = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
       s_patch[pcell(c, q * 4 + 0)] = v.x; s_patch[pcell(c, q * 4 + 1)] = v.y;
       s_patch[pcell(c, q * 4 + 2)] = v.z; s_patch[pcell(c, q * 4 + 3)] = v.w;
     }
   } else {
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
-      const int e = i * RB_CONV_THREADS + t;
+      const int e = i * THREADS + t;
       if (e < total1) { const int c = e / per_c, q = e - c * per_c; s_patch[pcell(c, q)] = xs[i]; }
     }
-    for (int e = XS * RB_CONV_THREADS + t; e < total1; e += RB_CONV_THREADS) {               // beyond one batch
+    for (int e = XS * THREADS + t; e < total1; e += THREADS) {               // beyond one batch
       const int c = e / per_c, q = e - c * per_c;
-      float v;
-      if constexpr ((COH & 1) != 0) v = rb_ld1_buf_sc1(rb_make_buf(xbase), 4u * (unsigned)(c * G::IP + iy0 * G::IH + q), 0u);
-      else v = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
+      const float v = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
       s_patch[pcell(c, q)] = v;
     }
   }
@@ -466,6 +456,52 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   RB_CSTAMP(SB + 1);
   RB_WGT(WK, wgi, 3);
 
+  if constexpr (T16) {
+    constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4;
+    const int pt = wave % PT, ct = wave / PT;         // wave-uniform: position tile, channel tile
+    const int x = lane & 15, kq = lane >> 4;
+    int p = p0 + pt * 16 + x;
+    const bool pv = p < G::P && p < p0 + PCH;
+    if (p > G::P - 1) p = G::P - 1;                   // clamped lanes are never stored
+    const float* bp = s_patch + kq * CQ * PLANE + (p / G::OH - oy0) * G::S * RP + (p % G::OH);
+    const float* ap = s_w + (ct * 16 + x) * WS + kq * KQ;
+    float bias4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = cout0 + ct * 16 + 4 * kq + r;
+      bias4[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+    }
+    rb_f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int jq = 0; jq < KQ / 4; ++jq) {
+      const float4 w4 = rb_ld4(ap + 4 * jq);
+      acc = rb_mfma16(w4.x, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], acc);
+      acc = rb_mfma16(w4.y, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)], acc);
+      acc = rb_mfma16(w4.z, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], acc);
+      acc = rb_mfma16(w4.w, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)], acc);
+    }
+    RB_CSTAMP(SB + 2);
+    RB_WGT(WK, wgi, 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                     // D[r]: channel 4 kq + r of the tile, position x
+      const int m = cout0 + ct * 16 + 4 * kq + r;
+      if (pv && m < a.cout) {
+        const float o = fmaxf(acc[r] + bias4[r], 0.0f);
+        a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+        if (a.out_blocked) {
+          const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+          a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+        }
+      }
+    }
+    RB_CSTAMP(SB + 3);
+    RB_CSTAMP_LAST(SB + 5);
+    RB_WGT(WK, wgi, 5);
+    RB_WGT(WK, wgi, 6);
+    return;
+  }
   // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW) of the padded reduction (weights beyond K are zero)
   const int kb = wave * KW;
   int noff[NT];
@@ -481,10 +517,10 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
   const int kh = lane >> 5, ml = lane & 31;
-  float bias_r[(16 * 64) / RB_CONV_THREADS];          // the epilogue's bias terms (its rows do not depend on the tile)
+  float bias_r[(16 * 64) / THREADS];          // the epilogue's bias terms (its rows do not depend on the tile)
 #pragma unroll
-  for (int it = 0; it < (16 * 64) / RB_CONV_THREADS; ++it) {
-    const int idx = t + it * RB_CONV_THREADS;
+  for (int it = 0; it < (16 * 64) / THREADS; ++it) {
+    const int idx = t + it * THREADS;
     const int m = cout0 + rb_mfma_row(idx >> 6, idx & 63);
     bias_r[it] = a.bias[net][m < a.cout ? m : a.cout - 1];
   }
@@ -492,7 +528,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   // (offset -> operand address) on the critical path of every step (measured 7.1 us of MFMA phase for 5.1 us of MFMAs)
   int kos[HW];
 #pragma unroll
-  for (int j = 0; j < HW; ++j) kos[j] = s_koff[WREG ? kb + kh * HW + j : kb + 2 * j + kh];
+  for (int j = 0; j < HW; ++j) kos[j] = s_koff[kb + 2 * j + kh];
   // A operand: row ml, column k = kb + 2 j + kh of the row-major slab.  The row stride is a multiple of 4 (16-byte staging
   // stores), so 32 lanes reading one column would meet in 8 banks, four deep; with the swizzle rows ml, ml + 8, ml + 16, ml + 24
   // keep that column in four different words of its group: conflict-free.  kb % 4 == 0: two lane constants, immediate offsets.
@@ -502,8 +538,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
 #pragma unroll
   for (int j = 0; j < HW; ++j) {
     float av;
-    if constexpr (WREG) av = areg[j];
-    else if constexpr (KW % 4 == 0) av = s_w[((j & 1) ? a_odd : a_even) + 4 * (j >> 1)];
+    if constexpr (KW % 4 == 0) av = s_w[((j & 1) ? a_odd : a_even) + 4 * (j >> 1)];
     else av = s_w[ml * WS + rb_wswz(ml, kb + 2 * j + kh)];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_patch[noff[nt] + kos[j]], acc[nt]);
@@ -513,7 +548,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   // cross-wave sum, fixed order w0..w7.  Where the operand area is large enough for the partial sums of ALL NT tiles
   // (the later layers: 2-3 x 32 KB inside 97-118 KB) they are exchanged in one pass — two barriers instead of 2 NT; the
   // first layer keeps one 32 KB tile at a time (its LDS footprint decides how many workgroups share a CU).
-  constexpr int EIT = (16 * 64) / RB_CONV_THREADS;
+  constexpr int EIT = (16 * 64) / THREADS;
   constexpr bool ONEPASS = NT * SZ::RED <= SZ::WSZ;
   constexpr int TP = ONEPASS ? NT : 1;                  // tiles per pass
 #pragma unroll
@@ -529,7 +564,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
       const int nt = nt0 + u;
 #pragma unroll
       for (int it = 0; it < EIT; ++it) {
-        const int idx = t + it * RB_CONV_THREADS;
+        const int idx = t + it * THREADS;
         const int l = idx & 63, r = idx >> 6;
         float v = s_all[u * SZ::RED + (0 * 16 + r) * 64 + l];
 #pragma unroll
@@ -539,8 +574,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
         if (m < a.cout && p < G::P && p < p0 + PCH) {
           const float o = fmaxf(v + bias_r[it], 0.0f);      // (bias fetched before the MFMA loop: a global load here sat on
                                                             //  the critical path of every tile's epilogue)
-          if constexpr ((COH & 2) != 0) rb_st1_wt(a.out, 4u * (unsigned)((img * a.cout + m) * G::P + p), o);
-          else a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+          a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
           if (a.out_blocked) {
             const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
             a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
@@ -552,73 +586,28 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   RB_CSTAMP(SB + 3);
   RB_CSTAMP_LAST(SB + 5);
   RB_WGT(WK, wgi, 5);
-  if (link.done_ctr) rb_chain_signal<(COH & 2) != 0>(link.done_ctr);
   RB_WGT(WK, wgi, 6);
 }
 
 // (second launch bound = waves per SIMD: a 512-thread workgroup is 2; 4 where the LDS footprint lets two workgroups share a
 // CU — the first layer on u8 frames — so that the register allocation does too; the float-input variant of the acting path
 // would spill under that cap, and no kernel of this library may carry a scratch segment)
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false, bool F32SRC = false>
-__global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS * 4 <= 80 * 1024 && !F32SRC) ? 4 : 2) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, WREG>::FLOATS];
-  const ChainLink none{nullptr, 0u, nullptr, nullptr};
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false>
+__global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX>::FLOATS * 4 <= 80 * 1024 && !F32SRC) ? 4 : 2) void k_conv_fwd_lds(ConvLdsFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX>::FLOATS];
   // img_fast: workgroups are spread over the 8 XCDs by linear block index mod 8; with the image as the fastest index (and an
   // image count that is a multiple of 8) every workgroup of image i, in every layer, runs on XCD i mod 8 — the next layer's
   // input is then in that XCD's own L2 instead of behind the fabric
-  if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG, 0, F32SRC>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem, none);
-  else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, WREG, 0, F32SRC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem, none);
+  if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
+  else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
-// The whole conv stack of the learn step in ONE launch at small batches (<= 96 images): block ranges [layer 0 | layer 1 |
-// layer 2], image-major inside a range.  A layer's workgroup for image i depends only on the previous layer's workgroups
-// of the SAME image, so instead of two kernel boundaries (each a full drain, an L2 write-back / invalidate and ~4.7 us of
-// dispatch floor on this part) it waits on image i's arrival counter — after it has staged its weight slab and tap
-// table, which do not depend on the producer.  Workgroups are dispatched in index order, so by the time a layer-1
-// workgroup occupies a CU every layer-0 workgroup is resident or finished (rb_device.h rb_chain_*).
-struct ConvFwdChainArgs {
-  ConvLdsFwdArgs layer[3];
-  int nblocks[3];            // workgroups of each layer
-  int per_img[3];            // workgroups per image (= arrivals that complete an image of that layer)
-  int cotiles[3];
-  unsigned* done[3];         // [images] arrival counters of each layer's output (monotonic across launches)
-  unsigned epoch;            // this launch's number (1-based): an image of layer l is final at done[l][img] == epoch * per_img[l]
-  unsigned* err;
-};
-// SC1: hand-offs by write-through stores + agent-coherent loads (no fences); else release / acquire fences.
-template <class G0, int NT0, int PR0, int K0, int PCH0, class G1, int NT1, int PR1, int K1, class G2, int NT2, int PR2, int K2, int NL, bool SC1>
-__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_chain(ConvFwdChainArgs a) {
-  typedef ConvFwdLdsSize<G0, NT0, PR0, K0> S0;
-  typedef ConvFwdLdsSize<G1, NT1, PR1, K1> S1;
-  typedef ConvFwdLdsSize<G2, NT2, PR2, K2> S2;
-  constexpr int M01 = S0::FLOATS > S1::FLOATS ? S0::FLOATS : S1::FLOATS;
-  constexpr int MAXF = (NL > 2 && S2::FLOATS > M01) ? S2::FLOATS : M01;
-  __shared__ __attribute__((aligned(16))) float smem[MAXF];
-  int b = (int)blockIdx.x;
-  if (b < a.nblocks[0]) {                               // decode: position chunk fastest, then cout tile, then image
-    constexpr int CH = (G0::P + PCH0 - 1) / PCH0;
-    const int img = b / a.per_img[0], r = b - img * a.per_img[0];
-    const ChainLink link{nullptr, 0u, a.done[0] + img, a.err};
-    rb_conv_fwd_body<G0, NT0, PR0, K0, true, PCH0, false, SC1 ? 2 : 0>(a.layer[0], r % CH, r / CH, img, smem, link);
-    return;
-  }
-  b -= a.nblocks[0];
-  if (NL == 2 || b < a.nblocks[1]) {
-    constexpr int CH = (G1::P + 32 * NT1 - 1) / (32 * NT1);
-    const int img = b / a.per_img[1], r = b - img * a.per_img[1];
-    // (nblocks[0] == 0: the first layer ran as a launch of its own — nothing to wait for)
-    const ChainLink link{a.nblocks[0] > 0 ? a.done[0] + img : nullptr, a.epoch * (unsigned)a.per_img[0], NL > 2 ? a.done[1] + img : nullptr, a.err};
-    if (a.nblocks[0] > 0) rb_conv_fwd_body<G1, NT1, PR1, K1, false, 32 * NT1, false, SC1 ? (NL > 2 ? 3 : 1) : 0>(a.layer[1], r % CH, r / CH, img, smem, link);
-    else rb_conv_fwd_body<G1, NT1, PR1, K1, false, 32 * NT1, false, SC1 ? (NL > 2 ? 2 : 0) : 0>(a.layer[1], r % CH, r / CH, img, smem, link);
-    return;
-  }
-  if (NL > 2) {
-    b -= a.nblocks[1];
-    constexpr int CH = (G2::P + 32 * NT2 - 1) / (32 * NT2);
-    const int img = b / a.per_img[2], r = b - img * a.per_img[2];
-    const ChainLink link{a.done[1] + img, a.epoch * (unsigned)a.per_img[1], nullptr, a.err};
-    rb_conv_fwd_body<G2, NT2, PR2, K2, false, 32 * NT2, false, SC1 ? 1 : 0>(a.layer[2], r % CH, r / CH, img, smem, link);
-  }
+// the t16 variant (rb_conv_fwd_body<..., T16 = true>): grid as k_conv_fwd_lds, block = 64 * (2 * ceil(PCH / 16)) threads
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false>
+__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, true>::NWV)) void k_conv_fwd_t16(ConvLdsFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, true>::FLOATS];
+  if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC, true>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
+  else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC, true>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
 // ---- large batches: one weight slab per workgroup, a loop over images -----------------------------------------
@@ -1031,7 +1020,6 @@ struct ConvLdsDxArgs {
   int64_t dy_stride;     // floats between partials
   int dy_splits;
   int ipb, batch;        // MULTI instantiation: images per workgroup (grid z = ceil(batch / ipb)), image count
-  int wt;                // write-through stores (strided phases: see rb_st1_wt)
   int img_fast;          // grid = (image groups, channel tiles, phase x position groups): see k_conv_fwd_lds
 };
 
@@ -1116,7 +1104,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 
   // dY of an image: global loads into registers (issue), LDS stores later (commit) — with MULTI the next image's loads
   // are in flight under this image's MFMA loop and reduction
-  // The staging of these kernels is INSTRUCTION-bound, not memory-bound (fine-grained stamps, tools/_fine_dx.py: 7.5 us from
+  // The staging of these kernels is INSTRUCTION-bound, not memory-bound (fine-grained stamps, tools/stamp/fine_dx.py: 7.5 us from
   // workgroup start to the first MFMA with every load landed at 3.3 us — two waves per SIMD executing ~2000 VALU
   // instructions of index arithmetic each).  So: only the INTERIOR cells of dY are loaded and stored (contiguous in memory:
   // no halo-indexed gather), the zero halo is one block of 16-byte stores at kernel start, all offsets are 32-bit and go
@@ -1339,8 +1327,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       for (int wv = 1; wv < RB_CONV_WAVES; ++wv) v += s_red[((wv * NT + nt) * 16 + r) * 64 + l];
       if (eoff[it] >= 0) {
         const float o = mask[it] > 0.0f ? v : 0.0f;
-        if (a.wt) rb_st1_wt(dxi, 4u * (unsigned)eoff[it], o);            // uniform
-        else dxi[eoff[it]] = o;
+        dxi[eoff[it]] = o;
       }
     }
   }
@@ -1599,12 +1586,6 @@ __device__ __forceinline__ void rb_conv_dw_body(const ConvLdsDwArgs& a, int chun
 #endif
   RB_WGT(5, wgi, 5);
   RB_WGT(5, wgi, 6);
-}
-
-template <class G, int RC, int KMAX, bool FIRST>
-__global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_lds(ConvLdsDwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[ConvDwLdsSize<G, RC, KMAX>::FLOATS];
-  rb_conv_dw_body<G, RC, KMAX, FIRST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, 1, (int)gridDim.z, smem);
 }
 
 // Every conv layer's weight gradient in ONE launch (they only feed the optimiser and are independent of each other

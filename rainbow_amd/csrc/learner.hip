@@ -48,13 +48,14 @@ extern "C" int rb_debug_wgtrace(long long* out, int clear) {
   return 0;
 }
 #endif
-#define RB_CHAIN_ARRAYS 8     // per-image arrival counter arrays of the chained conv launches (3 forward, up to 5 backward)
 #define RB_HEAD_MAX_NZ 1408   // 3 logit rows of this many floats live in the head kernel's LDS (18 actions x 51 atoms = 969)
 typedef ConvGeom<8, 4, 84, 20> GeomC1;   // model.py:56
 typedef ConvGeom<4, 2, 20, 9> GeomC2;    // model.py:57
 typedef ConvGeom<3, 1, 9, 7> GeomC3;     // model.py:58
 typedef ConvGeom<5, 5, 84, 16> GeomD1;   // model.py:61
 typedef ConvGeom<5, 5, 16, 3> GeomD2;    // model.py:62
+// geometries of the LAST conv layer of their network (its output is the feature vector of the hidden layer)
+#define RB_LAST_CONV_GEOM(G) (G::KS == 3 || (G::KS == 5 && G::IH == 16))
 
 struct ConvLayer {
   int cin, cout, ks, s, ih, oh;
@@ -153,15 +154,16 @@ struct rb_learner {
   float *feat_b, *h_b;  // k-blocked copies of feat [NI][F] and h [NI][2H] for the streamed forward kernels
   float* logits;        // [NI][NZ]
   float* dlogits;       // [B][NZ]
-  float* dlogitsT;      // [NZ][B] (RB_Z_DYT=0: not written)
+  float* dlogitsT;      // [NZ][B]: the same, transposed (the output layer's input gradient reads its dY operand from it)
   float* dh;            // [B][2H]
   float* dhT;           // [2H][B]: the same, transposed (the hidden layer's input gradient reads its dY operand from it)
   float* dfeat_part;    // [xs][B][F]
   int lazy_dfeat;       // this step: the last conv layer's backward kernels sum the partials themselves (no k_dfeat_finish)
   int lazy_splits;
-  // A/B and test switches read ONCE, when the handle is created (not per launch): RB_CONV_MULTI (-1 = by image count),
-  // RB_CONV_FULL, RB_DX_IPB (0 = by batch), RB_DX_WT
-  int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_dx_wt;
+  // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
+  // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
+  int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_img_fast;
+  int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   float* dw_part[3];    // [ws_l][cout][K+1]
   float* log_ps_a;      // [B][Z]
   float* pns_a;         // [B][Z]
@@ -174,14 +176,6 @@ struct rb_learner {
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   NoiseJob* job_dev;               // [3] device copies of the noise jobs (rb_learner_noise_job), uploaded on request
-  // in-launch dataflow of the conv stack at small batches (conv_lds.h k_conv_fwd_chain / k_conv_bwd_chain): arrival
-  // counters [8][3B] (monotonic: one epoch per launch, never reset), the launch numbers, an error word the kernels set
-  // when a bounded spin expires
-  unsigned* chain_ctr;
-  unsigned chain_epoch_fwd, chain_epoch_bwd;
-  int opt_chain;        // RB_CONV_CHAIN (A/B switch, read once): 0 = one launch per layer
-  int opt_img_fast;     // RB_CONV_IMGFAST (A/B switch, read once)
-  int opt_dw_wide, opt_dx_wide;   // RB_DW_WIDE / RB_DX_WIDE: the large-batch hidden-layer backward kernels (opt-in)
   int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
@@ -193,10 +187,6 @@ struct rb_learner {
   const int64_t* sink_idx;
   int fast_fc;          // streamed 16x16x4 noisy-linear kernels usable (alignment preconditions hold)
   int fast_conv;        // LDS-resident conv kernels usable (history <= 4, standard channel counts)
-  // backward fork/join: weight-gradient kernels run on side streams next to the input-gradient chain
-  int use_side;
-  hipStream_t side[2];
-  hipEvent_t ev[8];
   // replica exchange: world > 1 defers the noisy-linear WEIGHT gradients — instead of all-reducing 27 MB of
   // gradient, the replicas all-gather the two factors of every FC gradient (dY and X rows, 0.7 MB per rank) and each
   // computes the replica-mean gradient from the gathered rows itself (rb_learner_finish_grads)
@@ -884,7 +874,7 @@ static int launch_conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const I
   return RB_OK;
 }
 
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool WREG = false>
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT>
 static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                                const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
@@ -918,8 +908,8 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
       return RB_OK;
     }
   }
-  if constexpr (ConvFwdMultiLds<G, PR, KMAX>::FITS) {
-    if (ipb > 0 && !(FIRST && src.f32)) {
+  if constexpr (!FIRST && ConvFwdMultiLds<G, PR, KMAX>::FITS) {      // (first layers: k_conv_fwd_full above)
+    if (ipb > 0) {
       a.ipb = ipb;
       const unsigned ngroups = (unsigned)rb_div_up(n_on + n_tg, ipb);
       dim3 gridm((unsigned)rb_div_up(G::P, PCH), (unsigned)rb_div_up(c.cout, 32), ngroups);
@@ -937,10 +927,19 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
     a.img_fast = 1;
     grid1 = dim3((unsigned)(n_on + n_tg), (unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(G::P, PCH));
   }
+  if constexpr (KMAX % 16 == 0 && (KMAX / G::KK) % 4 == 0 && 2 * ((PCH + 15) / 16) <= 16 && (PCH % 16 == 0 || PCH >= G::P) && G::P > 16) {
+    // whole-K 16x16x4 tiles, one wave per tile, no cross-wave reduction (conv_lds.h T16): the learn step's u8 / f32 inputs
+    if (((l->opt_t16 >> layer) & 1) && !(FIRST && src.f32) && c.cin * G::KK == KMAX && c.cout % 32 == 0) {
+      constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, true>::NWV;
+      RB_LAUNCH_T(tags[layer], (k_conv_fwd_t16<G, NT, PR, KMAX, FIRST, PCH>), grid1, dim3(64 * NWV), stream, a);
+      RB_LAUNCH_CHECK();
+      return RB_OK;
+    }
+  }
   if (FIRST && src.f32) {       // float states (act / evaluate): an instantiation of its own (conv_lds.h F32SRC)
-    RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG, FIRST>), grid1, dim3(RB_CONV_THREADS), stream, a);
+    RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, FIRST>), grid1, dim3(RB_CONV_THREADS), stream, a);
   } else {
-    RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH, WREG>), grid1, dim3(RB_CONV_THREADS), stream, a);
+    RB_LAUNCH_T(tags[layer], (k_conv_fwd_lds<G, NT, PR, KMAX, FIRST, PCH>), grid1, dim3(RB_CONV_THREADS), stream, a);
   }
   RB_LAUNCH_CHECK();
   return RB_OK;
@@ -949,27 +948,11 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
 static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on,
                     const NetPtrs& tg, hipStream_t stream) {
   const ConvLayer& c = l->L.conv[layer];
-  // Weight operand in registers instead of LDS (conv_lds.h WREG): two workgroups share a CU, no transposing LDS stores.
-  // Pays once there are at least two workgroups per CU to overlap — batch 256 (768 images): conv forward 93 / 81 / 79 ->
-  // 78 / 72 / 65 us, step 733 -> 691 us — and LOSES at batch 32 (96 images, 192-480 workgroups: nothing to overlap with,
-  // and 64 lanes fetching 64 different weight lines per instruction cost more than the LDS round trip: conv2 17.6 ->
-  // 19.0 us).  So: by image count; RB_CONV_WREG=0/1 forces it for A/B runs.
-  static const int wreg_env = getenv("RB_CONV_WREG") ? atoi(getenv("RB_CONV_WREG")) : -1;
-  const bool wreg = wreg_env >= 0 ? wreg_env != 0 : (n_on + n_tg) >= 256;
-  if (l->fast_conv && wreg) {
-    if (c.ks == 8) return launch_conv_fwd_lds<GeomC1, 3, 20, 256, true, 80, true>(l, layer, n_on, n_tg, src, on, tg, stream);
-    if (c.ks == 4) return launch_conv_fwd_lds<GeomC2, 3, 20, 512, false, 96, true>(l, layer, n_on, n_tg, src, on, tg, stream);
-    if (c.ks == 3) return launch_conv_fwd_lds<GeomC3, 2, 9, 576, false, 64, true>(l, layer, n_on, n_tg, src, on, tg, stream);
-    if (c.ih == 84) return launch_conv_fwd_lds<GeomD1, 2, 20, 100, true, 64, true>(l, layer, n_on, n_tg, src, on, tg, stream);
-    return launch_conv_fwd_lds<GeomD2, 1, 16, 800, false, 32, true>(l, layer, n_on, n_tg, src, on, tg, stream);
-  }
   if (l->fast_conv) {
     if (c.ks == 8) {
       // 80 positions (4 output rows) per workgroup: 5 x 96 = 480 workgroups at batch 32, one round at two per CU
       // (64 positions gave 672, the seventh chunk of each image nearly empty: 224.4 vs 222.6 us per step; 100 positions
-      // = 384 workgroups measured 225); RB_CONV1_PCH=64 restores the former shape for A/B
-      static const bool old64 = getenv("RB_CONV1_PCH") && atoi(getenv("RB_CONV1_PCH")) == 64;
-      if (old64) return launch_conv_fwd_lds<GeomC1, 2, 20, 256, true>(l, layer, n_on, n_tg, src, on, tg, stream);
+      // = 384 workgroups measured 225)
       return launch_conv_fwd_lds<GeomC1, 3, 20, 256, true, 80>(l, layer, n_on, n_tg, src, on, tg, stream);
     }
     if (c.ks == 4) return launch_conv_fwd_lds<GeomC2, 3, 20, 512, false>(l, layer, n_on, n_tg, src, on, tg, stream);
@@ -982,68 +965,6 @@ static int conv_fwd(rb_learner* l, int layer, int n_on, int n_tg, const ImgSrc& 
   if (c.ks == 3) return launch_conv_fwd<GeomC3>(l, layer, n_on, n_tg, src, on, tg, stream);
   if (c.ih == 84) return launch_conv_fwd<GeomD1>(l, layer, n_on, n_tg, src, on, tg, stream);
   return launch_conv_fwd<GeomD2>(l, layer, n_on, n_tg, src, on, tg, stream);
-}
-
-// The chained conv launches run the learn step's geometry only (3B images, u8 frames: the arrival counters advance by one
-// epoch per launch for exactly those images), at batches whose per-image workgroups are what fills the chip, and never
-// under stream capture (the launch number is a by-value argument: a replayed graph would wait for a stale epoch).
-static bool conv_chain_usable(rb_learner* l, int NI, const ImgSrc& src, hipStream_t stream) {
-  if (!l->opt_chain || !l->fast_conv || !l->chain_ctr || src.f32 || NI != 3 * l->L.B || NI > 96) return false;
-#if !defined(RB_HOST_INTERP)
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
-#else
-  (void)stream;
-#endif
-  return true;
-}
-
-static int conv_fwd_chain(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const NetPtrs& on, const NetPtrs& tg,
-                          hipStream_t stream) {
-  const Layout& L = l->L;
-  const int NI = n_on + n_tg;
-  ConvFwdChainArgs c;
-  memset(&c, 0, sizeof(c));
-  // position-chunk sizes of the per-layer launches (conv_fwd above): C1 80, C2 96, C3 64, D1 64, D2 32
-  const int pch[2][3] = {{80, 96, 64}, {64, 32, 32}};
-  unsigned total = 0;
-  for (int i = 0; i < L.nconv; ++i) {
-    const ConvLayer& cl = L.conv[i];
-    ConvLdsFwdArgs& a = c.layer[i];
-    a.cin = cl.cin; a.cout = cl.cout; a.n_on = n_on;
-    a.w[0] = on.conv_w[i]; a.w[1] = tg.conv_w[i]; a.bias[0] = on.conv_b[i]; a.bias[1] = tg.conv_b[i];
-    a.src = src; a.in_f = i > 0 ? l->act[i - 1] : nullptr; a.out = l->act[i];
-    a.out_blocked = (i == L.nconv - 1 && l->fast_fc) ? l->feat_b : nullptr;
-    a.rows_total = NI; a.ipb = 1; a.img_fast = 0;
-    c.cotiles[i] = (int)rb_div_up(cl.cout, 32);
-    c.per_img[i] = (int)rb_div_up(cl.P(), pch[L.nconv == 3 ? 0 : 1][i]) * c.cotiles[i];
-    c.nblocks[i] = c.per_img[i] * NI;
-    c.done[i] = l->chain_ctr + (int64_t)i * NI;
-    total += (unsigned)c.nblocks[i];
-  }
-  for (int i = L.nconv; i < 3; ++i) { c.layer[i] = c.layer[0]; c.nblocks[i] = 0; c.per_img[i] = 1; c.cotiles[i] = 1; c.done[i] = c.done[0]; }
-  c.epoch = l->chain_epoch_fwd + 1;
-  c.err = l->chain_ctr + (int64_t)RB_CHAIN_ARRAYS * NI;
-  // RB_CONV_CHAIN: 1 = hand-offs by release / acquire fences, 2 = by write-through stores + coherent loads (default),
-  // 3 = as 2 with the first layer as a launch of its own (it runs two workgroups per CU there; the chain's LDS footprint
-  // — the largest of its layers — allows one)
-  const bool sc1 = l->opt_chain >= 2;
-  if (l->opt_chain == 3) {
-    int rc = conv_fwd(l, 0, n_on, n_tg, src, on, tg, stream);
-    if (rc != RB_OK) return rc;
-    total -= (unsigned)c.nblocks[0];
-    c.nblocks[0] = 0;
-  }
-  if (L.nconv == 3) {
-    if (sc1) { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomC1, 3, 20, 256, 80, GeomC2, 3, 20, 512, GeomC3, 2, 9, 576, 3, true>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
-    else { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomC1, 3, 20, 256, 80, GeomC2, 3, 20, 512, GeomC3, 2, 9, 576, 3, false>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
-  } else {
-    if (sc1) { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomD1, 2, 20, 100, 64, GeomD2, 1, 16, 800, GeomD2, 1, 16, 800, 2, true>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
-    else { RB_LAUNCH_T("conv_fwd_chain", (k_conv_fwd_chain<GeomD1, 2, 20, 100, 64, GeomD2, 1, 16, 800, GeomD2, 1, 16, 800, 2, false>), dim3(total), dim3(RB_CONV_THREADS), stream, c); }
-  }
-  RB_LAUNCH_CHECK();
-  l->chain_epoch_fwd += 1;
-  return RB_OK;
 }
 
 static NlWeights nl_h(const NetPtrs& p) {
@@ -1062,14 +983,9 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
                    hipStream_t stream) {
   const Layout& L = l->L;
   const int NI = n_on + n_tg;
-  if (conv_chain_usable(l, NI, src, stream)) {
-    int rc = conv_fwd_chain(l, n_on, n_tg, src, on, tg, stream);
+  for (int layer = 0; layer < L.nconv; ++layer) {
+    int rc = conv_fwd(l, layer, n_on, n_tg, src, on, tg, stream);
     if (rc != RB_OK) return rc;
-  } else {
-    for (int layer = 0; layer < L.nconv; ++layer) {
-      int rc = conv_fwd(l, layer, n_on, n_tg, src, on, tg, stream);
-      if (rc != RB_OK) return rc;
-    }
   }
   const float* feat = l->act[L.nconv - 1];
   const int m_max = n_on > n_tg ? n_on : n_tg;
@@ -1089,27 +1005,13 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     a.grp[0] = NlRowGroup{0, L.H, 0, 0, 0};
     a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, ht16};
     a.out = l->h; a.out_blocked = l->h_b; a.ld_out = 2 * L.H; a.rows_total = NI; a.relu = 1;
-    static const int wide_env = getenv("RB_FWD_WIDE") ? atoi(getenv("RB_FWD_WIDE")) : -1;   // A/B switch (1: 64-row m-chunks at any batch)
-    const bool wide = wide_env >= 0 ? (wide_env != 0 && m_max >= 64) : m_max >= 128;     // batch 256: 64-row m-chunks halve the passes over the weights
+    // batch 256: 64-row m-chunks halve the passes over the weights (at batch 32 one 64-row chunk for the online net's rows
+    // reads every tile once instead of twice and is 7 us per step SLOWER: a workgroup's MFMAs are serial on its CU)
+    const bool wide = m_max >= 128;
     const unsigned mch32 = (unsigned)rb_div_up(m_max, wide ? 64 : RB_FWD2_MROWS);
-    static const int abl = getenv("RB_FWD2_ABLATE") ? atoi(getenv("RB_FWD2_ABLATE")) : 0;   // tools/gpu_ablate.sh only
     const dim3 hg((unsigned)(2 * ht16), 1, 2 * mch32), hb(64 * RB_NL_FWD_WAVES);
-    switch (abl) {
-      case 1: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<1>, hg, hb, stream, a); break;
-      case 2: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<2>, hg, hb, stream, a); break;
-      case 3: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<3>, hg, hb, stream, a); break;
-      case 4: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<4>, hg, hb, stream, a); break;
-      case 7: RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<7>, hg, hb, stream, a); break;
-      default: {
-        static const bool fwd3 = !(getenv("RB_FWD3") && getenv("RB_FWD3")[0] == '0');   // A/B switch (0 = k_nl_fwd2)
-        if (fwd3) {
-          if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
-          else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a); }
-        } else if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), hg, hb, stream, a); }
-        else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd2", k_nl_fwd2<0>, hg, hb, stream, a); }
-        break;
-      }
-    }
+    if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
+    else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a); }
     RB_LAUNCH_CHECK();
     // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
     NlFwd2Args z;
@@ -1121,16 +1023,9 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
     z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
-    static const bool zfwd3 = !(getenv("RB_FWD3") && getenv("RB_FWD3")[0] == '0');
     const dim3 zgrid((unsigned)(vt16 + at16), 1, 2 * mch32), zblock(64 * RB_NL_FWD_WAVES);
-    if (zfwd3) {
-      if (wide) { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<4>, zgrid, zblock, stream, z); }
-      else { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<2>, zgrid, zblock, stream, z); }
-    } else if (wide) {
-      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", (k_nl_fwd2<0, 4>), zgrid, zblock, stream, z);
-    } else {
-      RB_LAUNCH_T("fc_z_fwd:k_nl_fwd2", k_nl_fwd2<0>, zgrid, zblock, stream, z);
-    }
+    if (wide) { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<4>, zgrid, zblock, stream, z); }
+    else { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<2>, zgrid, zblock, stream, z); }
     RB_LAUNCH_CHECK();
     return RB_OK;
   }
@@ -1169,18 +1064,7 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   float* gw = l->grads + L.conv_w[layer];
   float* gb = l->grads + L.conv_b[layer];
   const int splits = l->ws[layer];
-  int lds_slices = 0;
   if (!(mode & 1)) {
-  } else if (layer == 0 && l->fast_conv && (G::IH == 84)) {
-    constexpr int RC = G::KS == 8 ? 5 : 4;            // output rows per chunk (100 / 64 positions)
-    constexpr int KMAXW = 4 * G::KK;
-    constexpr int CHUNKS = (G::OH + RC - 1) / RC;
-    ConvLdsDwArgs a;
-    a.cin = c.cin; a.cout = c.cout; a.dy = l->dact[0]; a.src = l->cur_src; a.x_f = nullptr; a.part = l->dw_part[0];
-    a.dy_part = nullptr; a.dy_mask = nullptr; a.dy_stride = 0; a.dy_splits = 0;
-    RB_LAUNCH((k_conv_dw_lds<G, RC, KMAXW, true>), dim3((unsigned)CHUNKS, (unsigned)rb_div_up(c.cout, 32), (unsigned)L.B),
-              dim3(RB_CONV_THREADS), stream, a);
-    lds_slices = L.B * CHUNKS;
   } else if (layer == 0) {
     ConvDwProb<G, true> p;
     p.B = L.B; p.cin = c.cin; p.cout = c.cout; p.splits = splits;
@@ -1196,17 +1080,19 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   }
   if (mode & 1) {
     RB_LAUNCH_CHECK();
-    l->dw_slices[layer] = lds_slices ? lds_slices : splits;   // summed by k_reduce_conv_dw_all after the last layer
+    l->dw_slices[layer] = splits;   // summed by k_reduce_conv_dw_all after the last layer
     (void)gw; (void)gb;
   }
   if (!(mode & 2)) return RB_OK;
   if constexpr (G::IH == 84) {
     // first-layer geometries never need a data gradient (frames are not differentiated)
-  } else if (layer > 0 && l->fast_conv) {
+  } else if (layer > 0 && l->fast_conv && ((l->lazy_dfeat && layer == L.nconv - 1) == RB_LAST_CONV_GEOM(G))) {
+    // (the last layer's LDS kernel exists in its LAZY form only — dY summed from the hidden layer's row-split partials while
+    // it is staged; when those are not what the step produced, i.e. the generic FC path ran, the generic kernel below runs)
     ConvLdsDxArgs a;
     a.cin = c.cin; a.cout = c.cout;
     a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
-    const bool lazy = l->lazy_dfeat && layer == L.nconv - 1;
+    constexpr bool lazy = RB_LAST_CONV_GEOM(G);
     a.dy_part = l->dfeat_part; a.dy_mask = l->act[layer]; a.dy_stride = (int64_t)L.B * L.F; a.dy_splits = lazy ? l->lazy_splits : 0;
     constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
     constexpr int NT_ALL = (NPOS + 31) / 32;
@@ -1223,24 +1109,18 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
       while (per_img * (int)rb_div_up(L.B, ipb) > 256) ++ipb;
       // image-group-fastest order wants a group count that is a multiple of 8 — and the same groups as the next layer's launch and
       // the weight-gradient launch (8 images each at batch 256), so that a group's dY stays in one XCD's L2 down the chain
-      if (l->opt_img_fast == 1)
+      if (l->opt_img_fast)
         while (ipb < L.B && (rb_div_up(L.B, ipb) % 8 != 0 || L.B % ipb != 0)) ++ipb;
     }
     a.ipb = ipb; a.batch = L.B;
-    a.wt = l->opt_dx_wt;
     dim3 grid((unsigned)(G::S * G::S) * groups, (unsigned)rb_div_up(c.cin, 32), (unsigned)rb_div_up(L.B, ipb));
     a.img_fast = 0;
-    if (l->opt_img_fast == 1 && L.B % ipb == 0 && (L.B / ipb) % 8 == 0) {      // image(-group)-fastest block order: image i on XCD i mod 8 in every conv launch
+    if (l->opt_img_fast && L.B % ipb == 0 && (L.B / ipb) % 8 == 0) {      // image(-group)-fastest block order: image i on XCD i mod 8 in every conv launch
       a.img_fast = 1;
       grid = dim3((unsigned)(L.B / ipb), (unsigned)rb_div_up(c.cin, 32), (unsigned)(G::S * G::S) * groups);
     }
-    if (ipb > 1) {
-      if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
-      else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, false, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
-    } else {
-      if (lazy) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
-      else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64>), grid, dim3(RB_CONV_THREADS), stream, a); }
-    }
+    if (ipb > 1) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, lazy, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
+    else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, lazy, false>), grid, dim3(RB_CONV_THREADS), stream, a); }
     RB_LAUNCH_CHECK();
   } else if (layer > 0) {
     ConvDxProb<G> p;
@@ -1288,7 +1168,7 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   for (int i = L.nconv; i < 3; ++i) { a.nblocks[i] = 0; a.cotiles[i] = 1; a.layer[i] = a.layer[0]; }
   // image-fastest decode (an image group's workgroups of every layer on XCD group mod 8, where the input-gradient chain left
   // its dY): block ranges and the group count must be multiples of 8
-  a.img_fast = (l->opt_img_fast == 1 && groups % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
+  a.img_fast = (l->opt_img_fast && groups % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
   if (L.nconv == 3) {
     RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomC1, 7, GeomC2, 9, 512, GeomC3, 7, 576, 3>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
   } else {
@@ -1408,14 +1288,9 @@ int rb_learner_destroy(rb_learner_t* l) {
     if (*p) rb_dev_free(*p);
   if (l->a_star) rb_dev_free(l->a_star);
   if (l->noise_ctr) rb_dev_free(l->noise_ctr);
-  if (l->chain_ctr) rb_dev_free(l->chain_ctr);
   if (l->job_dev) rb_dev_free(l->job_dev);
   if (l->status_copy) rb_dev_free(l->status_copy);
   if (l->adam_args_dev) rb_dev_free(l->adam_args_dev);
-  if (l->use_side) {
-    for (int i = 0; i < 2; ++i) if (l->side[i]) (void)hipStreamDestroy(l->side[i]);
-    for (int i = 0; i < 8; ++i) if (l->ev[i]) (void)hipEventDestroy(l->ev[i]);
-  }
   delete l;
   return RB_OK;
 }
@@ -1447,28 +1322,24 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->delta_z = (float)(((double)cfg->v_max - (double)cfg->v_min) / (double)(cfg->atoms - 1));
   const int B = L.B, NI = 3 * B;
   // split-K factors: aim for >= ~2 workgroups per CU on the 256-CU part
-  const char* generic_only = getenv("RB_GENERIC_GEMM_ONLY");   // A/B switch: force the gemm_core fallback
-  l->fast_fc = (L.F % 32 == 0 && L.H % 32 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
-  l->fast_conv = (L.hist <= 4 && !(generic_only && generic_only[0] == '1')) ? 1 : 0;
-  {
-    const char* generic_fc = getenv("RB_GENERIC_FC");             // A/B switch: only the noisy-linear layers fall back
-    if (generic_fc && generic_fc[0] == '1') l->fast_fc = 0;
-    const char* e;
-    l->opt_conv_multi = (e = getenv("RB_CONV_MULTI")) ? atoi(e) : -1;
-    l->opt_conv_full = (e = getenv("RB_CONV_FULL")) ? (e[0] != '0') : 1;
-    l->opt_dx_ipb = (e = getenv("RB_DX_IPB")) ? atoi(e) : 0;
-    l->opt_dx_wt = (e = getenv("RB_DX_WT")) ? atoi(e) : 0;      // measured slower (batch 256: 45 -> 53 us): off
-    l->opt_dw_wide = (e = getenv("RB_DW_WIDE")) ? (e[0] == '1') : 0;
-    l->opt_dx_wide = (e = getenv("RB_DX_WIDE")) ? (e[0] == '1') : 0;
-    l->opt_img_fast = (e = getenv("RB_CONV_IMGFAST")) ? atoi(e) : 1;      // 0 off | 1 forward + input gradients | 2 forward only
-    l->opt_chain = (e = getenv("RB_CONV_CHAIN")) ? atoi(e) : 0;      // measured: 3 = -1.5 us per step, 2 = equal, 1 = +13 us (profiles/round3_chain_*): opt-in
-  }
+  // RB_OPTS (rb_common.h): generic=1 forces the gemm_core fallback for every contraction, generic=2 for the noisy-linear
+  // layers only (both exercised by the CPU tests); the rest are test hooks that force the large-batch paths onto small fixtures
+  const int generic = rb_opt("generic", 0);
+  l->fast_fc = (L.F % 32 == 0 && L.H % 32 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && generic == 0) ? 1 : 0;
+  l->fast_conv = (L.hist <= 4 && generic != 1) ? 1 : 0;
+  l->opt_conv_multi = rb_opt("conv_multi", -1);       // images per workgroup of the conv forward (-1: by image count)
+  l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
+  l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
+  l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
+  l->opt_t16 = rb_opt("t16", 6);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
     // input-gradient row splits: 256 weight rows per workgroup (64 per wave = 4 sixteen-row iterations); measured
     // 225.1 us per step against 228.3 with the former ~100-row splits (xs 10) and 239 without splitting
+    // (at most 4: the consumers of the partials — the last conv layer's dX and dW kernels — sum up to 4 of them while staging)
     l->xs = (int)rb_div_up(2 * L.H, 256);
-    if (getenv("RB_XS")) l->xs = atoi(getenv("RB_XS"));                 // A/B switch
+    if (l->xs > 4) l->xs = 4;
+    l->xs = rb_opt("xs", l->xs);
   } else {
     l->hs = pick_splits(rb_div_up(2 * B, 64) * rb_div_up(2 * L.H, 64) * 2, (L.F + 15) / 16, 512);
     l->xs = pick_splits(rb_div_up(B, 32) * rb_div_up(L.F, 64), (2 * L.H + 15) / 16, 512);
@@ -1505,7 +1376,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->h_b, (int64_t)NI * (2 * L.H + 16));
   RB_ALLOC(l->logits, (int64_t)NI * L.NZ);
   RB_ALLOC(l->dlogits, (int64_t)B * L.NZ);
-  if (!(getenv("RB_Z_DYT") && getenv("RB_Z_DYT")[0] == '0')) RB_ALLOC(l->dlogitsT, (int64_t)B * L.NZ);
+  RB_ALLOC(l->dlogitsT, (int64_t)B * L.NZ);
   RB_ALLOC(l->dh, (int64_t)B * 2 * L.H);
   RB_ALLOC(l->dhT, (int64_t)B * 2 * L.H);
   RB_ALLOC(l->dfeat_part, (int64_t)l->xs * B * L.F);
@@ -1519,21 +1390,9 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->noise_ctr, 4);
   RB_ALLOC(l->status_copy, 4);
   RB_ALLOC(l->adam_args_dev, (sizeof(ClipAdamArgs) + 3) / 4);
-  RB_ALLOC(l->chain_ctr, (int64_t)RB_CHAIN_ARRAYS * NI + 64);
 #undef RB_ALLOC
-  RB_HIP_TRY(hipMemset(l->chain_ctr, 0, ((size_t)RB_CHAIN_ARRAYS * NI + 64) * 4));
   RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
   RB_HIP_TRY(hipMemset(l->status_copy, 0, 16));
-  {
-    // measured on MI355X (gpurun_out/ab.log, round 1): cross-stream fork/join costs more than the overlap buys at
-    // batch 32 (eager 357 -> 380 us, graph 364 -> 430 us), so the side streams are opt-in.
-    const char* want_side = getenv("RB_SIDE_STREAMS");
-    l->use_side = (want_side && want_side[0] == '1') ? 1 : 0;
-    if (l->use_side) {
-      for (int i = 0; i < 2; ++i) RB_HIP_TRY(hipStreamCreateWithFlags(&l->side[i], hipStreamNonBlocking));
-      for (int i = 0; i < 8; ++i) RB_HIP_TRY(hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming));
-    }
-  }
   float sup[RB_MAX_ATOMS];
   linspace_f32(cfg->v_min, cfg->v_max, L.Z, sup);
   RB_HIP_TRY(hipMemcpy(l->support, sup, L.Z * sizeof(float), hipMemcpyHostToDevice));
@@ -1605,8 +1464,7 @@ int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_norm
 // covered, the caller falls back to the training kernels.
 static int act_forward_single(rb_learner* l, const float* state_dev, const NetPtrs& on, int noisy, hipStream_t stream) {
   const Layout& L = l->L;
-  static const bool off = getenv("RB_ACT_PATH") && getenv("RB_ACT_PATH")[0] == '0';
-  if (off || !l->fast_fc || (L.F & 3) || (L.H & 3)) return RB_ERR_STATE;   // RB_GENERIC_GEMM_ONLY=1 also lands here
+  if (!l->fast_fc || (L.F & 3) || (L.H & 3)) return RB_ERR_STATE;   // RB_GENERIC_GEMM_ONLY=1 also lands here
   int rg[3];
   for (int layer = 0; layer < L.nconv; ++layer) {   // output rows per workgroup: <= 128 positions, patch fits the LDS
     const ConvLayer& c = L.conv[layer];
@@ -1741,10 +1599,6 @@ static FcDwPlan fc_dw_plan(rb_learner* l, const NetPtrs& on, int which, const fl
     p.dw_y = 2 * ht;
   }
   p.dw_x = (int)rb_div_up(w.K, 256 * (ct > 0 ? ct : 1));
-  if (ct < 0) {              // 64 x 64 tiles (rb_nl_dw_body_wide): the caller checked K % 64 == 0 and 64-row problems
-    p.dw_x = w.K / 64;
-    p.dw_y = (w.prob[0].row_cnt + w.prob[1].row_cnt) / 64;
-  }
   p.slots = 4 * p.dw_x * p.dw_y;
   return p;
 }
@@ -1794,45 +1648,24 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
             l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status, l->status_copy, l->dlogitsT);
   RB_LAUNCH_CHECK();
 
-  // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the
-  // critical path; every weight-gradient kernel only feeds the optimiser, so those are forked onto two side
-  // streams (events below; captured as parallel graph branches under stream capture) and joined at the end.
-  const bool side = l->use_side && l->fast_fc;
-  hipStream_t s_fc = side ? l->side[0] : stream;     // fc weight grads
-  hipStream_t s_cv = side ? l->side[1] : stream;     // conv weight grads
-  int ev_i = 0;
-  auto fork = [&](hipStream_t to) -> int {
-    if (!side) return RB_OK;
-    RB_HIP_TRY(hipEventRecord(l->ev[ev_i], stream));
-    RB_HIP_TRY(hipStreamWaitEvent(to, l->ev[ev_i], 0));
-    ++ev_i;
-    return RB_OK;
-  };
+  // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the critical
+  // path; the weight-gradient work rides in the same launches as block ranges (side streams measured slower, round 1).
   const float* feat = l->act[L.nconv - 1];
   const bool exch = l->world > 1 && l->fact_local != nullptr && l->fast_fc;   // replica exchange: FC weight grads deferred
-  if (exch && side) { rb_set_error("rb_learner_learn: RB_SIDE_STREAMS and the replica exchange are mutually exclusive"); return RB_ERR_STATE; }
   l->exch_pending = 0;
   l->dw_deferred = 0;
   if (l->fast_fc) {
     // ---- output layer: weight/bias grads and (ReLU-masked) input grads in one launch
     // sum-of-squares slots (clip_grad_norm_ without re-reading the gradient): [fc_z dW waves | fc_h dW waves | conv reduce blocks]
     // pipelined weight-gradient body (one reduction pass per tile, i.e. batch <= 32): column tiles per wave
-    static const int ct_env = getenv("RB_DW_CT") ? atoi(getenv("RB_DW_CT")) : -1;      // A/B switch
-    const bool pipe = B <= 32 && !side && !exch;         // (the side-stream variant launches the plain k_nl_dw)
-    const int z_ct = pipe ? (ct_env >= 0 ? (ct_env > 2 ? 2 : ct_env) : 2) : 0;
-    // batch >= 64, RB_DW_WIDE=1: the hidden layer's weight gradient on LDS-shared 64 x 64 tiles as a launch of its own.
-    // Measured at batch 256 (profiles/round3_fc_bwd_b256_ab.txt): 26.2 us for the gradient alone (0.40 of f32 MFMA, against
-    // 0.31 for the fused launch as a whole) but the input-gradient part then runs alone for 45.5 us — 71.7 us in sequence
-    // against 67.4 us fused, where the two overlap.  Opt-in until the input-gradient part is rebuilt the same way.
-    const bool wide_off = !l->opt_dw_wide;
-    const bool h_wide = !pipe && !side && !exch && !wide_off && B >= 64 && L.F % 64 == 0 && L.H % 64 == 0;
-    const int h_ct = pipe ? (ct_env >= 0 ? ct_env : 4) : (h_wide ? -1 : 0);
+    const bool pipe = B <= 32 && !exch;
+    const int z_ct = pipe ? 2 : 0, h_ct = pipe ? 4 : 0;
     FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
     FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, feat, B, h_ct);
     int64_t conv_out = 0;
     for (int layer = 0; layer < L.nconv; ++layer) conv_out += (int64_t)L.conv[layer].cout * (L.conv[layer].K() + 1);
     const int c_slots = (int)rb_div_up(conv_out, 64);
-    const bool fuse_norm = !side && !exch && zp.slots + hp.slots + c_slots <= 16384;
+    const bool fuse_norm = !exch && zp.slots + hp.slots + c_slots <= 16384;
     NlDwArgs& zw = zp.a;
     NlDwArgs& hw_ = hp.a;
     const bool defer_dw = (l->flags & RB_LEARNER_FUSE_FC_H_DW) && pipe && h_ct > 0 && fuse_norm && l->fast_conv;
@@ -1849,8 +1682,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     zx.prob[1] = NlDxProblem{L.Z, L.NZ - L.Z, 1 << 30, L.H, L.H, L.H};
     zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
     zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
-    static const bool dyt_off = getenv("RB_DX_DYT") && getenv("RB_DX_DYT")[0] == '0';          // A/B switch
-    zx.dyT = l->dlogitsT; zx.ldyT = B; zx.outT = dyt_off ? nullptr : l->dhT;
+    zx.dyT = l->dlogitsT; zx.ldyT = B; zx.outT = l->dhT;
     NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
     // ---- hidden layer
     NlDxArgs hx;
@@ -1860,7 +1692,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hx.rows_per_split = (int)rb_div_up(rb_div_up(2 * L.H, l->xs), 16) * 16;
     const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
     hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
-    hx.dyT = dyt_off ? nullptr : l->dhT; hx.ldyT = B; hx.outT = nullptr;
+    hx.dyT = l->dhT; hx.ldyT = B; hx.outT = nullptr;
     NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : hp.dw_y, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
     NlPriorityUpdate up;
     memset(&up, 0, sizeof(up));
@@ -1871,22 +1703,11 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         return RB_ERR_STATE;
       }
     }
-    if (side) {   // opt-in side streams: weight grads beside the input-gradient chain
-      if ((rc = fork(s_fc)) != RB_OK) return rc;
-      RB_LAUNCH(k_nl_dw, dim3((unsigned)zg.dw_x, (unsigned)zg.dw_y), dim3(256), s_fc, zw);
-      RB_LAUNCH(k_nl_dx, dim3((unsigned)zg.dx_x, (unsigned)zg.dx_y, (unsigned)zg.dx_z), dim3(256), stream, zx);
-      if ((rc = fork(s_fc)) != RB_OK) return rc;
-      RB_LAUNCH_T("fc_h_dw:k_nl_dw", k_nl_dw, dim3((unsigned)hg.dw_x, (unsigned)hg.dw_y), dim3(256), s_fc, hw_);
-      RB_LAUNCH_T("fc_h_dx:k_nl_dx", k_nl_dx, dim3((unsigned)hg.dx_x, (unsigned)hg.dx_y, (unsigned)hg.dx_z), dim3(256), stream, hx);
-    } else {
+    {
       NlPriorityUpdate none;
       memset(&none, 0, sizeof(none));
-      // the priority write-back (a single-workgroup latency chain of ~11 us) rides in the LONGER of the two backward
-      // launches: as a tenant of the output layer's launch (~8 us of real work) it was that launch's long pole
-      static const bool up_in_z = getenv("RB_UPDATE_IN_Z") && getenv("RB_UPDATE_IN_Z")[0] == '1';   // A/B switch
-      RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd,
-                  dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z + ((up.enabled && up_in_z) ? 1 : 0))), dim3(256), stream,
-                  zw, zx, zg, up_in_z ? up : none);
+      RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z)), dim3(256), stream,
+                  zw, zx, zg, none);
       if (exch) {
         // every factor of the FC weight gradients exists now (dlogits, h, dh, feat rows [0, B)): pack them into this rank's
         // exchange block; the conv gradients join it at the end of the backward (k_reduce_conv_dw_all stores them twice)
@@ -1900,39 +1721,16 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         RB_LAUNCH_CHECK();
         l->exch_pending = 1;
       }
-      const bool dx_wide_ok = hx.dyT && B >= 128 && B % 4 == 0 && L.F % 64 == 0 && hx.rows_per_split % 16 == 0;
-      if (h_wide && l->opt_dx_wide && dx_wide_ok) {
-        // both wide bodies + the priority write-back as block ranges of ONE launch (noisy_linear.h k_nl_bwd_wide)
-        const int n_dw = hg.dw_x * hg.dw_y, n_dx = (L.F / 64) * hsplits * (int)rb_div_up(B, 256);
-        RB_LAUNCH_T("fc_h_bwd:k_nl_bwd_wide", k_nl_bwd_wide, dim3((unsigned)(n_dw + n_dx + ((up.enabled && !up_in_z) ? 1 : 0))), dim3(256),
-                    stream, hw_, hg.dw_x, n_dw, hx, L.F / 64, hsplits, up_in_z ? none : up);
-        hg.dw_x = 0; hg.dw_y = 0; hg.dx_x = 0; hg.dx_y = 0; hg.dx_z = 0;
-        if (!up_in_z && up.enabled) up.enabled = 2;                            // (2: done above — no block left for k_nl_bwd)
-      } else {
-      if (h_wide) {        // batch >= 64: the weight gradient as a launch of its own (noisy_linear.h k_nl_dw_wide)
-        RB_LAUNCH_T("fc_h_dw:k_nl_dw_wide", k_nl_dw_wide, dim3((unsigned)(hg.dw_x * hg.dw_y)), dim3(256), stream, hw_, hg.dw_x);
-        hg.dw_x = 0; hg.dw_y = 0;
-      }
-      // batch >= 128, RB_DX_WIDE=1: the input gradient on the weight-stationary kernel (noisy_linear.h k_nl_dx_wide).
-      // Measured at batch 256: 34.9 us on its own (0.30 of f32 MFMA, against 0.23 for the per-m-chunk body alone) and the
-      // rest of the fused launch 41.4 us -> 76 us in sequence against 67.4 us fused: opt-in, like RB_DW_WIDE.
-      if (l->opt_dx_wide && dx_wide_ok) {
-        RB_LAUNCH_T("fc_h_dx:k_nl_dx_wide", k_nl_dx_wide, dim3((unsigned)(L.F / 64), (unsigned)hsplits, (unsigned)rb_div_up(B, 256)), dim3(256),
-                    stream, hx);
-        hg.dx_x = 0; hg.dx_y = 0; hg.dx_z = 0;
-      }
-      }
-      const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + ((up.enabled == 1 && !up_in_z) ? 1 : 0));
-      if (h_blocks > 0) {    // (0: both parts ran as launches of their own and there is no priority write-back to host)
-        RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up_in_z ? none : up);
-      }
+      // the priority write-back (a single-workgroup latency chain of ~11 us) rides in the LONGER of the two backward
+      // launches: as a tenant of the output layer's launch (~8 us of real work) it was that launch's long pole
+      const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + (up.enabled ? 1 : 0));
+      if (h_blocks > 0) { RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up); }
     }
-    l->sink_done = (up.enabled && !side) ? 1 : 0;
+    l->sink_done = up.enabled ? 1 : 0;
     RB_LAUNCH_CHECK();
     // d(conv output) = relu' * sum of the row-split partials: formed by its two consumers (the last conv layer's dX and
     // dW kernels) while they stage it, instead of a ~5 us launch of its own between two dependent kernels
-    static const bool lazy_off = getenv("RB_LAZY_DFEAT") && getenv("RB_LAZY_DFEAT")[0] == '0';   // A/B switch
-    l->lazy_dfeat = (!lazy_off && !side && l->fast_conv && L.nconv >= 2 && hsplits <= 4) ? 1 : 0;
+    l->lazy_dfeat = (l->fast_conv && L.nconv >= 2 && hsplits <= 4) ? 1 : 0;
     l->lazy_splits = hsplits;
     if (!l->lazy_dfeat) {
       const int64_t total = (int64_t)B * L.F;
@@ -1982,16 +1780,13 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     RB_LAUNCH_CHECK();
   }
   }
-  if (l->fast_conv && !side) {
+  if (l->fast_conv) {
     for (int layer = L.nconv - 1; layer > 0; --layer)                 // the input-gradient chain first ...
       if ((rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;
     if ((rc = conv_dw_all(l, stream)) != RB_OK) return rc;            // ... then every weight gradient in one launch
   } else {
-    for (int layer = L.nconv - 1; layer >= 0; --layer) {
-      if ((rc = fork(s_cv)) != RB_OK) return rc;                      // dact[layer] is final on the main stream
-      if ((rc = conv_bwd(l, layer, states_dev, s_cv, 1)) != RB_OK) return rc;       // weight grads: side stream
-      if (layer > 0 && (rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;   // data grads: main
-    }
+    for (int layer = L.nconv - 1; layer >= 0; --layer)
+      if ((rc = conv_bwd(l, layer, states_dev, stream, 3)) != RB_OK) return rc;
   }
   {   // one fixed-order reduction of every conv layer's split slices into the gradient buffer
     ReduceAllArgs ra;
@@ -2006,14 +1801,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     ra.sq_part = l->norm_slots > 0 ? l->norm_part + l->norm_conv_base : nullptr;
     ra.grads_base = l->grads;
     ra.copy_base = exch ? l->fact_local + l->fact_off[5] : nullptr;
-    RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(off, 64)), dim3(64), s_cv, ra);
+    RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(off, 64)), dim3(64), stream, ra);
     RB_LAUNCH_CHECK();
-  }
-  if (side) {   // join
-    RB_HIP_TRY(hipEventRecord(l->ev[6], s_fc));
-    RB_HIP_TRY(hipEventRecord(l->ev[7], s_cv));
-    RB_HIP_TRY(hipStreamWaitEvent(stream, l->ev[6], 0));
-    RB_HIP_TRY(hipStreamWaitEvent(stream, l->ev[7], 0));
   }
   return RB_OK;
 }
@@ -2163,9 +1952,8 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
   a.batch_status = l->status_copy;        // (k_head's copy of l->batch_status: see status_copy)
   const int64_t n4 = n >> 2;
   // 4 quadruples per thread: measured best of {2, 4, 8} on MI355X (254.3 / 255.6 / 256.6 us per step)
-  // write-through stores: same-box A/B 253.7 -> 250.8 us per step (RB_ADAM_WT=0 restores plain stores)
-  static const bool plain = getenv("RB_ADAM_WT") && getenv("RB_ADAM_WT")[0] == '0';
-  const bool wt = !plain && n * 4 < (int64_t)0x7fffffff;   // buffer-store offsets are 31-bit
+  // write-through stores (same-box A/B 253.7 -> 250.8 us per step) through buffer instructions: offsets are 31-bit
+  RB_REQUIRE(n * 4 < (int64_t)0x7fffffff, "rb_learner_clip_adam: the flat parameter buffer must be smaller than 2 GiB");
   FusedDwAdamArgs f;
   memset(&f, 0, sizeof(f));
   a.skip_lo4 = 0; a.skip_len4 = 0;
@@ -2179,12 +1967,11 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
     f.write_grads = (l->flags & RB_LEARNER_WRITE_FUSED_GRADS) ? 1 : 0;
     a.skip_lo4 = L.h_mu >> 2; a.skip_len4 = (L.h_bmu - L.h_mu) >> 2;
     const unsigned grid = (unsigned)(f.n_tile_blocks + rb_div_up(n4 - a.skip_len4 > 0 ? n4 - a.skip_len4 : 1, 256 * 4));
-    if (wt) { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, true>), dim3(grid), dim3(256), stream, a, f); }
-    else { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false, true>), dim3(grid), dim3(256), stream, a, f); }
+    RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, true>), dim3(grid), dim3(256), stream, a, f);
     l->dw_deferred = 0;
   } else {
     const unsigned grid = (unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4);
-    if (defer && wt && a.step_dev != nullptr && a.nparts > 0 && l->adam_args_dev != nullptr) {
+    if (defer && a.step_dev != nullptr && a.nparts > 0 && l->adam_args_dev != nullptr) {
       // left pending: the next train_step's sampler launch hosts these workgroups (or flush_update launches them).  The
       // arguments are all step-invariant (the step number and the norm partials live on the device): uploaded on change only
       if (!l->adam_args_valid || memcmp(&a, &l->adam_args_host, sizeof(a)) != 0) {
@@ -2197,8 +1984,7 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
       l->adam_blocks = (int)grid;
       return RB_OK;
     }
-    if (wt) { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3(grid), dim3(256), stream, a, f); }
-    else { RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, false, false>), dim3(grid), dim3(256), stream, a, f); }
+    RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3(grid), dim3(256), stream, a, f);
   }
   RB_LAUNCH_CHECK();
   return RB_OK;
@@ -2355,7 +2141,6 @@ int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_strea
     case 2: src = l->a_star; bytes = (size_t)L.B * 4; break;
     case 3: src = l->pns_a; bytes = (size_t)L.B * L.Z * 4; break;
     case 4: src = l->logits; bytes = (size_t)3 * L.B * L.NZ * 4; break;
-    case 5: src = l->chain_ctr + (int64_t)RB_CHAIN_ARRAYS * 3 * L.B; bytes = 4; break;   // chained conv launches: 1 = a bounded spin expired
     default: rb_set_error("rb_learner_debug_read: unknown selector %d", what); return RB_ERR_INVALID;
   }
   RB_HIP_TRY(hipMemcpyAsync(out_dev, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));

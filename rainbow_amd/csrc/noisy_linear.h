@@ -80,184 +80,6 @@ struct NlFwd2Args {
 #define RB_FWD2_MROWS 32
 #define RB_FWD2_KMAX 4096          // eps_in slice staged in LDS (host checks K <= this)
 #define RB_FWD2_WT_LD 36           // row stride (floats) of a wave's 16 x 32 weight tile: 16-byte reads of 16 rows hit 64 distinct banks
-// ABL: ablation bits for tools/gpu_ablate.sh: 1 no weight refill, 2 no activation refill, 4 no MFMA (0 = product).
-// MT: 16-row m-tiles per workgroup (2 = 32 rows, the batch-32 shape; 4 = 64 rows, which halves the number of passes over
-// the weights when a net has >= 128 rows, i.e. batch 256).  Requires K % 32 == 0 (whole 32-wide k blocks).
-template <int ABL, int MT = 2>
-__global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd2(NlFwd2Args a) {
-  __shared__ float s_red[RB_NL_FWD_WAVES][4 * MT][64];
-  __shared__ __attribute__((aligned(16))) float s_ein[RB_FWD2_KMAX];
-  __shared__ __attribute__((aligned(16))) float s_wt[RB_NL_FWD_WAVES][16 * RB_FWD2_WT_LD];
-  const int lane = rb_lane(), wave = rb_wave();
-  const int net = (int)blockIdx.z & 1, mc = (int)blockIdx.z >> 1;
-  const int M = a.m_cnt[net];
-  const int m0 = mc * (16 * MT);
-  if (m0 >= M) return;                                   // block-uniform
-  const int g = (a.n_groups > 1 && (int)blockIdx.x >= a.grp[1].tile_begin) ? 1 : 0;
-  const NlRowGroup grp = a.grp[g];
-  const int row0 = grp.row_begin + ((int)blockIdx.x - grp.tile_begin) * 16;
-  const int row_end = grp.row_begin + grp.row_cnt;
-  const NlWeights w = a.w[net];
-  const int K = a.K;
-  const int nchunks = K / 16;
-  const int per_wave = ((nchunks + RB_NL_FWD_WAVES - 1) / RB_NL_FWD_WAVES + 1) / 2 * 2;   // even: whole 32-wide blocks
-  int wc0 = wave * per_wave, wc1 = wc0 + per_wave;
-  if (wc0 > nchunks) wc0 = nchunks;
-  if (wc1 > nchunks) wc1 = nchunks;
-  const int nsc = (wc1 - wc0 + 1) / 2;                   // 32-wide k blocks of this wave
-
-  const int r = lane & 15, q = lane >> 4;
-  // WEIGHT LOADS are line-wide: an instruction covers 8 rows x 128 B (lane -> row 8 i + (lane >> 3), 16 B at
-  // 4 (lane & 7)), i.e. 8 full cache lines, not the MFMA operand layout (16 rows x 64 B = 16 half lines per
-  // instruction, which measured 31.4 us against 22.5 us for the same bytes read as flat 1 KB runs: the request count,
-  // not the byte count, was the limiter).  The noisy weight is formed in that load layout and transposed to the
-  // MFMA layout through a private 16 x 32 LDS tile per wave.
-  const int lr = lane >> 3, lk = lane & 7;
-  const float* mu_p[2];
-  const float* sg_p[2];
-  float eo2[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row = row0 + 8 * i + lr;
-    if (row > row_end - 1) row = row_end - 1;
-    mu_p[i] = w.mu + (int64_t)row * K + 4 * lk;
-    sg_p[i] = w.sigma + (int64_t)row * K + 4 * lk;
-    eo2[i] = w.eout[row];
-  }
-  float* wt = &s_wt[wave][0];                             // [16 rows][RB_FWD2_WT_LD]
-  const float* x_p[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int m = m0 + 16 * mt + r;
-    if (m > M - 1) m = M - 1;
-    x_p[mt] = a.x + ((int64_t)(grp.x_off >> 4) * a.rows_total + a.m_base[net] + m) * 16 + 4 * q;
-  }
-  const int64_t xs = (int64_t)a.rows_total * 16;
-
-  rb_f32x4 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[mt][e] = 0.0f;
-
-  // Software pipeline.  Weights come from HBM (latency ~2 us under load), so FOUR 32-wide k blocks of mu/sigma
-  // (16 KB per wave) are kept in flight in a statically indexed register ring.  The activations ride in the SAME ring
-  // at the SAME depth: vector-memory loads retire in issue order (one vmcnt counter), so an activation load issued
-  // one block ahead would sit behind the weight loads issued four blocks ahead and every wait for it would drain
-  // the whole weight prefetch.  eps_in is staged in LDS once (its reads count on lgkmcnt, not vmcnt).  Every load is
-  // UNCONDITIONAL (out-of-range blocks re-read the wave's last block and are multiplied by a zero mask): a branch
-  // around a load would make the outstanding-load count unknown to the compiler, which then drains the whole queue
-  // (s_waitcnt vmcnt(0)) at every use — measured 79 us vs 30.
-  // (MT = 4 carries twice the activation registers: a 4-deep ring spilled 20 B per lane there, and a kernel with a scratch
-  // segment slows the whole step on this platform, so the 64-row variant keeps 3 blocks in flight)
-  constexpr int RING = MT >= 4 ? 3 : 4;
-  float4 r_mu[RING][2], r_sg[RING][2], r_x[RING][2][MT];
-  const int c_last = wc1 > wc0 ? wc1 - 1 : (nchunks > 0 ? nchunks - 1 : 0);
-  auto chunk_of = [&](int sc, int h) { const int cc = wc0 + 2 * sc + h; return cc < wc1 ? cc : c_last; };
-  auto block_of = [&](int sc) { const int cc = wc0 + 2 * sc; return cc + 1 < wc1 ? cc : (c_last > 0 ? c_last - 1 : 0); };   // first chunk of a 32-wide block
-  auto live = [&](int sc) { return (wc0 + 2 * sc < wc1) ? 1.0f : 0.0f; };
-  {
-    const float* ein_g = w.ein + grp.ein_off;
-    for (int k4 = (int)threadIdx.x; k4 < (K >> 2); k4 += 64 * RB_NL_FWD_WAVES)
-      *reinterpret_cast<float4*>(&s_ein[4 * k4]) = rb_ld4(ein_g + 4 * k4);
-  }
-#pragma unroll
-  for (int d = 0; d < RING; ++d) {
-    const int cb = block_of(d);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      r_mu[d][i] = rb_ld4(mu_p[i] + cb * 16);
-      r_sg[d][i] = rb_ld4(sg_p[i] + cb * 16);
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cc = chunk_of(d, h);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cc * xs);
-    }
-  }
-  __syncthreads();                                       // eps_in visible
-  const int nsc_pad = (nsc + RING - 1) / RING * RING;
-  for (int sc0 = 0; sc0 < nsc_pad; sc0 += RING) {
-#pragma unroll
-    for (int d = 0; d < RING; ++d) {
-      const int sc = sc0 + d;
-      {
-        const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[block_of(sc) * 16 + 4 * lk]);
-        const float lv = live(sc);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          float4 wv = rb_noisy4(r_mu[d][i], r_sg[d][i], eo2[i], e4);
-          wv.x *= lv; wv.y *= lv; wv.z *= lv; wv.w *= lv;
-          *reinterpret_cast<float4*>(&wt[(8 * i + lr) * RB_FWD2_WT_LD + 4 * lk]) = wv;
-        }
-      }
-      if constexpr (!(ABL & 1)) {
-        const int cb = block_of(sc + RING);              // refill the weight half of this ring slot (block sc + RING)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          r_mu[d][i] = rb_ld4(mu_p[i] + cb * 16);
-          r_sg[d][i] = rb_ld4(sg_p[i] + cb * 16);
-        }
-      }
-      rb_wave_sync();                                    // the tile is private to the wave: LDS executes its ops in order
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4 w4 = *reinterpret_cast<const float4*>(&wt[r * RB_FWD2_WT_LD + 16 * h + 4 * q]);
-        if constexpr (ABL & 4) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            acc[mt][0] += r_x[d][h][mt].x * w4.x; acc[mt][1] += r_x[d][h][mt].y * w4.y;
-            acc[mt][2] += r_x[d][h][mt].z * w4.z; acc[mt][3] += r_x[d][h][mt].w * w4.w;
-          }
-        } else {
-          // k-slot outer, m-tile inner: consecutive MFMAs write different accumulators (back-to-back MFMAs on the
-          // same accumulator wait for each other's result)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].x, w4.x, acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].y, w4.y, acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].z, w4.z, acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = rb_mfma16(r_x[d][h][mt].w, w4.w, acc[mt]);
-        }
-      }
-      if constexpr (!(ABL & 2)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                    // ... and its activation half, once the MFMAs have read it
-          const int cw = chunk_of(sc + RING, h);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4(x_p[mt] + cw * xs);
-        }
-      }
-      rb_wave_sync();                                    // tile reads done before the next block overwrites it
-      RB_SCHED_FENCE();                                  // keep this slot's refill here, not at the end of the loop
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s_red[wave][mt * 4 + e][lane] = acc[mt][e];
-  __syncthreads();
-  for (int idx = (int)threadIdx.x; idx < 4 * MT * 64; idx += 64 * RB_NL_FWD_WAVES) {
-    const int slot = idx >> 6, l = idx & 63;
-    float v = s_red[0][slot][l];
-#pragma unroll
-    for (int wv = 1; wv < RB_NL_FWD_WAVES; ++wv) v += s_red[wv][slot][l];
-    const int mt = slot >> 2, e = slot & 3;
-    const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
-    const int n = row0 + (l & 15);
-    if (m < M && m < m0 + 16 * MT && n < row_end) {
-      float o = v + (w.bmu[n] + w.bsigma[n] * w.eout[n]);                 // model.py:44
-      if (a.relu) o = fmaxf(o, 0.0f);
-      const int rowi = a.m_base[net] + m;
-      a.out[(int64_t)rowi * a.ld_out + n] = o;
-      if (a.out_blocked) a.out_blocked[((int64_t)(n >> 4) * a.rows_total + rowi) * 16 + (n & 15)] = o;
-    }
-  }
-}
-
 // k_nl_fwd3 — k_nl_fwd2 with the loop overhead taken out (same tiling, same LDS transpose, same results up to the order
 // in which the 8 waves' partial sums were formed — the K ranges of the waves are balanced differently):
 //   * every load is a buffer load: per-lane byte offset fixed before the loop, the running block offset is wave-uniform and
@@ -565,143 +387,6 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
     }
   }
 }
-// Large batches (M >= 128; the hidden layer at batch 256): dx[m][k] = sum_n dy[m][n] W[n][k] with the weights of a
-// 64-column tile streamed ONCE per row split and shared by the whole batch.  The body above gives every 64-row m-chunk a
-// workgroup of its own (the 25.7 MB of mu | sigma are streamed four times at batch 256 and every lane group gathers dy
-// across 4 KB-strided rows): 45.5 us for 1.64 GFLOP, 0.23 of f32 MFMA, 3.6x the algorithmic HBM bytes at the counters.
-// Here a workgroup owns (64 columns, one row split, up to 256 samples): wave w keeps samples [64 w, 64 w + 64) in its
-// accumulators for the WHOLE row range — no cross-wave reduction — and the four waves share each 16-row chunk of noisy
-// weights (formed once, by the thread that loads mu and sigma) and of dY^T (from the transposed copy dyT, 16-byte loads)
-// through LDS; the next chunk's loads are in flight under the current chunk's 64 MFMAs per wave.
-// grid = (K / 64, row splits, ceil(M / 256)).  Requires dyT, K % 64 == 0, rows_per_split % 16 == 0, M % 4 == 0.
-#define RB_NL_DXW_DY_LD 272        // row stride (floats) of the dY^T chunk: the (q, c) lanes of an operand read hit distinct banks
-#define RB_NL_DXW_W_LD 68
-// RC = weight rows per chunk (16: 43 KB of LDS, three workgroups per CU; 32: 87 KB, one — measured equal)
-#define RB_NL_DXW_LDS(RC) (2 * (RC) * (RB_NL_DXW_DY_LD + RB_NL_DXW_W_LD))
-template <int RC>
-__device__ __forceinline__ void rb_nl_dx_body_wide(const NlDxArgs& a, int bx, int by, int bz, float* lds) {
-  constexpr int RU = RC / 16;                                   // rows per thread in the staging pattern
-  float* s_dy = lds;                                            // [2][RC][RB_NL_DXW_DY_LD]
-  float* s_w = lds + 2 * RC * RB_NL_DXW_DY_LD;                  // [2][RC][RB_NL_DXW_W_LD]
-  const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
-  const NlDxProblem pr = a.prob[0];
-  const int kt = bx * 64;
-  const int mbase = bz * 256;
-  const int row_end = pr.row_begin + pr.row_cnt;
-  const int rb = pr.row_begin + by * a.rows_per_split;
-  int re = rb + a.rows_per_split;
-  if (re > row_end) re = row_end;
-  if (rb >= re) return;                                         // block-uniform
-  const int c = lane & 15, q = lane >> 4;
-  const int m0 = mbase + 64 * wave;                             // this wave's 64 samples
-  const bool wave_on = m0 < a.M;
-  int mt_cnt = wave_on ? (a.M - m0 + 15) / 16 : 0;
-  if (mt_cnt > 4) mt_cnt = 4;
-  // staging coordinates: rows sr + 16 u of the chunk; weights — float4 column sc; dY^T — 4 float4 per row along m
-  const int sr = t >> 4, sc = t & 15;
-  const float4 e0 = rb_ld4(a.w.ein + pr.ein_off0 + kt + 4 * sc);
-  const float4 e1 = rb_ld4(a.w.ein + pr.ein_off1 + kt + 4 * sc);
-  rb_f32x4 acc[4][4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[mt][j][e] = 0.0f;
-  float4 p_mu[RU], p_sg[RU], p_dy[RU][4];
-  float p_eo[RU];
-  int p_n0 = 0;
-  auto issue = [&](int nb) {
-    p_n0 = nb;
-#pragma unroll
-    for (int r = 0; r < RU; ++r) {
-      const int n = nb + sr + 16 * r;
-      const int nc = n < re ? n : re - 1;
-      p_mu[r] = rb_ld4(a.w.mu + (int64_t)nc * a.K + kt + 4 * sc);
-      p_sg[r] = rb_ld4(a.w.sigma + (int64_t)nc * a.K + kt + 4 * sc);
-      p_eo[r] = a.w.eout[nc];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int m = mbase + 4 * (sc + 16 * u);
-        p_dy[r][u] = m + 3 < a.M ? rb_ld4(a.dyT + (int64_t)nc * a.ldyT + m) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      }
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < RU; ++r) {
-      const int n = p_n0 + sr + 16 * r;
-      const bool nv = n < re;                                   // rows beyond the split contribute zeros
-      float4 wv = rb_noisy4(p_mu[r], p_sg[r], p_eo[r], n >= pr.ein_split_row ? e1 : e0);
-      if (!nv) wv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      rb_st4(s_w + (buf * RC + sr + 16 * r) * RB_NL_DXW_W_LD + 4 * sc, wv);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        rb_st4(s_dy + (buf * RC + sr + 16 * r) * RB_NL_DXW_DY_LD + 4 * (sc + 16 * u), nv ? p_dy[r][u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    }
-  };
-  issue(rb);
-  commit(0);
-  __syncthreads();
-  int buf = 0;
-  for (int nb = rb; nb < re; nb += RC) {
-    const bool more = nb + RC < re;
-    if (more) issue(nb + RC);
-    const float* dyb = s_dy + buf * RC * RB_NL_DXW_DY_LD + 64 * wave;
-    const float* wb = s_w + buf * RC * RB_NL_DXW_W_LD;
-    if (wave_on) {                                              // wave-uniform
-#pragma unroll
-      for (int st = 0; st < RC / 4; ++st) {
-        if (nb + 4 * st < re) {                                 // uniform (the chunk's tail rows are zeros anyway)
-          const float4 w4 = rb_ld4(wb + (4 * st + q) * RB_NL_DXW_W_LD + 4 * c);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            if (mt < mt_cnt) {
-              const float av = dyb[(4 * st + q) * RB_NL_DXW_DY_LD + 16 * mt + c];
-              acc[mt][0] = rb_mfma16(av, w4.x, acc[mt][0]);
-              acc[mt][1] = rb_mfma16(av, w4.y, acc[mt][1]);
-              acc[mt][2] = rb_mfma16(av, w4.z, acc[mt][2]);
-              acc[mt][3] = rb_mfma16(av, w4.w, acc[mt][3]);
-            }
-          }
-        }
-      }
-    }
-    if (more) commit(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  if (!wave_on) return;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    if (mt < mt_cnt) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = m0 + 16 * mt + 4 * q + e;
-        if (m < a.M) {
-          float4 v;
-          v.x = acc[mt][0][e]; v.y = acc[mt][1][e]; v.z = acc[mt][2][e]; v.w = acc[mt][3][e];
-          const int64_t o = ((int64_t)by * a.M + m) * a.ld_out + pr.out_off + kt + 4 * c;
-          if (a.mask_src) {
-            const float4 ms = rb_ld4(a.mask_src + o);
-            v.x = ms.x > 0.0f ? v.x : 0.0f; v.y = ms.y > 0.0f ? v.y : 0.0f; v.z = ms.z > 0.0f ? v.z : 0.0f; v.w = ms.w > 0.0f ? v.w : 0.0f;
-          }
-          rb_st4(a.out + o, v);
-        }
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256, 1) void k_nl_dx_wide(NlDxArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[RB_NL_DXW_LDS(32)];
-  rb_nl_dx_body_wide<32>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
-}
-__global__ __launch_bounds__(256) void k_nl_dx(NlDxArgs a) {
-  __shared__ float lds[RB_NL_DX_LDS];
-  rb_nl_dx_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
-}
-
 // ===================================================================== weight gradient ==
 // g_mu[n][k] = sum_m dy[m][n] * x[m][x_off + k] ; g_sigma = g_mu * (eps_out[n]*eps_in[k]) ;
 // g_bmu[n] = sum_m dy[m][n] ; g_bsigma = g_bmu * eps_out[n].   One writer per element.
@@ -817,104 +502,6 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
     }
   }
   if (a.sq_part) {                                        // wave-uniform
-    sq = rb_wave_sum(sq);
-    if (lane == 0) a.sq_part[slot_base + wave] = sq;
-  }
-}
-// Large batches (M >= 64; the hidden layer at batch 256): a workgroup owns a 64-row x 64-column tile of the gradient and
-// walks the M reduction rows in chunks of 32 that are staged ONCE in LDS for its four waves (wave w: rows 16 w .. 16 w + 15
-// of the tile, all 64 columns) — the body above has every wave fetch its own operands from L2 (x re-read by each of the 64
-// row tiles: 205 MB of L2 -> CU traffic for 1.6 GFLOP, 3.6x the algorithmic HBM bytes at the counters).  The next
-// chunk's global loads are in flight under the current chunk's MFMAs (registers -> the other LDS buffer).
-// Same MFMA operand order per output element as the body above (k ascending in steps of 4): identical results.
-// grid: bx over K / 64 column tiles, by over (rows of both problems) / 64.  Requires K % 64 == 0, row_cnt % 64 == 0.
-#define RB_NL_DWW_DY_LD 80         // row stride (floats) of the dY chunk: lanes (q, c) of an operand read hit distinct banks
-#define RB_NL_DWW_X_LD 68
-#define RB_NL_DWW_LDS (2 * 32 * (RB_NL_DWW_DY_LD + RB_NL_DWW_X_LD))
-__device__ __forceinline__ void rb_nl_dw_body_wide(const NlDwArgs& a, int bx, int by, int slot_base, float* lds) {
-  const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
-  float* s_dy = lds;                                            // [2][32][RB_NL_DWW_DY_LD]
-  float* s_x = lds + 2 * 32 * RB_NL_DWW_DY_LD;                  // [2][32][RB_NL_DWW_X_LD]
-  const int tile_row0 = by * 64;                                // in the concatenated row space of the problems
-  const int g = (a.n_prob > 1 && tile_row0 >= a.prob[1].row_begin) ? 1 : 0;
-  const NlDwProblem pr = a.prob[g];
-  const int row0 = tile_row0 + 16 * wave;                       // this wave's 16 rows (problem rows are contiguous: row == dy column)
-  const int col0 = bx * 64;
-  const int c = lane & 15, q = lane >> 4;
-  const int col4 = col0 + 4 * c;
-  // staging coordinates of this thread: two float4 of each operand per chunk
-  const int sm = t >> 4, sc4 = t & 15;                          // rows sm and sm + 16 of the chunk, float4 column sc4
-  rb_f32x4 acc[4], accb;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
-  const bool do_bias = bx == 0;
-  const float4 e4 = rb_ld4(a.ein + pr.ein_off + col4);
-  float eo4[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) eo4[e] = a.eout[row0 + 4 * q + e];
-  float4 px[2], pd[2];
-  auto issue = [&](int mb) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int m = mb + sm + 16 * u;
-      const int mc = m < a.M ? m : a.M - 1;
-      px[u] = rb_ld4(a.x + (int64_t)mc * a.ldx + pr.x_off + col0 + 4 * sc4);
-      pd[u] = rb_ld4(a.dy + (int64_t)mc * a.ldy + tile_row0 + 4 * sc4);
-      if (m >= a.M) { px[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); pd[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      rb_st4(s_x + (buf * 32 + sm + 16 * u) * RB_NL_DWW_X_LD + 4 * sc4, px[u]);
-      rb_st4(s_dy + (buf * 32 + sm + 16 * u) * RB_NL_DWW_DY_LD + 4 * sc4, pd[u]);
-    }
-  };
-  issue(0);
-  commit(0);
-  __syncthreads();
-  int buf = 0;
-  for (int mb = 0; mb < a.M; mb += 32) {
-    const bool more = mb + 32 < a.M;
-    if (more) issue(mb + 32);
-    const float* dyb = s_dy + buf * 32 * RB_NL_DWW_DY_LD;
-    const float* xb = s_x + buf * 32 * RB_NL_DWW_X_LD;
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      if (mb + 4 * st < a.M) {                                  // uniform
-        const float av = dyb[(4 * st + q) * RB_NL_DWW_DY_LD + 16 * wave + c];
-        const float4 xs = rb_ld4(xb + (4 * st + q) * RB_NL_DWW_X_LD + 4 * c);
-        acc[0] = rb_mfma16(av, xs.x, acc[0]);
-        acc[1] = rb_mfma16(av, xs.y, acc[1]);
-        acc[2] = rb_mfma16(av, xs.z, acc[2]);
-        acc[3] = rb_mfma16(av, xs.w, acc[3]);
-        if (do_bias) accb = rb_mfma16(av, 1.0f, accb);          // block-uniform
-      }
-    }
-    if (more) commit(buf ^ 1);
-    __syncthreads();                                            // the other buffer is complete; this one may be overwritten next time
-    buf ^= 1;
-  }
-  float sq = 0.0f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int n = row0 + 4 * q + e;
-    const float eo = eo4[e];
-    float4 gm, gs;
-    gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
-    gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
-    rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
-    rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
-    sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
-    sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
-    if (do_bias && c == 0) {
-      const float gb = accb[e], gbs = accb[e] * eo;
-      a.g_bmu[n] = gb;
-      a.g_bsigma[n] = gbs;
-      sq = fmaf(gb, gb, sq); sq = fmaf(gbs, gbs, sq);
-    }
-  }
-  if (a.sq_part) {                                              // block-uniform
     sq = rb_wave_sum(sq);
     if (lane == 0) a.sq_part[slot_base + wave] = sq;
   }
@@ -1134,16 +721,6 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
 }
 // the wide body as a launch of its own: inside k_nl_bwd it would inherit that kernel's register allocation (145 + 64: two
 // workgroups per CU), and with 8 short chunks per workgroup it is latency-bound — it wants many resident workgroups
-__global__ __launch_bounds__(256, 4) void k_nl_dw_wide(NlDwArgs a, int dw_x) {
-  __shared__ __attribute__((aligned(16))) float lds[RB_NL_DWW_LDS];
-  const int b = (int)blockIdx.x;
-  rb_nl_dw_body_wide(a, b % dw_x, b / dw_x, 4 * b, lds);
-}
-__global__ __launch_bounds__(256) void k_nl_dw(NlDwArgs a) {
-  const int slot = 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x);
-  if (a.rpb > 0) rb_nl_dw_body_ranks(a, (int)blockIdx.x, (int)blockIdx.y, slot);
-  else rb_nl_dw_body(a, (int)blockIdx.x, (int)blockIdx.y, slot);
-}
 
 // Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in
 // ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
@@ -1199,21 +776,4 @@ __global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdG
     rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     RB_SPAN_END(sb + 2);
   }
-}
-
-// Large batches: the hidden layer's whole backward on the two wide bodies in ONE launch — block ranges [priority
-// write-back | 64 x 64 weight-gradient tiles | weight-stationary input-gradient workgroups] — so that the three overlap on
-// the chip as they do in k_nl_bwd (either wide body as a launch of its own lost more to the sequence than it gained).
-__global__ __launch_bounds__(256, 3) void k_nl_bwd_wide(NlDwArgs dw, int dw_x, int n_dw, NlDxArgs dx, int dx_x, int dx_y, NlPriorityUpdate up) {
-  constexpr int L0 = RB_NL_DXW_LDS(16) > RB_NL_DWW_LDS ? RB_NL_DXW_LDS(16) : RB_NL_DWW_LDS;
-  constexpr int LDSW = L0 > UpdateLds<512, 256>::WORDS ? L0 : UpdateLds<512, 256>::WORDS;
-  __shared__ __attribute__((aligned(16))) float lds[LDSW];
-  int b = (int)blockIdx.x;
-  if (up.enabled) {
-    if (b == 0) { rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds); return; }
-    b -= 1;
-  }
-  if (b < n_dw) { rb_nl_dw_body_wide(dw, b % dw_x, b / dw_x, 4 * b, lds); return; }
-  b -= n_dw;
-  rb_nl_dx_body_wide<16>(dx, b % dx_x, (b / dx_x) % dx_y, b / (dx_x * dx_y), lds);
 }

@@ -43,6 +43,10 @@ void rb_dev_free(void* p);
 
 static inline int64_t rb_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- RB_OPTS="key=value,key=value": the library's ONE tuning / test-hook variable (common.hip; DESIGN.md §8 lists the keys).
+// Returns `dflt` when the key is absent.  Read when a handle is created, never per launch.
+int rb_opt(const char* key, int dflt);
+
 // ---- Philox4x32-10 counter RNG (device sampler + noise) ------------------------------
 struct rb_philox_out {
   uint32_t v[4];

@@ -886,6 +886,13 @@ int rb_replay_find(rb_replay_t* r, const double* values_dev, int32_t n, float* p
   return RB_OK;
 }
 
+// the pending optimiser pass of the learner (adam_body.h) as a launch of its own: what sample_impl falls back to when the
+// sampler variant that can host it does not fit the replay's window length
+__global__ __launch_bounds__(256) void k_adam_pending(const ClipAdamArgs* ad) {
+  __shared__ float s_adam[18];
+  rb_adam_hosted_block<4>(ad, (int)blockIdx.x, (int)gridDim.x, s_adam);
+}
+
 static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
                        int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
                        int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
@@ -916,22 +923,28 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   if (noise_job && job.adam_dev && job.adam_blocks > 0) {
     RB_REQUIRE(threads == 256, "rb_replay_sample_fused_noise: the hosted optimiser pass needs a 256-thread sampler launch (batch <= 256)");
     adam_dev = static_cast<const ClipAdamArgs*>(job.adam_dev);
-    // RB_ADAM_HOST=deep: the 256-thread sampler variant with 8 quadruples per hosted thread; default: the 1024-thread
-    // variant (four tree levels per trip, 127 VGPRs -> twice the resident waves) with 4 — job.adam_blocks counts blocks of
-    // 4 quadruples per thread
-    static const bool deep = getenv("RB_ADAM_HOST") && !strcmp(getenv("RB_ADAM_HOST"), "deep");
-    host_mode = deep ? 2 : 1;
-    blocks += (unsigned)(deep ? (job.adam_blocks + 1) / 2 : (job.adam_blocks * 4 + RB_HOST_AU_WIDE - 1) / RB_HOST_AU_WIDE);
+    // the host is the 1024-thread sampler variant (four tree levels per trip, 127 VGPRs -> 4 waves per SIMD for the hosted
+    // streaming workgroups; under the 256-thread variant's 205 VGPRs the pass took 46 us instead of 38) with 4 quadruples per
+    // hosted thread — job.adam_blocks counts blocks of 4 quadruples per thread.  That variant holds windows of up to 24
+    // transitions; a longer window (history + multi_step > 24) gets the pending pass as a launch of its own in front of an
+    // un-hosted sampler: same order in the stream, same results.
+    if (r->history + r->n <= 24) {
+      host_mode = 1;
+      blocks += (unsigned)((job.adam_blocks * 4 + RB_HOST_AU_WIDE - 1) / RB_HOST_AU_WIDE);
+    } else {
+      RB_LAUNCH_T("clip_adam:k_adam_pending", k_adam_pending, dim3((unsigned)job.adam_blocks), dim3(256), stream, adam_dev);
+      RB_LAUNCH_CHECK();
+      adam_dev = nullptr;
+    }
   }
-  // RB_SAMPLER=global searches without the LDS-staged tree top (A/B switch).  Measured on MI355X, back-to-back launches,
-  // B = 32 / 1M leaves: 11.1 us (LDS top, 11 LDS steps + 2 trips) vs 11.6 (4 trips); n = 20 / 100k: 14.3 vs 16.1;
-  // B = 256: 20.0 vs 24.4 — a trip costs ~1.3 us of ISSUE (62 loads + select chain), more than the staging it replaces.
-  static const int lds_top = (getenv("RB_SAMPLER") && !strcmp(getenv("RB_SAMPLER"), "global")) ? 0 : 1;
+  // (the tree search keeps its top 4095 nodes in LDS: measured against an all-global search, B = 32 / 1M leaves: 11.1 vs
+  // 11.6 us, n = 20 / 100k: 14.3 vs 16.1, B = 256: 20.0 vs 24.4 — a trip costs ~1.3 us of issue, more than the staging)
+  const int lds_top = 1;
   if (threads <= 256 && host_mode != 1) {
     RB_LAUNCH_T("sample:k_sample", (k_sample<256, 8>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
                 r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
   } else {
-    RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: batch > 256 supports history + multi_step <= 24");
+    RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: the 1024-thread sampler (batch > 256) supports history + multi_step <= 24");
     RB_LAUNCH_T("sample:k_sample", (k_sample<1024, RB_HOST_AU_WIDE>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
                 r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
   }

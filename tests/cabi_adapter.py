@@ -304,7 +304,6 @@ class CAbiLearnAdapter:
             grads = self._unflat(m.download(self.grads))
             self.opt.step()                                                                        # agent.py:98
         m.sync()
-        assert int(self.debug(5, (1,), np.int32)[0]) == 0, "a bounded in-launch wait of the chained conv launches expired"
         return dict(loss=m.download(self._loss), grad_norm=float(m.download(norm)[0]), grads=grads)
 
     def learn_step(self, batch, target_raw):

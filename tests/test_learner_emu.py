@@ -26,9 +26,9 @@ def test_learn_step_matches_reference_golden(emu, name):
 
 
 def test_generic_gemm_fallback_still_matches_golden(emu, monkeypatch):
-    """RB_GENERIC_GEMM_ONLY=1 forces every contraction through gemm_core.h (the fallback used when the
+    """RB_OPTS=generic=1 forces every contraction through gemm_core.h (the fallback used when the
     streamed noisy-linear kernels' alignment preconditions do not hold)."""
-    monkeypatch.setenv("RB_GENERIC_GEMM_ONLY", "1")
+    monkeypatch.setenv("RB_OPTS", "generic=1")
     name = "atoms21"
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O)
@@ -38,8 +38,8 @@ def test_generic_gemm_fallback_still_matches_golden(emu, monkeypatch):
 
 def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
     """The hidden layer's input gradient split over 4 row ranges + k_dfeat_finish(splits = 4) — the shape the canonical
-    hidden-512 network runs (xs = 2H/256 = 4, learner.hip) — forced on the small canonical fixture with RB_XS=4."""
-    monkeypatch.setenv("RB_XS", "4")
+    hidden-512 network runs (xs = 2H/256 = 4, learner.hip) — forced on the small canonical fixture with RB_OPTS=xs=4."""
+    monkeypatch.setenv("RB_OPTS", "xs=4")
     name = "canon"
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=1)          # the first golden step is enough to pin the split path
@@ -50,9 +50,9 @@ def test_row_split_input_gradient_matches_golden(emu, monkeypatch):
 
 
 def test_chunk_fastest_conv_block_order_matches_golden(emu, monkeypatch):
-    """RB_CONV_IMGFAST=0: the (chunk, tile, image) block order of the conv launches — the fallback when the image count is
+    """RB_OPTS=img_fast=0: the (chunk, tile, image) block order of the conv launches — the fallback when the image count is
     not a multiple of 8; the default image-fastest order is what every other test here runs (3B = 24 images on this fixture)."""
-    monkeypatch.setenv("RB_CONV_IMGFAST", "0")
+    monkeypatch.setenv("RB_OPTS", "img_fast=0")
     name = "canon"
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=1)
@@ -62,14 +62,30 @@ def test_chunk_fastest_conv_block_order_matches_golden(emu, monkeypatch):
     ad.close()
 
 
+@pytest.mark.parametrize("t16", ["0", "7"], ids=["split-k-32x32", "whole-k-16x16-all-layers"])
+def test_conv_forward_tile_variants_match_golden(emu, monkeypatch, t16):
+    """The conv forward's MFMA phase exists twice (conv_lds.h rb_conv_fwd_body): 32x32x2 tiles with the reduction split over 8
+    waves + an LDS sum, and (T16) one wave per 16x16 tile over the whole reduction with the epilogue straight from the
+    accumulators.  Default: T16 for the second and third layer (RB_OPTS t16=6, what every other test runs); here all layers
+    on the split-K body (t16=0) and all layers incl. the u8 first layer on T16 (t16=7)."""
+    monkeypatch.setenv("RB_OPTS", "t16=" + t16)
+    name = "canon"
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    trace = scenarios.learn_scenario(ad, name, O, steps=1)
+    golden = load_golden("learn_%s.npz" % name)
+    assert_learn_trace_matches(trace, {k: v for k, v in golden.items() if k in trace}, label="emu-t16=%s/%s" % (t16, name))
+    assert any("_grad/convs" in k for k in trace)
+    ad.close()
+
+
 @pytest.mark.parametrize("name,steps,full", [("dataeff", None, "1"), ("canon", 1, "1"), ("canon", 1, "0")])
 def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, full):
     """Large batches run the conv forward and data-gradient kernels with one weight slab per workgroup and a loop over
-    images (k_conv_fwd_multi, k_conv_dx_lds<..., MULTI>); RB_CONV_MULTI / RB_DX_IPB force those paths (ragged: neither
+    images (k_conv_fwd_multi, k_conv_dx_lds<..., MULTI>); RB_OPTS conv_multi / dx_ipb force those paths (ragged: neither
     divides the batch) on the small fixtures, with the last layer's dY formed from the row-split partials in the loop."""
-    monkeypatch.setenv("RB_DX_IPB", "3")
-    monkeypatch.setenv("RB_CONV_MULTI", "5")         # and the forward's multi-image kernels, ragged as well
-    monkeypatch.setenv("RB_CONV_FULL", full)         # first layer: whole-image kernel (k_conv_fwd_full) / chunked k_conv_fwd_multi
+    # dx_ipb / conv_multi: ragged image groups in the input-gradient and forward kernels; conv_full: the first layer's
+    # whole-image kernel (k_conv_fwd_full) or, 0, the one-image kernel
+    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s" % full)
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=steps)
     golden = load_golden("learn_%s.npz" % name)
@@ -509,16 +525,11 @@ def test_trajectory_tracks_reference_for_30_steps(emu):
     ad.close()
 
 
-@pytest.mark.parametrize("nbatch,dx_wide", [(64, "0")] + ([(128, "1")] if os.environ.get("RB_TEST_FULL") == "1" else []),
-                         ids=lambda v: str(v))
-def test_large_batch_fc_backward_variants_match_oracle(emu, monkeypatch, nbatch, dx_wide):
-    """Batch 64 / 128 on the data-efficient stack with hidden 64 (F = 576, 2H = 128: multiples of 64): the LDS-shared
-    64 x 64-tile weight-gradient kernel of the hidden layer (k_nl_dw_wide, RB_DW_WIDE=1), the transposed-dh operand of its
-    input gradient (dhT, default) and — batch 128, RB_DX_WIDE=1 — both wide bodies plus the priority write-back as block
-    ranges of one launch (k_nl_bwd_wide) against the oracle: loss and every gradient (the GPU runs the same check at 256; the
-    batch-128 case takes 80 s on the interpreter and runs with RB_TEST_FULL=1 only — the kernel is opt-in and GPU-tested)."""
-    monkeypatch.setenv("RB_DW_WIDE", "1")
-    monkeypatch.setenv("RB_DX_WIDE", dx_wide)
+def test_large_batch_fc_backward_matches_oracle(emu, monkeypatch):
+    """Batch 64 on the data-efficient stack with hidden 64: the batch > 32 bodies of the noisy-linear backward (weight
+    gradient without the pipelined one-pass body, the transposed-dh operand of the input gradient, image groups in the conv
+    kernels) against the oracle: loss and every gradient (the GPU runs the same check at batch 256)."""
+    nbatch = 64
     cfgd = dict(scenarios.LEARN_CONFIGS["dataeff"], batch=nbatch, multi_step=3, hidden=64)
     monkeypatch.setitem(scenarios.LEARN_CONFIGS, "wide64", cfgd)
     cfg = O.Config(**cfgd)
@@ -538,19 +549,4 @@ def test_large_batch_fc_backward_variants_match_oracle(emu, monkeypatch, nbatch,
     for k, g in clipped.items():
         scale = float(np.max(np.abs(g))) if g.size else 0.0
         np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
-    ad.close()
-
-
-@pytest.mark.parametrize("mode", ["1", "3"])
-def test_chained_conv_launch_matches_golden(emu, monkeypatch, mode):
-    """RB_CONV_CHAIN (opt-in): the conv stack of the learn step as ONE dataflow launch — block ranges per layer, per-image
-    arrival counters, epoch-based waits (mode 1: fences; 3: write-through stores + coherent loads, first layer as its own
-    launch).  Two consecutive steps (the counters are monotonic across launches) against the reference's golden vectors;
-    the bounded waits must not expire (CAbiLearnAdapter.finish_step asserts the error word)."""
-    monkeypatch.setenv("RB_CONV_CHAIN", mode)
-    name = "dataeff"
-    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
-    trace = scenarios.learn_scenario(ad, name, O, steps=2)
-    golden = load_golden("learn_%s.npz" % name)
-    assert_learn_trace_matches(trace, {k: golden[k] for k in trace}, label="emu-chain%s/%s" % (mode, name))
     ad.close()

@@ -173,43 +173,6 @@ def test_compat_path_with_foreign_replay(hip):
     assert np.all(fm.got[1] > 0)
 
 
-def test_graph_replay_matches_eager(hip, monkeypatch):
-    """Agent.learn captured into a hipGraph must follow the eager trajectory (same device Philox streams)."""
-    from rainbow_amd.agent import Agent
-    from rainbow_amd.memory import ReplayMemory
-
-    def run(graph):
-        monkeypatch.setenv("RAINBOW_AMD_GRAPH", "1" if graph else "0")   # graph replay is opt-in
-        args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
-        env = types.SimpleNamespace(action_space=lambda: 4)
-        torch.manual_seed(5)
-        np.random.seed(5)
-        agent = Agent(args, env)
-        mem = ReplayMemory(args, 2048, seed=17)
-        g = torch.Generator(device="cuda").manual_seed(1)
-        rs = np.random.RandomState(1)
-        for _ in range(2):
-            mem.append_batch(torch.randint(0, 256, (1500, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
-                             rs.randint(0, 4, 1500), rs.choice([-1.0, 0.0, 1.0], size=1500), rs.random_sample(1500) < 0.01)
-        losses = []
-        for k in range(12):
-            mem.priority_weight = min(1.0, 0.4 + 0.05 * k)      # annealed beta must reach the captured sampler
-            agent.reset_noise()
-            agent.learn(mem)
-            losses.append(agent._loss.clone())
-            if k == 6:
-                agent.update_target_net()
-        torch.cuda.synchronize()
-        assert (agent._graph is not None) == graph
-        return torch.stack(losses).cpu().numpy(), agent.params.detach().cpu().numpy(), mem._grab("tree")
-
-    le, pe, te = run(False)
-    lg, pg, tg = run(True)
-    np.testing.assert_allclose(lg, le, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(pg, pe, rtol=0, atol=2e-6)
-    np.testing.assert_allclose(tg, te, rtol=1e-4)
-
-
 @pytest.mark.parametrize("base", ["dataeff", "canon"])
 def test_wide_batch_matches_oracle(hip, monkeypatch, base):
     """Batch 64 (128 online rows): the noisy-linear forward switches to 64-row m-chunks (k_nl_fwd2<0, 4>) and the conv
@@ -248,14 +211,13 @@ BASELINE_SHAPES = {
 }
 
 
-@pytest.mark.parametrize("order", ["0", "2"], ids=["chunk-fastest", "image-fastest-forward-only"])
 @pytest.mark.parametrize("shape", ["cfg2-canonical-h512-b32-a6", "cfg3-canonical-h512-b256-a4"])
-def test_conv_block_orders_match_oracle(hip, monkeypatch, shape, order):
+def test_conv_block_orders_match_oracle(hip, monkeypatch, shape):
     """The conv launches' block order is a placement decision (which XCD's L2 holds a layer's input), never a numerical one:
-    the (chunk, tile, image) order that remains the fallback when the image count is not a multiple of 8 (RB_CONV_IMGFAST=0)
-    and the forward-only variant (2) against the oracle at the shapes the bench times; the default (1) is what every other
-    test of this file runs."""
-    monkeypatch.setenv("RB_CONV_IMGFAST", order)
+    the (chunk, tile, image) order that remains the fallback when the image count is not a multiple of 8 (RB_OPTS=img_fast=0)
+    against the oracle at the shapes the bench times; the default image-fastest order is what every other test of this file
+    runs."""
+    monkeypatch.setenv("RB_OPTS", "img_fast=0")
     test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape, False)
 
 
@@ -629,72 +591,3 @@ def test_update_target_net_copies_noise_buffers_too(hip):
     torch.cuda.synchronize()
     assert torch.equal(agent.target_noise, agent.noise) and float(agent.noise.abs().sum()) > 0
     assert torch.equal(agent.target_params, agent.params.detach())
-
-
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
-def test_chained_conv_launch_matches_oracle_at_baseline_shape(hip, monkeypatch, mode):
-    """RB_CONV_CHAIN=1/2/3 (opt-in dataflow launch of the conv stack, conv_lds.h k_conv_fwd_chain) at BASELINE cfg 2's
-    shape: three consecutive steps (monotonic arrival counters), loss / gradients / parameters against the oracle; the
-    bounded in-launch waits must not expire."""
-    from cabi_adapter import CAbiLearnAdapter, TorchMem
-    monkeypatch.setenv("RB_CONV_CHAIN", mode)
-    shape = "cfg2-canonical-h512-b32-a6"
-    cfgd = BASELINE_SHAPES[shape]
-    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
-    cfg = O.Config(**cfgd)
-    hy = scenarios.LEARN_HYPER
-    ad = CAbiLearnAdapter(hip, TorchMem(), shape)
-    online, target = O.init_params(cfg, 901), O.init_params(cfg, 902)     # (the inputs of the unchained BASELINE-shape test)
-    ad.load(online, target)
-    adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
-    draws = O.noise_draw_count(cfg)
-    rs = np.random.RandomState(55)
-    got_t, want_t = {}, {}
-    for k in range(3):
-        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
-        ad.reset_noise_online(raw_on)
-        batch = scenarios.make_batch(cfgd, 700 + k)
-        got = ad.learn_step(batch, raw_tg)
-        want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
-        total, clipped = O.clip_grads(want["grads"], hy["norm_clip"])
-        online = adam.step(clipped)
-        got_t["s%d_loss" % k], want_t["s%d_loss" % k] = got["loss"], want["loss"]
-        for name in clipped:
-            got_t["s%d_grad/%s" % (k, name)], want_t["s%d_grad/%s" % (k, name)] = got["grads"][name], clipped[name]
-    for name, p in ad.params().items():
-        got_t["s2_param/%s" % name], want_t["s2_param/%s" % name] = p, online[name]
-    assert_learn_trace_matches(got_t, want_t, label="hip-chain%s/%s" % (mode, shape))
-    assert int(ad.debug(5, (1,), np.int32)[0]) == 0
-    ad.close()
-
-
-@pytest.mark.parametrize("env", [{"RB_DW_WIDE": "1"}, {"RB_DX_WIDE": "1"}, {"RB_DW_WIDE": "1", "RB_DX_WIDE": "1"}],
-                         ids=["dw-wide", "dx-wide", "both-wide"])
-def test_large_batch_hidden_layer_backward_kernels_match_oracle(hip, monkeypatch, env):
-    """The opt-in large-batch kernels of the hidden layer's backward (k_nl_dw_wide: LDS-shared 64 x 64 gradient tiles;
-    k_nl_dx_wide: weight-stationary input gradient on the transposed dh) at BASELINE cfg 3's shape (batch 256): loss, norm
-    and every gradient against the oracle."""
-    from cabi_adapter import CAbiLearnAdapter, TorchMem
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    shape = "cfg3-canonical-h512-b256-a4"
-    cfgd = BASELINE_SHAPES[shape]
-    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
-    cfg = O.Config(**cfgd)
-    ad = CAbiLearnAdapter(hip, TorchMem(), shape)
-    online, target = O.init_params(cfg, 921), O.init_params(cfg, 922)
-    ad.load(online, target)
-    rs = np.random.RandomState(57)
-    draws = O.noise_draw_count(cfg)
-    raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
-    ad.reset_noise_online(raw_on)
-    batch = scenarios.make_batch(cfgd, 900)
-    got = ad.learn_step(batch, raw_tg)
-    want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
-    total, clipped = O.clip_grads(want["grads"], scenarios.LEARN_HYPER["norm_clip"])
-    np.testing.assert_allclose(got["loss"], want["loss"], rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(got["grad_norm"], total, rtol=5e-5)
-    for k, g in clipped.items():
-        scale = float(np.max(np.abs(g))) if g.size else 0.0
-        np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
-    ad.close()
