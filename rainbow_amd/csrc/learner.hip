@@ -163,6 +163,8 @@ struct rb_learner {
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
   int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_img_fast;
+  int opt_prefetch;     // L2 warm-up tenants (HeadPrefetch)
+  int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   float* dw_part[3];    // [ws_l][cout][K+1]
   float* log_ps_a;      // [B][Z]
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k_pack_factors(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------- head --
-// One workgroup (256 threads) per sample b.  Dueling combine (model.py:74-75), log-softmax of
+// One workgroup per sample b.  Dueling combine (model.py:74-75), log-softmax of
 // the taken action (agent.py:66-67), double-Q argmax on the online net (agent.py:71-73), target
 // probabilities of that action (agent.py:75-76), C51 projection with the atom bins staged in LDS
 // and accumulated in the reference's order (agent.py:79-92), cross-entropy (agent.py:94) and
@@ -378,20 +380,23 @@ __device__ __forceinline__ float rb_dueling_q(const float* lg, const float* mean
   return (lg[z] + lg[Z + a * Z + z]) - mean_a[z];
 }
 
-// One 256-thread workgroup per sample.  The three logit rows (3*(Z + A*Z) floats) are pulled into LDS with one
-// coalesced sweep; after that the kernel touches global memory only for its outputs.  Work is spread over the four
-// waves: the A actions of the double-Q selection go round-robin over the waves; then wave 0 does the target
-// softmax + projection inputs while wave 1 does the online log-softmax of the taken action in parallel.  Every
-// reduction over atoms is a wave64 butterfly (each lane owns atoms z = lane, lane+64, ...).
-#define RB_ZI (RB_MAX_ATOMS / 64)
+// One workgroup per sample.  The three logit rows (3*(Z + A*Z) floats) are pulled into LDS with one coalesced sweep; after
+// that the kernel touches global memory only for its outputs.  ALL softmaxes of the sample are independent tasks spread over
+// the waves in ONE phase: the A double-Q softmaxes of online(next_states) (agent.py:71-73), the A candidate softmaxes of
+// target(next_states) — computed for every action while a* is still unknown instead of for a* alone afterwards (round 3's
+// per-workgroup timeline: 1.4 us double-Q, then 2.0 us for the two remaining softmaxes on two of eight waves) — and the
+// log-softmax of online(states)[action].  Every reduction over atoms is a wave64 DPP reduction (each lane owns atoms
+// z = lane, lane + 64, ...; ZI = ceil(Z / 64) is a template parameter: 51 atoms are ONE slot per lane, the former fixed four
+// slots quadrupled the instruction count of a phase that runs at one lone wave's issue rate).
 #define RB_MAX_NZ RB_HEAD_MAX_NZ
 
+template <int ZI>
 struct HeadWave {
   int lane;
   // dueling mean over actions for this lane's atoms: a.mean(1)            model.py:75
   __device__ void mean_of(const float* lg, int Z, int A, float* mean) const {
 #pragma unroll
-    for (int i = 0; i < RB_ZI; ++i) {
+    for (int i = 0; i < ZI; ++i) {
       const int z = lane + 64 * i;
       float acc = 0.0f;
       if (z < Z)
@@ -403,7 +408,7 @@ struct HeadWave {
   __device__ float softmax_of(const float* lg, int Z, const float* mean, int a, float* e, float* qm) const {
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < RB_ZI; ++i) {
+    for (int i = 0; i < ZI; ++i) {
       const int z = lane + 64 * i;
       qm[i] = z < Z ? (lg[z] + lg[Z + a * Z + z]) - mean[i] : -INFINITY;   // q = v + a - mean_a(a)
       mx = fmaxf(mx, qm[i]);
@@ -411,7 +416,7 @@ struct HeadWave {
     mx = rb_wave_max(mx);
     float se = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RB_ZI; ++i) {
+    for (int i = 0; i < ZI; ++i) {
       const int z = lane + 64 * i;
       qm[i] = z < Z ? qm[i] - mx : 0.0f;
       e[i] = z < Z ? expf(qm[i]) : 0.0f;
@@ -421,52 +426,113 @@ struct HeadWave {
   }
 };
 
-// 8 waves: with 6 actions every action's softmax of the double-Q selection has a wave of its own (4 waves needed two
-// rounds: 2.4 us of the kernel's 8)
-#define RB_HEAD_THREADS 512
+// L2 warm-up tenants.  The NEXT launch (the output layer's backward) starts with every weight line cold: the optimiser pass
+// stored the parameters write-through (the lines left the L2s), and the forward pulled each 16-row tile into ONE XCD's L2 —
+// the input-gradient workgroup of column tile bx, which reads ALL rows of its 64 columns, runs on another XCD and pays a
+// fabric round trip per dependent batch of loads (5 batches: 8-11.5 us of a 11.8 us launch, profiles/round4_*timeline*).
+// This launch has 32 busy CUs of 256: 8 extra workgroups, one per XCD (workgroup index mod 8 = XCD), request exactly the
+// column tiles the next launch's workgroups of THAT XCD will read and drop the values — the lines are then in the right L2.
+struct HeadPrefetch {
+  const float* mu;       // [rows][K]
+  const float* sigma;
+  int rows, K;
+  int tiles;             // 64-column tiles per row
+  int next_first;        // block index of column tile 0's workgroup in the next launch (its XCD = index mod 8)
+  int period;            // ... and of tile bx: next_first + bx (+ period for the second problem: same XCD when period % 8 == 0)
+};
+__device__ __forceinline__ void rb_l2_prefetch_tiles(const HeadPrefetch& pf, int tenant, int my_block) {
+  if (!pf.mu) return;
+  (void)tenant;
+  const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  float acc = 0.0f;
+  for (int bx = 0; bx < pf.tiles; ++bx) {
+    if (((pf.next_first + bx) & 7) != (my_block & 7)) continue;        // block-uniform: tiles whose consumer shares this XCD
+    for (int r0 = 4 * wave; r0 < pf.rows; r0 += 4 * nw) {
+      int r = r0 + q;
+      if (r > pf.rows - 1) r = pf.rows - 1;
+      const float4 a = rb_ld4(pf.mu + (int64_t)r * pf.K + 64 * bx + 4 * c);
+      const float4 b = rb_ld4(pf.sigma + (int64_t)r * pf.K + 64 * bx + 4 * c);
+      acc += a.x + b.x;
+    }
+  }
+#if !defined(RB_HOST_INTERP)
+  asm volatile("" ::"v"(acc));                                           // the loads must be issued; their values are dropped
+#else
+  (void)acc;
+#endif
+}
+
+#define RB_HEAD_THREADS 1024      // launch bound; the launch uses 64 x min(16, max(8, 2A + 1)) threads
+template <int ZI>
 __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
                                                const float* returns, const float* nonterminals, const float* weights,
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
                                                int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr,
-                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT) {
+                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT, HeadPrefetch pf) {
+  if ((int)blockIdx.x >= B) { rb_l2_prefetch_tiles(pf, (int)blockIdx.x - B, (int)blockIdx.x); return; }   // tenants: see HeadPrefetch
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
-  __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS];
+  __shared__ float s_pt[RB_MAX_NZ];                  // target(next) probabilities of EVERY action: [a][z] at a * Z + z
+  __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS], s_sup[RB_MAX_ATOMS];
   __shared__ int s_l[RB_MAX_ATOMS], s_u[RB_MAX_ATOMS];
   __shared__ float s_ev[RB_MAX_ACTIONS];
   __shared__ float s_scal[2];                        // sum(m), -loss
-  const int t = (int)threadIdx.x, lane = rb_lane(), wave = rb_wave();
+  const int t = (int)threadIdx.x, T = (int)blockDim.x, lane = rb_lane(), wave = rb_wave(), nw = T >> 6;
   const int b = (int)blockIdx.x;
   const int NZ = Z + A * Z;
   RB_WGT(7, b, 0);
   RB_WGT_HW(7, b);
-  for (int i = t; i < NZ; i += RB_HEAD_THREADS) {
+  for (int i = t; i < NZ; i += T) {
     s_lg[0][i] = logits[(int64_t)b * NZ + i];
     s_lg[1][i] = logits[(int64_t)(B + b) * NZ + i];
     s_lg[2][i] = logits[(int64_t)(2 * B + b) * NZ + i];
   }
+  for (int z = t; z < Z; z += T) s_sup[z] = support[z];  // requested with the logits: one memory round trip, not two
   const float R = returns[b], nt = nonterminals[b], wgt = weights[b];
   const int act = (int)actions[b];
-  float sup[RB_ZI];                                  // requested with the logits: one memory round trip, not two
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) { const int z = lane + 64 * i; sup[i] = support[z < Z ? z : Z - 1]; }
   __syncthreads();
   RB_WGT(7, b, 1);
-#pragma unroll
-  for (int i = 0; i < RB_ZI; ++i) sup[i] = lane + 64 * i < Z ? sup[i] : 0.0f;
-  HeadWave hw;
+  HeadWave<ZI> hw;
   hw.lane = lane;
-  float mean[RB_ZI], e[RB_ZI], qm[RB_ZI];
+  float mean[ZI], e[ZI], qm[ZI];
 
-  // ---------------- double-Q selection on online(next_states)   agent.py:71-73   (actions round-robin over waves)
-  hw.mean_of(s_lg[1], Z, A, mean);
-  for (int a = wave; a < A; a += RB_HEAD_THREADS / 64) {
-    const float se = hw.softmax_of(s_lg[1], Z, mean, a, e, qm);
-    float sv = 0.0f;
+  // ---------------- every softmax of the sample, one task per wave (round-robin when 2A + 1 exceeds the wave count)
+  for (int task = wave; task < 2 * A + 1; task += nw) {                 // wave-uniform
+    if (task < A) {
+      // double-Q selection on online(next_states)   agent.py:71-73
+      hw.mean_of(s_lg[1], Z, A, mean);
+      const float se = hw.softmax_of(s_lg[1], Z, mean, task, e, qm);
+      float sv = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RB_ZI; ++i) sv += sup[i] * e[i];
-    sv = rb_wave_sum(sv);
-    if (lane == 0) s_ev[a] = sv / se;                             // sum_z z * p(z)
+      for (int i = 0; i < ZI; ++i) sv += (lane + 64 * i < Z ? s_sup[lane + 64 * i] : 0.0f) * e[i];
+      sv = rb_wave_sum(sv);
+      if (lane == 0) s_ev[task] = sv / se;                            // sum_z z * p(z)
+    } else if (task < 2 * A) {
+      // target(next_states)[a] probabilities for candidate a   agent.py:75-76
+      const int a = task - A;
+      hw.mean_of(s_lg[2], Z, A, mean);
+      const float se = hw.softmax_of(s_lg[2], Z, mean, a, e, qm);
+#pragma unroll
+      for (int i = 0; i < ZI; ++i) {
+        const int z = lane + 64 * i;
+        if (z < Z) s_pt[a * Z + z] = e[i] / se;
+      }
+    } else {
+      // online(states): log p(s_t, a_t)            agent.py:66-67
+      hw.mean_of(s_lg[0], Z, A, mean);
+      const float se = hw.softmax_of(s_lg[0], Z, mean, act, e, qm);
+      const float lse = logf(se);
+#pragma unroll
+      for (int i = 0; i < ZI; ++i) {
+        const int z = lane + 64 * i;
+        if (z < Z) {
+          const float lp = qm[i] - lse;                             // log_softmax = (q - max) - log(sum exp(q - max))
+          s_logp[z] = lp;
+          log_ps_a_out[(int64_t)b * Z + z] = lp;
+        }
+      }
+    }
   }
   __syncthreads();
   RB_WGT(7, b, 2);
@@ -483,42 +549,20 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     if (status_copy) *status_copy = st;
     if (step_ctr && st == 0) *step_ctr = *step_ctr + 1;
   }
-
-  if (wave == 0) {
-    // ---------------- target(next_states)[a*] probabilities      agent.py:75-76, projection inputs agent.py:79-86
-    hw.mean_of(s_lg[2], Z, A, mean);
-    const float se = hw.softmax_of(s_lg[2], Z, mean, a_star, e, qm);
-#pragma unroll
-    for (int i = 0; i < RB_ZI; ++i) {
-      const int z = lane + 64 * i;
-      if (z < Z) {
-        const float p = e[i] / se;
-        pns_a_out[(int64_t)b * Z + z] = p;
-        float Tz = R + (nt * gamma_n) * sup[i];                   // agent.py:79
-        Tz = fminf(fmaxf(Tz, v_min), v_max);                      // agent.py:80
-        const float bq = (Tz - v_min) / delta_z;                  // agent.py:82
-        int l = (int)floorf(bq), u = (int)ceilf(bq);              // agent.py:83
-        if (u > 0 && l == u) l -= 1;                              // agent.py:85
-        if (l < Z - 1 && l == u) u += 1;                          // agent.py:86
-        s_l[z] = l; s_u[z] = u;
-        s_lo[z] = p * ((float)u - bq);                            // agent.py:91
-        s_hi[z] = p * (bq - (float)l);                            // agent.py:92
-      }
-    }
-  } else if (wave == 1) {
-    // ---------------- online(states): log p(s_t, a_t)            agent.py:66-67
-    hw.mean_of(s_lg[0], Z, A, mean);
-    const float se = hw.softmax_of(s_lg[0], Z, mean, act, e, qm);
-    const float lse = logf(se);
-#pragma unroll
-    for (int i = 0; i < RB_ZI; ++i) {
-      const int z = lane + 64 * i;
-      if (z < Z) {
-        const float lp = qm[i] - lse;                             // log_softmax = (q - max) - log(sum exp(q - max))
-        s_logp[z] = lp;
-        log_ps_a_out[(int64_t)b * Z + z] = lp;
-      }
-    }
+  // ---------------- projection inputs from the selected action's probabilities      agent.py:79-86
+  for (int z = t; z < Z; z += T) {
+    const float p = s_pt[a_star * Z + z];
+    pns_a_out[(int64_t)b * Z + z] = p;
+    float Tz = R + (nt * gamma_n) * s_sup[z];                 // agent.py:79
+    Tz = fminf(fmaxf(Tz, v_min), v_max);                      // agent.py:80
+    const float bq = (Tz - v_min) / delta_z;                  // agent.py:82
+    int l = (int)floorf(bq), u = (int)ceilf(bq);              // agent.py:83
+    if (u > 0 && l == u) l -= 1;                              // agent.py:85
+    if (l < Z - 1 && l == u) u += 1;                          // agent.py:86
+    s_l[z] = l; s_u[z] = u;
+    s_lo[z] = p * ((float)u - bq);                            // agent.py:91
+    s_hi[z] = p * (bq - (float)l);                            // agent.py:92
+    s_m[z] = 0.0f;
   }
   __syncthreads();
   RB_WGT(7, b, 3);
@@ -526,10 +570,8 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   // b is monotone in the atom index (support increasing, nt*gamma^n >= 0), so equal l (and equal u) form
   // contiguous runs: the first atom of a run owns its bin and adds the run left to right — exactly the order of
   // the reference's first index_add_ (all l bins, j ascending) followed by the second (u bins) on the same m.
-  for (int k = t; k < Z; k += RB_HEAD_THREADS) s_m[k] = 0.0f;
-  __syncthreads();
   {
-    for (int j = t; j < Z; j += RB_HEAD_THREADS) {
+    for (int j = t; j < Z; j += T) {
       const int key = s_l[j];
       if (j == 0 || s_l[j - 1] != key) {
         float acc = 0.0f;
@@ -538,7 +580,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
       }
     }
     __syncthreads();
-    for (int j = t; j < Z; j += RB_HEAD_THREADS) {
+    for (int j = t; j < Z; j += T) {
       const int key = s_u[j];
       if (j == 0 || s_u[j - 1] != key) {
         float acc = s_m[key];
@@ -549,7 +591,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   }
   __syncthreads();
   RB_WGT(7, b, 4);
-  for (int k = t; k < Z; k += RB_HEAD_THREADS) m_out[(int64_t)b * Z + k] = s_m[k];
+  for (int k = t; k < Z; k += T) m_out[(int64_t)b * Z + k] = s_m[k];
   if (wave == 0) {                                                // loss = -sum m * log p   agent.py:94
     float pl = 0.0f, pm = 0.0f;
     for (int z = lane; z < Z; z += 64) { pl += s_m[z] * s_logp[z]; pm += s_m[z]; }
@@ -565,7 +607,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   const float coef = wgt / (float)B;
   const float msum = s_scal[0];
   float* dl = dlogits + (int64_t)b * NZ;
-  for (int i = t; i < NZ; i += RB_HEAD_THREADS) {
+  for (int i = t; i < NZ; i += T) {
     const int z = i < Z ? i : (i - Z) % Z;
     const float g = coef * (expf(s_logp[z]) * msum - s_m[z]);
     float o;
@@ -1331,6 +1373,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
+  l->opt_prefetch = rb_opt("prefetch", 1);
+  l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_t16 = rb_opt("t16", 6);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
@@ -1643,9 +1687,29 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   const NetPtrs tg = net_ptrs(L, l->p_target, l->n_target);
   int rc = forward(l, 2 * B, B, src, on, tg, stream);
   if (rc != RB_OK) return rc;
-  RB_LAUNCH(k_head, dim3((unsigned)B), dim3(RB_HEAD_THREADS), stream, B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev,
-            nonterminals_dev, weights_dev, (const float*)l->support, l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z,
-            l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr, l->batch_status, l->status_copy, l->dlogitsT);
+  {
+    // threads: one wave per softmax task (2A + 1) up to 16 waves, at least 8 (the logits sweep and the dlogits store want lanes)
+    int hwaves = 2 * L.A + 1;
+    if (hwaves < 8) hwaves = 8;
+    if (hwaves > 16) hwaves = 16;
+    HeadPrefetch pf;
+    memset(&pf, 0, sizeof(pf));
+    if (l->fast_fc && l->opt_prefetch && L.H % 64 == 0) {     // the output layer's backward follows: its dX tiles (learn_impl below)
+      const int vt_ = (int)rb_div_up(L.Z, 16), at_ = (int)rb_div_up(L.NZ - L.Z, 16);
+      pf.mu = on.z_mu; pf.sigma = on.z_sigma; pf.rows = L.NZ; pf.K = L.H; pf.tiles = L.H / 64;
+      pf.next_first = (int)rb_div_up(L.H, 512) * (vt_ + at_);       // = zg.dw_x * zg.dw_y with z_ct = 2 (batch <= 32)
+      pf.period = pf.tiles;
+      if (B > 32 || (l->world > 1 && l->fact_local)) pf.mu = nullptr;   // other grid shapes: no warm-up
+    }
+    const dim3 hgrid((unsigned)(B + (pf.mu ? 8 : 0))), hblock((unsigned)(64 * hwaves));
+#define RB_HEAD_ARGS B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev, nonterminals_dev, weights_dev, (const float*)l->support, \
+    l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z, l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr,          \
+    l->batch_status, l->status_copy, l->dlogitsT, pf
+    if (L.Z <= 64) { RB_LAUNCH_T("head:k_head", k_head<1>, hgrid, hblock, stream, RB_HEAD_ARGS); }
+    else if (L.Z <= 128) { RB_LAUNCH_T("head:k_head", k_head<2>, hgrid, hblock, stream, RB_HEAD_ARGS); }
+    else { RB_LAUNCH_T("head:k_head", k_head<4>, hgrid, hblock, stream, RB_HEAD_ARGS); }
+#undef RB_HEAD_ARGS
+  }
   RB_LAUNCH_CHECK();
 
   // ---- backward (online net, images [0,B)).  The input-gradient chain (fc_z dX -> fc_h dX -> conv dX ...) is the critical
@@ -1683,6 +1747,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     zx.rows_per_split = (int)rb_div_up(L.NZ, 16) * 16;
     zx.out = l->dh; zx.ld_out = 2 * L.H; zx.mask_src = l->h;
     zx.dyT = l->dlogitsT; zx.ldyT = B; zx.outT = l->dhT;
+    // the output layer's input gradient with eight waves per workgroup (noisy_linear.h rb_nl_dx_body_tall) at batch <= 32
+    // (RB_OPTS z_tall=0: the four-wave body)
+    const int z_tall = (l->opt_z_tall && B <= 32) ? 1 : 0;
     NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
     // ---- hidden layer
     NlDxArgs hx;
@@ -1706,8 +1773,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     {
       NlPriorityUpdate none;
       memset(&none, 0, sizeof(none));
-      RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd, dim3((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z)), dim3(256), stream,
-                  zw, zx, zg, none);
+      const dim3 zgrid_((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z));
+      if (z_tall) { RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd<true>, zgrid_, dim3(64 * RB_NL_DXT_WAVES), stream, zw, zx, zg, none); }
+      else { RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd<false>, zgrid_, dim3(256), stream, zw, zx, zg, none); }
       if (exch) {
         // every factor of the FC weight gradients exists now (dlogits, h, dh, feat rows [0, B)): pack them into this rank's
         // exchange block; the conv gradients join it at the end of the backward (k_reduce_conv_dw_all stores them twice)
@@ -1724,7 +1792,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
       // the priority write-back (a single-workgroup latency chain of ~11 us) rides in the LONGER of the two backward
       // launches: as a tenant of the output layer's launch (~8 us of real work) it was that launch's long pole
       const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + (up.enabled ? 1 : 0));
-      if (h_blocks > 0) { RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up); }
+      if (h_blocks > 0) { RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd<false>, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up); }
     }
     l->sink_done = up.enabled ? 1 : 0;
     RB_LAUNCH_CHECK();

@@ -297,6 +297,10 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
 
   // (staging this workgroup's dY slab in LDS first — row-contiguous loads instead of 16 dy rows per instruction —
   // measured slower: k_nl_bwd 16.7 -> 18.0 us; dY is 128 KB and L1/L2-resident, the extra phase costs more)
+#if defined(RB_STAMP)
+  const int kid_ = a.K > 1000 ? 9 : 8;
+  RB_WGT(kid_, (int)blockIdx.x, 2);
+#endif
   for (int nb = wr0; nb < wr1; nb += 16) {               // 4 row-steps of loads in flight per iteration
     float4 w4[4];
     float av[4][4];
@@ -327,7 +331,13 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
         }
       }
     }
+#if defined(RB_STAMP)
+    if (nb == wr0) RB_WGT(kid_, (int)blockIdx.x, 3);
+#endif
   }
+#if defined(RB_STAMP)
+  RB_WGT(kid_, (int)blockIdx.x, 4);
+#endif
   // cross-wave sum in a fixed order, (w0 + w2) + (w1 + w3), through two 16 KB tiles instead of four (the LDS footprint
   // sets how many workgroups of the fused backward launch a CU holds)
   if (wave >= 2) {
@@ -357,6 +367,9 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
         for (int j = 0; j < 4; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
   }
   __syncthreads();
+#if defined(RB_STAMP)
+  RB_WGT(kid_, (int)blockIdx.x, 5);
+#endif
   const int slots = mt_cnt * 4;                          // (mt, e) pairs; j is the float4 lane
   for (int idx = (int)threadIdx.x; idx < slots * 64; idx += 256) {
     const int slot = idx >> 6, l = idx & 63;
@@ -387,6 +400,123 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
     }
   }
 }
+// Tall form for SMALL weight matrices at batch <= 32 (the output layer: 357 x 512, 1.46 MB of mu | sigma): the same 64-column
+// tiles, EIGHT waves per workgroup.  With four waves the advantage stream's 306 rows are 80 rows per wave = five dependent
+// load -> MFMA iterations of ~1.5 us each (a memory round trip here is ~0.8 us, the 32 MFMAs behind it 0.4 us, nothing
+// overlaps: 8.7 of the workgroup's 12.1 us, tools/wg_timeline.py; 16-column tiles on four times the workgroups measured
+// SLOWER — 17 us — their dword loads cost more issue than the bytes they save per CU).  Eight waves take 40 rows each in ONE batch of loads: one
+// round trip, 10 MFMAs per accumulator chain, then one LDS pass sums the eight partial tiles in wave order.
+// Non-split launches with M <= 32 only; block = 64 * RB_NL_DXT_WAVES threads.
+#define RB_NL_DXT_WAVES 8        // (16 waves = 1024 threads cap the kernel at 128 registers: the weight-gradient body of the same launch spilled)
+#define RB_NL_DXT_LDS (RB_NL_DXT_WAVES * 32 * 64)
+__device__ __forceinline__ void rb_nl_dx_body_tall(const NlDxArgs& a, int bx, int bz, float* lds) {
+  float (*s_red)[32][64] = reinterpret_cast<float (*)[32][64]>(lds);   // [waves][(mt * 4 + e) * 4 + j][lane]
+  const int lane = rb_lane(), wave = rb_wave();
+  const int pi = bz % a.n_prob;
+  const NlDxProblem pr = a.prob[pi];
+  const int mt_cnt = (a.M + 15) / 16;                     // <= 2
+  const int K = a.K;
+  const int kt = bx * 64;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  constexpr int ST = 10;                                  // row-steps of 4 rows in flight per wave: 40 rows
+  const int per_wave = ((pr.row_cnt + RB_NL_DXT_WAVES - 1) / RB_NL_DXT_WAVES + 3) / 4 * 4;   // rows per wave, multiple of 4
+  const int wr0 = pr.row_begin + wave * per_wave;
+  int wr1 = wr0 + per_wave;
+  if (wr1 > row_end) wr1 = row_end;
+  const int c = lane & 15, q = lane >> 4;
+  int col4 = kt + 4 * c;
+  if (col4 > K - 4) col4 = K - 4;                        // clamped lanes are never stored
+  const float4 e0 = rb_ld4(a.w.ein + pr.ein_off0 + col4);
+  const float4 e1 = rb_ld4(a.w.ein + pr.ein_off1 + col4);
+  // the ReLU mask of this thread's output cells: requested with the operands (in the epilogue: one more dependent trip)
+  constexpr int TT = 64 * RB_NL_DXT_WAVES, EIT = (8 * 64 + TT - 1) / TT;     // 8 (mt, e) slots x 64 lanes over the threads
+  float4 msk[EIT];
+  int64_t oidx[EIT];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int idx = (int)threadIdx.x + it * TT;            // slot = idx >> 6 over (mt, e), lane = idx & 63
+    const int slot = idx >> 6, l = idx & 63;
+    const int m = 16 * (slot >> 2) + 4 * (l >> 4) + (slot & 3);
+    int k = kt + 4 * (l & 15);
+    if (k > K - 4) k = K - 4;
+    oidx[it] = (int64_t)(m < a.M ? m : a.M - 1) * a.ld_out + pr.out_off + k;
+    msk[it] = a.mask_src ? rb_ld4(a.mask_src + oidx[it]) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+  }
+  rb_f32x4 acc[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][j][e] = 0.0f;
+  for (int nb = wr0; nb < wr1; nb += 4 * ST) {            // (one pass for up to 320 rows per problem)
+    float4 w4[ST];
+    float av[ST][2];
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      const int n = nb + 4 * st + q;
+      const bool nv = n < wr1;
+      const int nc = nv ? n : wr1 - 1;
+      w4[st] = rb_noisy4(rb_ld4(a.w.mu + (int64_t)nc * K + col4), rb_ld4(a.w.sigma + (int64_t)nc * K + col4),
+                         a.w.eout[nc], nc >= pr.ein_split_row ? e1 : e0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = 16 * mt + c;
+        av[st][mt] = (mt < mt_cnt && nv && m < a.M) ? (a.dyT ? a.dyT[(int64_t)n * a.ldyT + m] : a.dy[(int64_t)m * a.ldy + n]) : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      if (nb + 4 * st < wr1) {                             // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (mt < mt_cnt) {
+            acc[mt][0] = rb_mfma16(av[st][mt], w4[st].x, acc[mt][0]);
+            acc[mt][1] = rb_mfma16(av[st][mt], w4[st].y, acc[mt][1]);
+            acc[mt][2] = rb_mfma16(av[st][mt], w4[st].z, acc[mt][2]);
+            acc[mt][3] = rb_mfma16(av[st][mt], w4[st].w, acc[mt][3]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int idx = (int)threadIdx.x + it * TT;
+    const int slot = idx >> 6, l = idx & 63;
+    if (slot >= mt_cnt * 4) continue;
+    float4 v;
+    float* vv = &v.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = s_red[0][slot * 4 + j][l];
+#pragma unroll
+      for (int w = 1; w < RB_NL_DXT_WAVES; ++w) s += s_red[w][slot * 4 + j][l];     // fixed order w0, w1, ...
+      vv[j] = s;
+    }
+    const int m = 16 * (slot >> 2) + 4 * (l >> 4) + (slot & 3);
+    const int k = kt + 4 * (l & 15);
+    if (m < a.M && k < K) {
+      if (a.mask_src) {
+        v.x = msk[it].x > 0.0f ? v.x : 0.0f; v.y = msk[it].y > 0.0f ? v.y : 0.0f;
+        v.z = msk[it].z > 0.0f ? v.z : 0.0f; v.w = msk[it].w > 0.0f ? v.w : 0.0f;
+      }
+      rb_st4(a.out + oidx[it], v);
+      if (a.outT && a.mask_src) {
+        float* ot = a.outT + (int64_t)(pr.out_off + k) * a.M + m;
+        ot[0] = v.x; ot[a.M] = v.y; ot[2 * (int64_t)a.M] = v.z; ot[3 * (int64_t)a.M] = v.w;
+      }
+    }
+  }
+}
+
 // ===================================================================== weight gradient ==
 // g_mu[n][k] = sum_m dy[m][n] * x[m][x_off + k] ; g_sigma = g_mu * (eps_out[n]*eps_in[k]) ;
 // g_bmu[n] = sum_m dy[m][n] ; g_bsigma = g_bmu * eps_out[n].   One writer per element.
@@ -746,34 +876,53 @@ extern __device__ long long g_span[64];
 #define RB_SPAN_BEGIN(slot) ((void)0)
 #define RB_SPAN_END(slot) ((void)0)
 #endif
-__global__ __launch_bounds__(256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g, NlPriorityUpdate up) {
+// TALL: 512-thread workgroups whose input-gradient blocks run rb_nl_dx_body_tall (the output layer at batch <= 32: 40
+// workgroups, LDS and occupancy are no concern); its weight-gradient blocks use the first four waves, the others leave.
+template <bool TALL>
+__global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(NlDwArgs dw, NlDxArgs dx, NlBwdGrid g, NlPriorityUpdate up) {
   // ONE LDS buffer for whichever body this workgroup runs (separate static arrays would add up: 132 KB, one workgroup
   // per CU for the whole launch; 32 KB lets five share a CU)
-  constexpr int LDSW = RB_NL_DX_LDS > UpdateLds<512, 256>::WORDS ? RB_NL_DX_LDS : UpdateLds<512, 256>::WORDS;
+  constexpr int LDS0 = RB_NL_DX_LDS > UpdateLds<512, 256>::WORDS ? RB_NL_DX_LDS : UpdateLds<512, 256>::WORDS;
+  constexpr int LDSW = TALL ? (RB_NL_DXT_LDS > LDS0 ? RB_NL_DXT_LDS : LDS0) : LDS0;
   __shared__ __attribute__((aligned(16))) float lds[LDSW];
   // the write-back block goes FIRST: it is the launch's longest single-workgroup chain and must not queue behind the tiles
   int b = (int)blockIdx.x;
   const int sb = dw.K > 1000 ? 3 : 0;                    // RB_STAMP builds: span slots of the hidden / output layer launch
   (void)sb;
+  // RB_STAMP builds: per-workgroup timeline (tools/nl_timeline.py): kernel id 8 = output layer's launch, 9 = hidden layer's;
+  // slot 0 start, 1 role (0 write-back, 1 dW, 2 dX), 6 end, 7 where it ran
+  const int kid = dw.K > 1000 ? 9 : 8, wgb = (int)blockIdx.x;
+  (void)kid; (void)wgb;
+  RB_WGT(kid, wgb, 0);
+  RB_WGT_HW(kid, wgb);
   if (up.enabled) {
+    if (TALL && threadIdx.x >= 256 && b == 0) return;    // (the write-back body is written for 256 threads)
     if (b == 0) {
       RB_SPAN_BEGIN(sb + 0);
       rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // n <= 256
       RB_SPAN_END(sb + 0);
+      RB_WGT_ROLE(kid, wgb, 0);
+      RB_WGT(kid, wgb, 6);
       return;
     }
     b -= 1;
   }
   const int ndw = g.dw_x * g.dw_y;
   if (b < ndw) {
+    if (TALL && threadIdx.x >= 256) return;              // the weight-gradient bodies are 4-wave bodies (their barriers count
+                                                         // the waves that are still alive)
     RB_SPAN_BEGIN(sb + 1);
     if (dw.ct > 0) rb_nl_dw_body_pipe(dw, b % g.dw_x, b / g.dw_x, 4 * b);
     else rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
     RB_SPAN_END(sb + 1);
+    RB_WGT_ROLE(kid, wgb, 1);
   } else {
     const int r = b - ndw;
     RB_SPAN_BEGIN(sb + 2);
-    rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
+    if constexpr (TALL) rb_nl_dx_body_tall(dx, r % g.dx_x, r / g.dx_x, lds);
+    else rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     RB_SPAN_END(sb + 2);
+    RB_WGT_ROLE(kid, wgb, 2);
   }
+  RB_WGT(kid, wgb, 6);
 }

@@ -30,6 +30,8 @@ struct Barrier {
 Fiber g_fibers[kMaxThreads];
 ucontext_t g_sched;
 int g_nthreads = 0;
+int g_live = 0;      // threads of the current block that have not returned: what a block barrier waits for (as s_barrier
+                     // counts the waves that are still alive — kernels may retire whole waves before a barrier)
 int g_current = -1;
 unsigned long g_progress = 0;  // bumped whenever any barrier releases or a fiber ends
 Barrier g_block_bar;
@@ -42,11 +44,22 @@ void yield_to_scheduler() {
   swapcontext(&f.ctx, &g_sched);
 }
 
+void thread_retired();
 void trampoline() {
   (*g_body)();
   g_fibers[g_current].done = true;
   ++g_progress;
+  thread_retired();
   yield_to_scheduler();
+}
+
+void thread_retired() {
+  --g_live;
+  if (g_live > 0 && g_block_bar.count == g_live) {      // everyone still alive is already parked at the block barrier
+    g_block_bar.count = 0;
+    ++g_block_bar.gen;
+    ++g_progress;
+  }
 }
 
 void wait_on(Barrier& b, int participants) {
@@ -69,7 +82,7 @@ int wave_width() {
   return rem >= 64 ? 64 : rem;
 }
 uint64_t* wave_slots(int which) { return g_slots[which][wave_id()]; }
-void block_barrier() { wait_on(g_block_bar, g_nthreads); }
+void block_barrier() { wait_on(g_block_bar, g_live); }
 void wave_barrier() { wait_on(g_wave_bar[wave_id()], wave_width()); }
 
 void launch(const std::function<void()>& body, dim3 grid, dim3 block) {
@@ -104,6 +117,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block) {
               f.ctx.uc_link = &g_sched;
               makecontext(&f.ctx, (void (*)())trampoline, 0);
             }
+        g_live = nthreads;
         int remaining = nthreads;
         while (remaining > 0) {
           unsigned long before = g_progress;

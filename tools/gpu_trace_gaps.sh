@@ -15,12 +15,12 @@ f = glob.glob("gpurun_out/gaps/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # the timed region: the last 40 k_head launches delimit steps (one per learn call; the optimiser pass may be hosted by the
 # sampler launch, RB_LEARNER_DEFER_UPDATE, so k_clip_adam is not a per-step launch any more)
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_head(")]
+idx = [i for i, r in enumerate(rows) if "k_head<" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_head(")]
 lo, hi = idx[-41], idx[-1]
 dur = collections.defaultdict(list); gap = collections.defaultdict(list)
 for i in range(lo + 1, hi + 1):
     r, p = rows[i], rows[i - 1]
-    name = r["Kernel_Name"].split("(")[0][:48] + ("|" + str(r.get("Grid_Size") or r.get("Grid_Size_X")) if "k_nl_" in r["Kernel_Name"] else "")
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:56] + ("|" + str(r.get("Grid_Size") or r.get("Grid_Size_X")) if "k_nl_" in r["Kernel_Name"] else "")
     dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     gap[name].append((int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / 1e3)
 # the PER-only phase of bench.py (k_sample / k_update alternate, no learner): the same statistics

@@ -26,7 +26,7 @@ agent = Agent(args, env)
 mem = ReplayMemory(args, cfg["capacity"], seed=7)
 bench.fill_replay(mem, cfg["capacity"], cfg["actions"], seed=0)
 lib = L.load()
-K, W = 8, 2048
+K, W = 12, 2048
 buf = (C.c_longlong * (K * W * 8))()
 lib.rb_debug_wgtrace.argtypes = [C.c_void_p, C.c_int]
 for it in range(40):
@@ -42,7 +42,7 @@ a = np.frombuffer(buf, dtype=np.int64).reshape(K, W, 8).astype(np.float64)
 names = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "conv3_dx", "conv2_dx", "conv_dw", "(fine)", "head: logits loaded | double-Q | softmaxes | projection | loss | dlogits"]
 phase = ["stage weights", "wait", "stage input", "mfma", "epilogue", "signal"]
 t0_all = None
-for k in range(K):
+for k in range(8):
     rows = a[k][a[k][:, 0] > 0]
     if not len(rows):
         continue
@@ -82,3 +82,26 @@ if len(idx):
     for nm, sel in (("first 255 workgroups (images < 51)", first), ("the rest (second workgroup of its CU)", ~first)):
         print("conv1 %s: start +%.2f | " % (nm, np.median(rows_all[idx][sel, 0] - rows_all[idx][:, 0].min()) * 0.01)
               + "  ".join("%s %.2f" % (phase[i], np.median(d0[sel, i])) for i in range(6)) + " | total %.2f" % np.median(d0[sel].sum(axis=1)))
+
+# noisy-linear backward launches (kernel ids 8 = output layer, 9 = hidden layer): per role (0 priority write-back, 1 dW tiles,
+# 2 dX tiles) when the workgroups start and end relative to the launch's first start
+for k, nm in ((8, "fc_z_bwd"), (9, "fc_h_bwd")):
+    rows = a[k][a[k][:, 0] > 0]
+    if not len(rows):
+        continue
+    t0 = rows[:, 0].min()
+    print("== %s: %d workgroups, launch span %.2f us" % (nm, len(rows), (rows[:, 6].max() - t0) * 0.01))
+    for role, rn in ((0, "write-back"), (1, "dW"), (2, "dX")):
+        r = rows[(rows[:, 1] == role) & (rows[:, 6] > 0)]
+        if len(r):
+            print("   %-10s n %4d  start median +%.2f last +%.2f | end median +%.2f last +%.2f | duration median %.2f max %.2f us"
+                  % (rn, len(r), np.median(r[:, 0] - t0) * 0.01, (r[:, 0].max() - t0) * 0.01, np.median(r[:, 6] - t0) * 0.01,
+                     (r[:, 6].max() - t0) * 0.01, np.median(r[:, 6] - r[:, 0]) * 0.01, (r[:, 6] - r[:, 0]).max() * 0.01))
+    r = rows[(rows[:, 1] == 2) & (rows[:, 6] > 0) & (rows[:, 2] > 0)]
+    if len(r):
+        d = np.diff(r[:, [0, 2, 3, 4, 5, 6]], axis=1) * 0.01
+        order = np.argsort(-(r[:, 6] - r[:, 0]))
+        print("   dX phases (prologue | first iteration | rest of the loop | cross-wave sum | epilogue), slowest 4 and median:")
+        for i in list(order[:4]):
+            print("      " + "  ".join("%.2f" % x for x in d[i]))
+        print("      median " + "  ".join("%.2f" % x for x in np.median(d, axis=0)))
