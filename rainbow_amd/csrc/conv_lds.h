@@ -117,7 +117,7 @@ __device__ __forceinline__ void rb_stage_weights_t(float* s_w, const float* w, i
 // PCH = output positions per workgroup (<= 32 NT; a multiple of the row length keeps the patch at PR rows).
 // T16 (the t16 variant below): no reduction scratch, no tap table; the channel planes of the patch are padded so that the four
 // k-slots of a 16x16x4 operand read (channel groups cin/4 apart) start 16 banks apart.
-template <class G, int NT, int PR, int KMAX, bool T16 = false>
+template <class G, int NT, int PR, int KMAX, int T16 = 0>
 struct ConvFwdLdsSize {
   static constexpr int KGRAN = 2 * RB_CONV_WAVES;
   static constexpr int KPAD = (KMAX + KGRAN - 1) / KGRAN * KGRAN;
@@ -160,16 +160,16 @@ struct ConvFwdLdsSize {
 // reduction: its A operands are whole float4s of weight row x (one ds_read_b128 per four MFMAs), its B operands are patch
 // cells whose offsets are compile-time functions of the step (immediates: no tap table).  Needs cin * KK == KMAX, cin % 4 == 0,
 // KMAX % 16 == 0 (host-checked).
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, bool T16 = false>
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, int T16 = 0>
 struct ConvFwdWaves {
   static constexpr int PT = (PCH + 15) / 16;
-  static constexpr int NWV = T16 ? 2 * PT : RB_CONV_WAVES;
+  static constexpr int NWV = T16 == 1 ? 2 * PT : T16 == 2 ? PT : RB_CONV_WAVES;     // T16 = channel tiles per wave
 };
 template <class G, int KMAX, int PLANE, int RP, int SUB>
 __device__ __forceinline__ constexpr int rb_t16_off(int j) {            // step j of a lane's K quarter -> offset in the patch
   return (j / G::KK) * PLANE + ((j % G::KK) / G::KS) * RP + (((j % G::KK) % G::KS) % G::S) * SUB + ((j % G::KK) % G::KS) / G::S;
 }
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, bool T16 = false>
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, int T16 = 0>
 __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx, int by, int img, float* smem) {
   typedef ConvFwdLdsSize<G, NT, PR, KMAX, T16> SZ;
   constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, T16>::NWV;
@@ -332,7 +332,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   RB_WGT(WK + 4, wgi, 1);                               // (fine: thread 0's loads have landed)
 #endif
   // ---- LDS: tap table (no memory operand), then the weights, then the input
-  if constexpr (!T16) {
+  if constexpr (T16 == 0) {
     for (int k = t; k < KPAD; k += THREADS) {
       const int kc = k < K ? k : K - 1;
       const int c = kc / G::KK, r = kc % G::KK;
@@ -458,46 +458,62 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   RB_CSTAMP(SB + 1);
   RB_WGT(WK, wgi, 3);
 
-  if constexpr (T16) {
-    constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4;
-    const int pt = wave % PT, ct = wave / PT;         // wave-uniform: position tile, channel tile
+  if constexpr (T16 != 0) {
+    // CTW channel tiles per wave: 1 = a wave per (position tile, channel tile); 2 = a wave per position tile, both channel
+    // tiles of the slab from ONE patch operand per step (the first layer: five waves instead of ten per workgroup)
+    constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4, CTW = T16;
+    const int pt = wave % PT, ct0 = (wave / PT) * CTW;      // wave-uniform: position tile, first channel tile
     const int x = lane & 15, kq = lane >> 4;
     int p = p0 + pt * 16 + x;
     const bool pv = p < G::P && p < p0 + PCH;
     if (p > G::P - 1) p = G::P - 1;                   // clamped lanes are never stored
     const float* bp = s_patch + kq * CQ * PLANE + (p / G::OH - oy0) * G::S * RP + (p % G::OH);
-    const float* ap = s_w + (ct * 16 + x) * WS + kq * KQ;
-    float bias4[4];
+    const float* ap = s_w + (ct0 * 16 + x) * WS + kq * KQ;
+    float bias4[CTW][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = cout0 + ct * 16 + 4 * kq + r;
-      bias4[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
-    }
-    rb_f32x4 acc;
+    for (int u = 0; u < CTW; ++u)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+      for (int r = 0; r < 4; ++r) {
+        const int m = cout0 + (ct0 + u) * 16 + 4 * kq + r;
+        bias4[u][r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+      }
+    rb_f32x4 acc[CTW];
+#pragma unroll
+    for (int u = 0; u < CTW; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[u][r] = 0.0f;
 #pragma unroll
     for (int jq = 0; jq < KQ / 4; ++jq) {
-      const float4 w4 = rb_ld4(ap + 4 * jq);
-      acc = rb_mfma16(w4.x, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], acc);
-      acc = rb_mfma16(w4.y, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)], acc);
-      acc = rb_mfma16(w4.z, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], acc);
-      acc = rb_mfma16(w4.w, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)], acc);
+      float4 w4[CTW];
+#pragma unroll
+      for (int u = 0; u < CTW; ++u) w4[u] = rb_ld4(ap + u * 16 * WS + 4 * jq);
+      const float b0 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], b1 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)];
+      const float b2 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], b3 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)];
+#pragma unroll
+      for (int u = 0; u < CTW; ++u) acc[u] = rb_mfma16(w4[u].x, b0, acc[u]);
+#pragma unroll
+      for (int u = 0; u < CTW; ++u) acc[u] = rb_mfma16(w4[u].y, b1, acc[u]);
+#pragma unroll
+      for (int u = 0; u < CTW; ++u) acc[u] = rb_mfma16(w4[u].z, b2, acc[u]);
+#pragma unroll
+      for (int u = 0; u < CTW; ++u) acc[u] = rb_mfma16(w4[u].w, b3, acc[u]);
     }
     RB_CSTAMP(SB + 2);
     RB_WGT(WK, wgi, 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                     // D[r]: channel 4 kq + r of the tile, position x
-      const int m = cout0 + ct * 16 + 4 * kq + r;
-      if (pv && m < a.cout) {
-        const float o = fmaxf(acc[r] + bias4[r], 0.0f);
-        a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
-        if (a.out_blocked) {
-          const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
-          a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+    for (int u = 0; u < CTW; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                   // D[r]: channel 4 kq + r of the tile, position x
+        const int m = cout0 + (ct0 + u) * 16 + 4 * kq + r;
+        if (pv && m < a.cout) {
+          const float o = fmaxf(acc[u][r] + bias4[u][r], 0.0f);
+          a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+          if (a.out_blocked) {
+            const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+            a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+          }
         }
       }
-    }
     RB_CSTAMP(SB + 3);
     RB_CSTAMP_LAST(SB + 5);
     RB_WGT(WK, wgi, 5);
@@ -604,12 +620,12 @@ __global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX>::
   else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
-// the t16 variant (rb_conv_fwd_body<..., T16 = true>): grid as k_conv_fwd_lds, block = 64 * (2 * ceil(PCH / 16)) threads
-template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false>
-__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, true>::NWV)) void k_conv_fwd_t16(ConvLdsFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, true>::FLOATS];
-  if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC, true>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
-  else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, F32SRC, true>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+// the t16 variant (rb_conv_fwd_body<..., T16 = CTW>): grid as k_conv_fwd_lds, block = 64 * ConvFwdWaves<..., CTW>::NWV threads
+template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, int CTW = 1>
+__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, CTW>::NWV)) void k_conv_fwd_t16(ConvLdsFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, CTW>::FLOATS];
+  if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, false, CTW>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
+  else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, false, CTW>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
 // ---- large batches: one weight slab per workgroup, a loop over images -----------------------------------------

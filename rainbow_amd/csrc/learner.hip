@@ -163,7 +163,6 @@ struct rb_learner {
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
   int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_img_fast;
-  int opt_prefetch;     // L2 warm-up tenants (HeadPrefetch)
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   float* dw_part[3];    // [ws_l][cout][K+1]
@@ -426,43 +425,6 @@ struct HeadWave {
   }
 };
 
-// L2 warm-up tenants.  The NEXT launch (the output layer's backward) starts with every weight line cold: the optimiser pass
-// stored the parameters write-through (the lines left the L2s), and the forward pulled each 16-row tile into ONE XCD's L2 —
-// the input-gradient workgroup of column tile bx, which reads ALL rows of its 64 columns, runs on another XCD and pays a
-// fabric round trip per dependent batch of loads (5 batches: 8-11.5 us of a 11.8 us launch, profiles/round4_*timeline*).
-// This launch has 32 busy CUs of 256: 8 extra workgroups, one per XCD (workgroup index mod 8 = XCD), request exactly the
-// column tiles the next launch's workgroups of THAT XCD will read and drop the values — the lines are then in the right L2.
-struct HeadPrefetch {
-  const float* mu;       // [rows][K]
-  const float* sigma;
-  int rows, K;
-  int tiles;             // 64-column tiles per row
-  int next_first;        // block index of column tile 0's workgroup in the next launch (its XCD = index mod 8)
-  int period;            // ... and of tile bx: next_first + bx (+ period for the second problem: same XCD when period % 8 == 0)
-};
-__device__ __forceinline__ void rb_l2_prefetch_tiles(const HeadPrefetch& pf, int tenant, int my_block) {
-  if (!pf.mu) return;
-  (void)tenant;
-  const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
-  const int c = lane & 15, q = lane >> 4;
-  float acc = 0.0f;
-  for (int bx = 0; bx < pf.tiles; ++bx) {
-    if (((pf.next_first + bx) & 7) != (my_block & 7)) continue;        // block-uniform: tiles whose consumer shares this XCD
-    for (int r0 = 4 * wave; r0 < pf.rows; r0 += 4 * nw) {
-      int r = r0 + q;
-      if (r > pf.rows - 1) r = pf.rows - 1;
-      const float4 a = rb_ld4(pf.mu + (int64_t)r * pf.K + 64 * bx + 4 * c);
-      const float4 b = rb_ld4(pf.sigma + (int64_t)r * pf.K + 64 * bx + 4 * c);
-      acc += a.x + b.x;
-    }
-  }
-#if !defined(RB_HOST_INTERP)
-  asm volatile("" ::"v"(acc));                                           // the loads must be issued; their values are dropped
-#else
-  (void)acc;
-#endif
-}
-
 #define RB_HEAD_THREADS 1024      // launch bound; the launch uses 64 x min(16, max(8, 2A + 1)) threads
 template <int ZI>
 __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
@@ -470,8 +432,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
                                                int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr,
-                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT, HeadPrefetch pf) {
-  if ((int)blockIdx.x >= B) { rb_l2_prefetch_tiles(pf, (int)blockIdx.x - B, (int)blockIdx.x); return; }   // tenants: see HeadPrefetch
+                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT) {
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_pt[RB_MAX_NZ];                  // target(next) probabilities of EVERY action: [a][z] at a * Z + z
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS], s_sup[RB_MAX_ATOMS];
@@ -972,8 +933,9 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
   if constexpr (KMAX % 16 == 0 && (KMAX / G::KK) % 4 == 0 && 2 * ((PCH + 15) / 16) <= 16 && (PCH % 16 == 0 || PCH >= G::P) && G::P > 16) {
     // whole-K 16x16x4 tiles, one wave per tile, no cross-wave reduction (conv_lds.h T16): the learn step's u8 / f32 inputs
     if (((l->opt_t16 >> layer) & 1) && !(FIRST && src.f32) && c.cin * G::KK == KMAX && c.cout % 32 == 0) {
-      constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, true>::NWV;
-      RB_LAUNCH_T(tags[layer], (k_conv_fwd_t16<G, NT, PR, KMAX, FIRST, PCH>), grid1, dim3(64 * NWV), stream, a);
+      constexpr int CTW = 1;                    // channel tiles per wave (2 measured slower for the first layer: 5-wave staging)
+      constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, CTW>::NWV;
+      RB_LAUNCH_T(tags[layer], (k_conv_fwd_t16<G, NT, PR, KMAX, FIRST, PCH, CTW>), grid1, dim3(64 * NWV), stream, a);
       RB_LAUNCH_CHECK();
       return RB_OK;
     }
@@ -1051,6 +1013,7 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     // reads every tile once instead of twice and is 7 us per step SLOWER: a workgroup's MFMAs are serial on its CU)
     const bool wide = m_max >= 128;
     const unsigned mch32 = (unsigned)rb_div_up(m_max, wide ? 64 : RB_FWD2_MROWS);
+    // (16-row m-chunks — 384 workgroups, every CU busy — measured 20.8 us against 16.2: the tiles are re-read four times)
     const dim3 hg((unsigned)(2 * ht16), 1, 2 * mch32), hb(64 * RB_NL_FWD_WAVES);
     if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
     else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a); }
@@ -1373,7 +1336,6 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
-  l->opt_prefetch = rb_opt("prefetch", 1);
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_t16 = rb_opt("t16", 6);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
   if (l->fast_fc) {
@@ -1692,19 +1654,10 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     int hwaves = 2 * L.A + 1;
     if (hwaves < 8) hwaves = 8;
     if (hwaves > 16) hwaves = 16;
-    HeadPrefetch pf;
-    memset(&pf, 0, sizeof(pf));
-    if (l->fast_fc && l->opt_prefetch && L.H % 64 == 0) {     // the output layer's backward follows: its dX tiles (learn_impl below)
-      const int vt_ = (int)rb_div_up(L.Z, 16), at_ = (int)rb_div_up(L.NZ - L.Z, 16);
-      pf.mu = on.z_mu; pf.sigma = on.z_sigma; pf.rows = L.NZ; pf.K = L.H; pf.tiles = L.H / 64;
-      pf.next_first = (int)rb_div_up(L.H, 512) * (vt_ + at_);       // = zg.dw_x * zg.dw_y with z_ct = 2 (batch <= 32)
-      pf.period = pf.tiles;
-      if (B > 32 || (l->world > 1 && l->fact_local)) pf.mu = nullptr;   // other grid shapes: no warm-up
-    }
-    const dim3 hgrid((unsigned)(B + (pf.mu ? 8 : 0))), hblock((unsigned)(64 * hwaves));
+    const dim3 hgrid((unsigned)B), hblock((unsigned)(64 * hwaves));
 #define RB_HEAD_ARGS B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev, nonterminals_dev, weights_dev, (const float*)l->support, \
     l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z, l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr,          \
-    l->batch_status, l->status_copy, l->dlogitsT, pf
+    l->batch_status, l->status_copy, l->dlogitsT
     if (L.Z <= 64) { RB_LAUNCH_T("head:k_head", k_head<1>, hgrid, hblock, stream, RB_HEAD_ARGS); }
     else if (L.Z <= 128) { RB_LAUNCH_T("head:k_head", k_head<2>, hgrid, hblock, stream, RB_HEAD_ARGS); }
     else { RB_LAUNCH_T("head:k_head", k_head<4>, hgrid, hblock, stream, RB_HEAD_ARGS); }
@@ -2197,6 +2150,18 @@ int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream) {
   return RB_OK;
 }
 
+#if defined(RB_STAMP)
+// RB_STAMP builds: what the runtime says about the residency of the first layer's forward kernels
+int rb_debug_occupancy(void) {
+  int a = 0, b = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void*)(k_conv_fwd_t16<GeomC1, 3, 20, 256, true, 80, 1>), 640, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)(k_conv_fwd_lds<GeomC1, 3, 20, 256, true, 80>), 512, 0);
+  hipFuncAttributes fa;
+  hipFuncGetAttributes(&fa, (const void*)(k_conv_fwd_t16<GeomC1, 3, 20, 256, true, 80, 1>));
+  printf("occupancy API: conv1 t16 (640 threads) %d blocks/CU, conv1 lds (512 threads) %d; t16: regs %d lds %zu maxThreads %d\n", a, b, fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);
+  return a;
+}
+#endif
 int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream) {
   RB_REQUIRE(l && out_dev, "rb_learner_debug_read: NULL argument");
   RB_FLUSH_UPDATE(l, stream);

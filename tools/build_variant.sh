@@ -4,9 +4,10 @@ set -e
 NAME=$1; shift
 CS=rainbow_amd/csrc
 OBJS=""
+HASH=$(python -c "import __graft_entry__ as g; print(g.source_hash())")     # bench.py refuses a library without its source hash
 for f in $CS/*.hip; do
   o=/tmp/rbv_${NAME}_$(basename $f .hip).o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result "$@" -c $f -o $o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result -DRB_SOURCE_HASH=\"$HASH\" "$@" -c $f -o $o &
   OBJS="$OBJS $o"
 done
 wait
