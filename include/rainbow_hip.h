@@ -403,6 +403,25 @@ int rb_learner_set_exchange(rb_learner_t* l, int32_t world, float* factors_local
 int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream);
 int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream);
 
+/* The same exchange WITHOUT a host framework in the loop: the library issues the all-gather itself on an RCCL
+ * communicator it owns (librccl is resolved at run time with dlopen — the library has no link-time dependency on it), so a
+ * C / C++ host needs no torch.distributed, and the Python host saves the ~16 us per step torch.distributed spends around a
+ * 1 MB collective (profiles/round3_defer_dist1.txt).  One communicator per process / GPU:
+ *   rank 0:     rb_comm_unique_id(id)                  128 opaque bytes (ncclGetUniqueId); ship them to every rank out of band
+ *   every rank: rb_comm_create(&comm, id, world, rank) ncclCommInitRank on the CURRENT device (collective: all ranks call it)
+ *   per step:   rb_learner_exchange_rccl(l, comm, stream)  =  ncclAllGather(local block -> gathered blocks) on `stream`
+ *                                                             + rb_learner_finish_grads(l, stream)
+ * A one-rank communicator with a two-block exchange buffer (the single-GPU plumbing run, RAINBOW_AMD_FORCE_DIST=1) gathers
+ * into block 0 and copies it to block 1.  Replaces the [caller: all-gather] step above; insert point agent.py:96-97.        */
+typedef struct rb_comm rb_comm_t;
+int rb_comm_unique_id(void* id128);
+int rb_comm_create(rb_comm_t** out, const void* id128, int32_t world, int32_t rank);
+int rb_comm_destroy(rb_comm_t* comm);
+int rb_learner_exchange_rccl(rb_learner_t* l, rb_comm_t* comm, rb_stream_t stream);
+/* rb_learner_train_step with the exchange in its place (sampler + noise, learn, exchange_rccl, clip + Adam): the replica
+ * step as ONE C call.  Needs rb_learner_set_exchange to be armed for comm's world size.                                  */
+int rb_learner_train_step_dist(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t* comm, rb_stream_t stream);
+
 /* Tell the library the caller changed grads_dev after rb_learner_learn (e.g. the RCCL
  * all-reduce of the replica path): the sum of squares the backward kernels accumulated on
  * the fly is then stale and rb_learner_clip_grad re-reads the gradient.                    */

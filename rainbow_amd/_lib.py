@@ -119,6 +119,11 @@ SIGNATURES = {
     "rb_learner_set_exchange": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "rb_learner_wait_factors": (c_int, [c_void_p, c_void_p]),
     "rb_learner_finish_grads": (c_int, [c_void_p, c_void_p]),
+    "rb_comm_unique_id": (c_int, [c_void_p]),
+    "rb_comm_create": (c_int, [C.POINTER(c_void_p), c_void_p, c_int32, c_int32]),
+    "rb_comm_destroy": (c_int, [c_void_p]),
+    "rb_learner_exchange_rccl": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rb_learner_train_step_dist": (c_int, [c_void_p, C.POINTER(TrainStep), c_void_p, c_void_p]),
     "rb_learner_sync_target": (c_int, [c_void_p, c_void_p]),
     "rb_learner_get_rng": (c_int, [c_void_p, C.POINTER(c_uint64), C.POINTER(c_uint64), c_void_p]),
     "rb_learner_set_rng": (c_int, [c_void_p, c_uint64, c_uint64, c_void_p]),

@@ -462,7 +462,10 @@ class Agent:
         ts.lr, ts.eps, ts.max_norm = float(g["lr"]), float(g["eps"]), float(self.norm_clip)
         ts.beta1, ts.beta2 = g["betas"]
         ts.step = 0 if self._step_dev is not None else int(st["step"].item())
-        rc = self._lib.rb_learner_train_step(self._h, C.byref(ts), stream)
+        if self._exchange is not None:     # replicas: the library's own RCCL all-gather sits between backward and clip
+            rc = self._lib.rb_learner_train_step_dist(self._h, C.byref(ts), self._exchange.comm, stream)
+        else:
+            rc = self._lib.rb_learner_train_step(self._h, C.byref(ts), stream)
         if rc != 0:
             L.check(self._lib, rc)
         self._update_pending = self._defer_update
@@ -476,8 +479,9 @@ class Agent:
         if self._zero_copy_ok is None:                # a property of the learner's configuration: asked once
             self._zero_copy_ok = bool(self._lib.rb_learner_zero_copy_ok(self._h))
         zero_copy = device_mem and self._zero_copy_ok and mem.history == self._cfg.history and mem.n == self.n
+        lib_comm = self._exchange is not None and getattr(self._exchange, "comm", None) is not None
         if (zero_copy and self._one_call and _target_raw_normals is None and _unit_uniforms is None and self._fuse_update
-                and self._exchange is None and not self._dist
+                and ((self._exchange is None and not self._dist) or lib_comm)
                 and isinstance(self.optimiser, _FlatAdam) and math.isfinite(float(self.norm_clip))):
             g = self.optimiser.param_groups[0]
             if not (g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"]):

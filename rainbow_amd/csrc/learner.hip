@@ -1875,7 +1875,15 @@ int rb_learner_clip_adam_deferred(rb_learner_t* l, float max_norm, float* exp_av
                         (l->flags & RB_LEARNER_DEFER_UPDATE) != 0);
 }
 
+static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t* comm, rb_stream_t stream);
 int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t stream) {
+  return train_step_impl(l, a, nullptr, stream);
+}
+int rb_learner_train_step_dist(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t* comm, rb_stream_t stream) {
+  RB_REQUIRE(comm != nullptr, "rb_learner_train_step_dist: NULL communicator");
+  return train_step_impl(l, a, comm, stream);
+}
+static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t* comm, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr && a != nullptr && a->replay != nullptr, "rb_learner_train_step: NULL argument");
   // the previous call's optimiser pass, if it was left pending, rides in this call's sampler launch (adam_body.h)
   rb_noise_job_t hosted_job;
@@ -1901,6 +1909,10 @@ int rb_learner_train_step(rb_learner_t* l, const rb_train_step_t* a, rb_stream_t
   rc = rb_learner_learn_windows(l, a->frames_dev, a->windows_dev, a->window_len, a->actions_dev, a->returns_dev,
                                 a->nonterminals_dev, a->weights_dev, a->loss_dev, stream);
   if (rc != RB_OK) return rc;
+  if (comm) {      // replicas: the factor all-gather + the finishing launch between backward and clip (agent.py:96-97)
+    rc = rb_learner_exchange_rccl(l, comm, stream);
+    if (rc != RB_OK) return rc;
+  }
   return clip_adam_impl(l, a->max_norm, a->exp_avg_dev, a->exp_avg_sq_dev, a->lr, a->beta1, a->beta2, a->eps, a->step,
                         a->norm_dev, (hipStream_t)stream, (l->flags & RB_LEARNER_DEFER_UPDATE) != 0);
 }
@@ -2052,6 +2064,115 @@ int rb_learner_wait_factors(rb_learner_t* l, rb_stream_t side_stream) {
   RB_REQUIRE(l->exch_pending, "rb_learner_wait_factors: no learn call with a pending exchange");
   (void)side_stream;     // the block is complete in the stream order of the learn call: nothing to wait for (see the header)
   return RB_OK;
+}
+
+// ---- RCCL, resolved at run time (include/rainbow_hip.h: rb_comm_*).  Prefers the librccl the process already has (PyTorch
+// ships one: the communicator then lives in the same library instance as torch.distributed's), else the ROCm installation's.
+#if !defined(RB_HOST_INTERP)
+#include <dlfcn.h>
+struct RbNcclUniqueId { char internal[128]; };
+struct RbNccl {
+  void* h;
+  int (*GetUniqueId)(RbNcclUniqueId*);
+  int (*CommInitRank)(void**, int, RbNcclUniqueId, int);
+  int (*CommDestroy)(void*);
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+  const char* (*GetErrorString)(int);
+};
+static RbNccl* rb_nccl() {
+  static RbNccl n;
+  static int state = 0;        // 0 untried, 1 ok, -1 unavailable
+  if (state == 0) {
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    n.h = nullptr;
+    for (const char* nm : names) if ((n.h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;     // already loaded?
+    if (!n.h) for (const char* nm : names) if ((n.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    state = -1;
+    if (n.h) {
+      n.GetUniqueId = (int (*)(RbNcclUniqueId*))dlsym(n.h, "ncclGetUniqueId");
+      n.CommInitRank = (int (*)(void**, int, RbNcclUniqueId, int))dlsym(n.h, "ncclCommInitRank");
+      n.CommDestroy = (int (*)(void*))dlsym(n.h, "ncclCommDestroy");
+      n.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(n.h, "ncclAllGather");
+      n.GetErrorString = (const char* (*)(int))dlsym(n.h, "ncclGetErrorString");
+      if (n.GetUniqueId && n.CommInitRank && n.CommDestroy && n.AllGather && n.GetErrorString) state = 1;
+    }
+  }
+  return state == 1 ? &n : nullptr;
+}
+#define RB_NCCL_TRY(n, expr)                                                                          \
+  do {                                                                                                \
+    const int r_ = (expr);                                                                            \
+    if (r_ != 0) { rb_set_error("%s failed: %s", #expr, (n)->GetErrorString(r_)); return RB_ERR_HIP; } \
+  } while (0)
+#endif
+struct rb_comm {
+  void* comm;
+  int world, rank;
+};
+
+int rb_comm_unique_id(void* id128) {
+  RB_REQUIRE(id128 != nullptr, "rb_comm_unique_id: NULL argument");
+#if defined(RB_HOST_INTERP)
+  rb_set_error("rb_comm_unique_id: RCCL is not part of the host-interpreted test build");
+  return RB_ERR_STATE;
+#else
+  RbNccl* n = rb_nccl();
+  if (!n) { rb_set_error("rb_comm_unique_id: librccl.so could not be loaded (dlopen)"); return RB_ERR_STATE; }
+  static_assert(sizeof(RbNcclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  RB_NCCL_TRY(n, n->GetUniqueId(reinterpret_cast<RbNcclUniqueId*>(id128)));
+  return RB_OK;
+#endif
+}
+
+int rb_comm_create(rb_comm_t** out, const void* id128, int32_t world, int32_t rank) {
+  RB_REQUIRE(out && id128, "rb_comm_create: NULL argument");
+  RB_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rb_comm_create: rank must be in [0, world)");
+#if defined(RB_HOST_INTERP)
+  rb_set_error("rb_comm_create: RCCL is not part of the host-interpreted test build");
+  return RB_ERR_STATE;
+#else
+  RbNccl* n = rb_nccl();
+  if (!n) { rb_set_error("rb_comm_create: librccl.so could not be loaded (dlopen)"); return RB_ERR_STATE; }
+  RbNcclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  void* c = nullptr;
+  RB_NCCL_TRY(n, n->CommInitRank(&c, world, id, rank));
+  rb_comm* rc = new (std::nothrow) rb_comm();
+  if (!rc) { n->CommDestroy(c); rb_set_error("rb_comm_create: host OOM"); return RB_ERR_OOM; }
+  rc->comm = c; rc->world = world; rc->rank = rank;
+  *out = rc;
+  return RB_OK;
+#endif
+}
+
+int rb_comm_destroy(rb_comm_t* comm) {
+  if (!comm) return RB_OK;
+#if !defined(RB_HOST_INTERP)
+  RbNccl* n = rb_nccl();
+  if (n && comm->comm) n->CommDestroy(comm->comm);
+#endif
+  delete comm;
+  return RB_OK;
+}
+
+int rb_learner_exchange_rccl(rb_learner_t* l, rb_comm_t* comm, rb_stream_t stream_) {
+  RB_REQUIRE(l && comm, "rb_learner_exchange_rccl: NULL argument");
+  RB_REQUIRE(l->exch_pending && l->fact_local && l->fact_all, "rb_learner_exchange_rccl: no learn call with a pending exchange");
+  RB_REQUIRE(comm->world == l->world || (comm->world == 1 && l->world == 2),
+             "rb_learner_exchange_rccl: the communicator has %d ranks, the exchange buffer %d blocks", comm->world, l->world);
+#if defined(RB_HOST_INTERP)
+  rb_set_error("rb_learner_exchange_rccl: RCCL is not part of the host-interpreted test build");
+  return RB_ERR_STATE;
+#else
+  RbNccl* n = rb_nccl();
+  if (!n) { rb_set_error("rb_learner_exchange_rccl: librccl.so could not be loaded (dlopen)"); return RB_ERR_STATE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  float* all = const_cast<float*>(l->fact_all);
+  RB_NCCL_TRY(n, n->AllGather(l->fact_local, all, (size_t)l->fact_stride, /* ncclFloat32 */ 7, comm->comm, stream));
+  if (comm->world == 1 && l->world == 2)      // single-GPU plumbing run: the lone block stands for both replicas
+    RB_HIP_TRY(hipMemcpyAsync(all + l->fact_stride, all, (size_t)l->fact_stride * 4, hipMemcpyDeviceToDevice, stream));
+  return rb_learner_finish_grads(l, stream_);
+#endif
 }
 
 int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {

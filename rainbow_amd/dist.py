@@ -57,6 +57,17 @@ def _mean_reduce(t):
     return t
 
 
+def _all_gather_blocks(out, local):
+    """all_gather_into_tensor; the gloo backend (tests: two ranks on ONE device, where RCCL refuses a second rank per GPU)
+    gathers host tensors only, so device blocks are staged through the host there — synchronous, never the product path."""
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        h_all = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(h_all, local.cpu())
+        out.copy_(h_all)
+    else:
+        dist.all_gather_into_tensor(out, local)
+
+
 def average_gradients(flat_grads):
     """In-place mean over replicas of the flat gradient buffer (4*P bytes, one collective): the 'allreduce' exchange."""
     if active():
@@ -69,6 +80,28 @@ def broadcast_parameters(flat_params, src=0):
         with torch.no_grad():
             dist.broadcast(flat_params, src)
     return flat_params
+
+
+def _create_library_comm(lib, dev):
+    """An RCCL communicator owned by the library over the ranks of the default process group (None when librccl cannot be
+    loaded: the caller then keeps the collective in torch.distributed)."""
+    ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+    ok = torch.ones(1, dtype=torch.int32, device=dev)
+    if dist.get_rank() == 0:
+        buf = (C.c_ubyte * 128)()
+        if lib.rb_comm_unique_id(buf) == 0:
+            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        else:
+            ok.zero_()
+    dist.broadcast(ok, 0)
+    if int(ok.item()) == 0:
+        return None
+    dist.broadcast(ident, 0)
+    raw = (C.c_ubyte * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+    comm = C.c_void_p()
+    with torch.cuda.device(dev):
+        L.check(lib, lib.rb_comm_create(C.byref(comm), raw, dist.get_world_size(), dist.get_rank()))
+    return comm
 
 
 class FactoredExchange:
@@ -90,6 +123,21 @@ class FactoredExchange:
         self.all = torch.zeros(self.lib_world * f.value, dtype=torch.float32, device=dev)
         L.check(lib, lib.rb_learner_set_exchange(handle, self.lib_world, self.local.data_ptr(), self.all.data_ptr()))
         self.bytes_per_step = 4 * f.value
+        # RCCL inside the library (rb_learner_exchange_rccl: ncclAllGather + the finishing launch as ONE C call, no
+        # torch.distributed on the step's path).  The communicator's 128-byte id travels through the process group that
+        # already exists; RAINBOW_AMD_EXCHANGE_VIA=torch keeps the collective in torch.distributed (the fallback, and what
+        # the gloo test groups use).
+        self.comm = None
+        if self.cuda and dist.get_backend() == "nccl" and os.environ.get("RAINBOW_AMD_EXCHANGE_VIA", "rccl") == "rccl":
+            self.comm = _create_library_comm(lib, dev)
+
+    def __del__(self):
+        try:
+            if getattr(self, "comm", None):
+                self.lib.rb_comm_destroy(self.comm)
+                self.comm = None
+        except Exception:
+            pass
 
     def close(self):
         if self.h:
@@ -101,10 +149,15 @@ class FactoredExchange:
         learn call's launches in stream order), then the library finishes the gradients of the global batch."""
         if self.cuda:
             stream_handle = torch.cuda.current_stream(self.local.device).cuda_stream
+        if self.comm is not None:
+            rc = self.lib.rb_learner_exchange_rccl(self.h, self.comm, stream_handle)
+            if rc != 0:
+                L.check(self.lib, rc)
+            return
         if self.lib_world != self.world:      # one-rank plumbing run
             n = self.local.numel()
-            dist.all_gather_into_tensor(self.all[:n], self.local)
+            _all_gather_blocks(self.all[:n], self.local)
             self.all[n:2 * n].copy_(self.all[:n])
         else:
-            dist.all_gather_into_tensor(self.all, self.local)
+            _all_gather_blocks(self.all, self.local)
         L.check(self.lib, self.lib.rb_learner_finish_grads(self.h, stream_handle))

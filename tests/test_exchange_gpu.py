@@ -109,3 +109,53 @@ def test_replica_exchange_kernels_match_oracle_on_mean_gradient(hip, monkeypatch
         exch.close()
     for ad in ads:
         ad.close()
+
+
+def test_library_rccl_exchange_equals_the_host_gathered_one(hip, monkeypatch):
+    """rb_comm_* + rb_learner_exchange_rccl (the library's own ncclAllGather on a communicator it created: librccl through
+    dlopen, no torch.distributed) on a ONE-rank communicator — all this box can host — against the same step whose block
+    was 'gathered' by a device copy: bit-identical gradients, norm partials and post-Adam parameters.  The lone block stands
+    for both replicas of a two-block exchange buffer, as in the RAINBOW_AMD_FORCE_DIST plumbing run."""
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    from rainbow_amd import _lib as L
+    shape = "cfg2-canonical-h512-b32-a6"
+    cfgd = BASELINE_SHAPES[shape]
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
+    cfg = O.Config(**cfgd)
+    ident = (C.c_ubyte * 128)()
+    L.check(hip, hip.rb_comm_unique_id(ident))
+    comm = C.c_void_p()
+    L.check(hip, hip.rb_comm_create(C.byref(comm), ident, 1, 0))
+    ads = [CAbiLearnAdapter(hip, TorchMem(), shape) for _ in range(2)]
+    online, target = O.init_params(cfg, 711), O.init_params(cfg, 712)
+    f = C.c_int64(0)
+    L.check(hip, hip.rb_learner_exchange_layout(ads[0].h, C.byref(f), None, None))
+    bufs = []
+    for ad in ads:
+        ad.load(online, target)
+        local = torch.zeros(f.value, dtype=torch.float32, device=ad.grads.device)
+        both = torch.zeros(2 * f.value, dtype=torch.float32, device=ad.grads.device)
+        L.check(hip, hip.rb_learner_set_exchange(ad.h, 2, local.data_ptr(), both.data_ptr()))
+        bufs.append((local, both))
+    draws = O.noise_draw_count(cfg)
+    for k in range(2):
+        rs = np.random.RandomState(300 + k)
+        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+        batch = scenarios.make_batch(cfgd, 400 + k)
+        for ad in ads:
+            ad.reset_noise_online(raw_on)
+            ad.learn_only(batch, raw_tg)
+        local, both = bufs[0]                                      # host-side 'gather': the block, twice
+        both[:f.value].copy_(local)
+        both[f.value:].copy_(local)
+        L.check(hip, hip.rb_learner_finish_grads(ads[0].h, ads[0].mem.stream))
+        L.check(hip, hip.rb_learner_exchange_rccl(ads[1].h, comm, ads[1].mem.stream))     # ncclAllGather + copy + finish
+        outs = [ad.finish_step() for ad in ads]
+        assert torch.equal(bufs[0][1], bufs[1][1]), "step %d: gathered blocks differ" % k
+        assert torch.equal(ads[0].grads, ads[1].grads), "step %d: gradients differ" % k
+        assert torch.equal(ads[0].p_on.detach(), ads[1].p_on.detach()), "step %d: parameters differ" % k
+        assert outs[0]["grad_norm"] == outs[1]["grad_norm"]
+    for ad in ads:
+        hip.rb_learner_set_exchange(ad.h, 1, None, None)
+        ad.close()
+    L.check(hip, hip.rb_comm_destroy(comm))

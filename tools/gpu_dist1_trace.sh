@@ -11,12 +11,12 @@ python - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/d1trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_head(")]
+idx = [i for i, r in enumerate(rows) if "k_head<" in r["Kernel_Name"]]
 lo, hi = idx[-41], idx[-1]
 dur = collections.defaultdict(list); gap = collections.defaultdict(list); order = []
 for i in range(lo + 1, hi + 1):
     r, p = rows[i], rows[i - 1]
-    name = r["Kernel_Name"].split("(")[0][:52] + "|" + str(r.get("Grid_Size_X"))
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:52] + "|" + str(r.get("Grid_Size_X"))
     if name not in dur: order.append(name)
     dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     gap[name].append((int(r["Start_Timestamp"]) - int(p["End_Timestamp"])) / 1e3)
