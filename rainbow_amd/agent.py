@@ -70,6 +70,9 @@ def init_parameters_flat(layout, n_params, noisy_std):
     return flat
 
 
+_ACT_PENDING = -7          # preset of the pinned action word while an act launch is in flight
+
+
 class _FlatAdam(torch.optim.Adam):
     """torch.optim.Adam over the single flat parameter tensor (agent.py:46).  The state is ordinary Adam state
     (step / exp_avg / exp_avg_sq, so state_dict() and load_state_dict() work as usual), but step() runs the library's
@@ -324,9 +327,23 @@ class Agent:
         (no device-to-host copy): they are final after the stream synchronize below."""
         self._flush_noise()
         st = state.to(device=self.device, dtype=torch.float32).contiguous()
-        L.check(self._lib, self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0,
-                                                    self._act_pin.data_ptr(), self._q_pin.data_ptr(), self._stream()))
-        torch.cuda.current_stream(self.device).synchronize()
+        act = self._act_np
+        act[0] = _ACT_PENDING
+        rc = self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0, self._act_pin.data_ptr(),
+                                      self._q_pin.data_ptr(), self._stream())
+        if rc != 0:
+            L.check(self._lib, rc)
+        # completion = the pinned action word changes (the head writes q, fences, then the action): polling it returns ~5 us
+        # before a stream synchronize would (46 -> 41 us per act, tools/stamp/act_host.py); bounded, then the synchronize
+        for _ in range(20000):
+            if act[0] != _ACT_PENDING:
+                break
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+        if act[0] < 0:
+            torch.cuda.current_stream(self.device).synchronize()
+            if act[0] < 0:
+                raise RuntimeError("rb_learner_act: the one-launch act path reported an expired in-launch wait (action %d)" % int(act[0]))
 
     def act(self, state):
         """agent.py:53-55: greedy action on the expected value of the (noisy) online distribution."""

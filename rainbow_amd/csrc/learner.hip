@@ -177,6 +177,10 @@ struct rb_learner {
   int norm_slots;       // > 0: the last learn() left the gradient's sum of squares in norm_part (no k_sumsq pass needed)
   unsigned long long* noise_ctr;   // [0] Philox epoch of the noise generator, [1] block ticket
   NoiseJob* job_dev;               // [3] device copies of the noise jobs (rb_learner_noise_job), uploaded on request
+  unsigned* act_ctr;    // arrival counters of the one-launch act path (act_path.h k_act_fused; monotonic, sharded) + its error word
+  unsigned act_epoch;   // launches of k_act_fused so far
+  int n_cu;             // compute units of the device (the one-launch act path runs one workgroup per CU)
+  int opt_act_fused;    // RB_OPTS act_fused (default 1): Agent.act as ONE launch
   int rows_cap;         // image rows the forward buffers (act, hpart, h, feat_b, h_b, logits) hold: 3B, grown by act_batch
   int hs, xs, ws[3];    // split counts
   int dw_slices[3];     // slices actually written by the last conv weight-grad launch of each layer
@@ -374,10 +378,6 @@ __global__ __launch_bounds__(256) void k_pack_factors(PackArgs a) {
 #define RB_MAX_ATOMS 256
 #define RB_MAX_ACTIONS 64
 
-__device__ __forceinline__ float rb_dueling_q(const float* lg, const float* mean_a, int Z, int a, int z) {
-  // q = v + a - mean_a(a)          model.py:75
-  return (lg[z] + lg[Z + a * Z + z]) - mean_a[z];
-}
 
 // One workgroup per sample.  The three logit rows (3*(Z + A*Z) floats) are pulled into LDS with one coalesced sweep; after
 // that the kernel touches global memory only for its outputs.  ALL softmaxes of the sample are independent tasks spread over
@@ -580,47 +580,14 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   RB_WGT(7, b, 6);
 }
 
-// Agent.act / evaluate_q head (agent.py:53-55, 110-112) for ONE image at logits row `row`.
+// Agent.act / evaluate_q head (agent.py:53-55, 110-112) for ONE image at logits row `row` (act_path.h rb_head_act_body).
 __global__ __launch_bounds__(256) void k_head_act(int Z, int A, const float* logits, int row, const float* support,
                                                    int32_t* action_out, float* q_out) {
   __shared__ float s_mean[RB_MAX_ATOMS];
   __shared__ float s_ev[RB_MAX_ACTIONS];
-  const int t = (int)threadIdx.x;
-  const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
-  const int NZ = Z + A * Z;
   row += (int)blockIdx.x;                       // batched acting: one workgroup per state, outputs indexed alike
-  if (action_out) action_out += blockIdx.x;
-  if (q_out) q_out += blockIdx.x;
-  const float* lg = logits + (int64_t)row * NZ;
-  for (int z = t; z < Z; z += (int)blockDim.x) {
-    float acc = 0.0f;
-    for (int a = 0; a < A; ++a) acc += lg[Z + a * Z + z];
-    s_mean[z] = acc / (float)A;
-  }
-  __syncthreads();
-  for (int a = wave; a < A; a += nw) {
-    float mx = -INFINITY;
-    for (int z = lane; z < Z; z += 64) mx = fmaxf(mx, rb_dueling_q(lg, s_mean, Z, a, z));
-    mx = rb_wave_max(mx);
-    float se = 0.0f, sv = 0.0f;
-    for (int z = lane; z < Z; z += 64) {
-      const float e = expf(rb_dueling_q(lg, s_mean, Z, a, z) - mx);
-      se += e;
-      sv += support[z] * e;
-    }
-    se = rb_wave_sum(se);
-    sv = rb_wave_sum(sv);
-    if (lane == 0) s_ev[a] = sv / se;
-  }
-  __syncthreads();
-  if (t == 0) {
-    int best = 0;
-    float bv = s_ev[0];
-    for (int a = 1; a < A; ++a)
-      if (s_ev[a] > bv) { bv = s_ev[a]; best = a; }
-    if (action_out) *action_out = best;
-    if (q_out) *q_out = bv;
-  }
+  rb_head_act_body(Z, A, logits + (int64_t)row * (Z + A * Z), support, s_mean, s_ev, action_out ? action_out + blockIdx.x : nullptr,
+                   q_out ? q_out + blockIdx.x : nullptr, nullptr);
 }
 
 // -------------------------------------------------------------- global-norm clip --
@@ -1293,6 +1260,7 @@ int rb_learner_destroy(rb_learner_t* l) {
     if (*p) rb_dev_free(*p);
   if (l->a_star) rb_dev_free(l->a_star);
   if (l->noise_ctr) rb_dev_free(l->noise_ctr);
+  if (l->act_ctr) rb_dev_free(l->act_ctr);
   if (l->job_dev) rb_dev_free(l->job_dev);
   if (l->status_copy) rb_dev_free(l->status_copy);
   if (l->adam_args_dev) rb_dev_free(l->adam_args_dev);
@@ -1396,7 +1364,20 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->noise_ctr, 4);
   RB_ALLOC(l->status_copy, 4);
   RB_ALLOC(l->adam_args_dev, (sizeof(ClipAdamArgs) + 3) / 4);
+  RB_ALLOC(l->act_ctr, 6 * RB_FAN_SHARDS * RB_FAN_STRIDE + 32);
 #undef RB_ALLOC
+  RB_HIP_TRY(hipMemset(l->act_ctr, 0, (6 * RB_FAN_SHARDS * RB_FAN_STRIDE + 32) * 4));
+  l->opt_act_fused = rb_opt("act_fused", 1);
+#if defined(RB_HOST_INTERP)
+  l->n_cu = 8;
+#else
+  {
+    int dev = 0, cus = 0;
+    RB_HIP_TRY(hipGetDevice(&dev));
+    RB_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    l->n_cu = cus;
+  }
+#endif
   RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
   RB_HIP_TRY(hipMemset(l->status_copy, 0, 16));
   float sup[RB_MAX_ATOMS];
@@ -1468,7 +1449,10 @@ int rb_learner_reset_noise(rb_learner_t* l, int32_t which, const float* raw_norm
 
 // One state through the act path (act_path.h).  RB_ERR_STATE (without touching the error string) = geometry not
 // covered, the caller falls back to the training kernels.
-static int act_forward_single(rb_learner* l, const float* state_dev, const NetPtrs& on, int noisy, hipStream_t stream) {
+// Returns RB_OK (logits ready: the caller launches the head), 1 (the one-launch path ran the head as well and wrote
+// head_action_out / head_q_out), or an error.
+static int act_forward_single(rb_learner* l, const float* state_dev, const NetPtrs& on, int noisy, hipStream_t stream,
+                              int32_t* head_action_out, float* head_q_out) {
   const Layout& L = l->L;
   if (!l->fast_fc || (L.F & 3) || (L.H & 3)) return RB_ERR_STATE;   // RB_GENERIC_GEMM_ONLY=1 also lands here
   int rg[3];
@@ -1480,24 +1464,61 @@ static int act_forward_single(rb_learner* l, const float* state_dev, const NetPt
     if (r < 1 || c.K() > RB_ACT_KMAX) return RB_ERR_STATE;
     rg[layer] = r;
   }
+  ActFusedArgs f;
+  memset(&f, 0, sizeof(f));
   const float* x = state_dev;
   for (int layer = 0; layer < L.nconv; ++layer) {
     const ConvLayer& c = L.conv[layer];
-    ActConvArgs a;
+    ActConvArgs& a = f.conv[layer];
     a.x = x; a.w = on.conv_w[layer]; a.bias = on.conv_b[layer]; a.y = l->act[layer];
     a.cin = c.cin; a.cout = c.cout; a.KS = c.ks; a.S = c.s; a.IH = c.ih; a.OH = c.oh; a.RG = rg[layer];
-    RB_LAUNCH(k_act_conv, dim3((unsigned)c.cout, (unsigned)rb_div_up(c.oh, rg[layer])), dim3(256), stream, a);
-    RB_LAUNCH_CHECK();
     x = l->act[layer];
   }
-  ActFcArgs h;
+  f.nconv = L.nconv;
+  ActFcArgs& h = f.h;
   h.x = x; h.w = nl_h(on); h.K = L.F; h.n_rows = 2 * L.H; h.split_row = L.H; h.x_off1 = 0; h.ein_off1 = L.F;
   h.out = l->h; h.relu = 1; h.mu_only = noisy ? 0 : 1;
-  RB_LAUNCH(k_act_fc, dim3((unsigned)rb_div_up(h.n_rows, 4)), dim3(256), stream, h);
-  RB_LAUNCH_CHECK();
-  ActFcArgs z;
+  ActFcArgs& z = f.z;
   z.x = l->h; z.w = nl_z(on); z.K = L.H; z.n_rows = L.NZ; z.split_row = L.Z; z.x_off1 = L.H; z.ein_off1 = L.H;
   z.out = l->logits; z.relu = 0; z.mu_only = noisy ? 0 : 1;
+  bool can_fuse = l->opt_act_fused != 0;
+#if !defined(RB_HOST_INTERP)
+  {
+    // (a captured launch would replay a stale launch number: under stream capture the per-layer launches below run instead)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) can_fuse = false;
+  }
+#endif
+  if (can_fuse) {
+    // ONE persistent launch (act_path.h k_act_fused): G workgroups, one per CU, all resident — the in-launch waits need that
+    f.Z = L.Z; f.A = L.A; f.logits = l->logits; f.support = l->support; f.action_out = head_action_out; f.q_out = head_q_out;
+    f.ctr = l->act_ctr; f.err = l->act_ctr + 6 * RB_FAN_SHARDS * RB_FAN_STRIDE;
+    int G = (l->n_cu < 256 ? l->n_cu : 256) / RB_FAN_SHARDS * RB_FAN_SHARDS;       // a multiple of the counter shards
+    if (G < RB_FAN_SHARDS) G = RB_FAN_SHARDS;
+#if defined(RB_HOST_INTERP)
+    // the host interpreter runs workgroups one after the other: one launch per phase (no in-launch dependency), same bodies
+    for (int ph = 0; ph < 6; ++ph) {
+      if (ph < 3 && ph >= L.nconv) continue;
+      f.phase_lo = ph; f.phase_hi = ph + 1; f.epoch = 0;
+      RB_LAUNCH(k_act_fused<0>, dim3((unsigned)G), dim3(256), stream, f);
+    }
+#else
+    f.phase_lo = 0; f.phase_hi = 6; f.epoch = ++l->act_epoch;
+    const int hq = (int)rb_div_up(L.F, 256);
+    if (hq <= 3) { RB_LAUNCH_T("act:k_act_fused", k_act_fused<3>, dim3((unsigned)G), dim3(256), stream, f); }
+    else if (hq <= 13) { RB_LAUNCH_T("act:k_act_fused", k_act_fused<13>, dim3((unsigned)G), dim3(256), stream, f); }
+    else { RB_LAUNCH_T("act:k_act_fused", k_act_fused<0>, dim3((unsigned)G), dim3(256), stream, f); }
+#endif
+    RB_LAUNCH_CHECK();
+    return 1;                                              // the head ran inside the launch
+  }
+  for (int layer = 0; layer < L.nconv; ++layer) {
+    const ConvLayer& c = L.conv[layer];
+    RB_LAUNCH(k_act_conv, dim3((unsigned)c.cout, (unsigned)rb_div_up(c.oh, rg[layer])), dim3(256), stream, f.conv[layer]);
+    RB_LAUNCH_CHECK();
+  }
+  RB_LAUNCH(k_act_fc, dim3((unsigned)rb_div_up(h.n_rows, 4)), dim3(256), stream, h);
+  RB_LAUNCH_CHECK();
   RB_LAUNCH(k_act_fc, dim3((unsigned)rb_div_up(z.n_rows, 4)), dim3(256), stream, z);
   RB_LAUNCH_CHECK();
   return RB_OK;
@@ -1512,7 +1533,8 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
   memset(&src, 0, sizeof(src));
   src.f32 = state_dev; src.B = 1;
   const NetPtrs on = net_ptrs(L, l->p_online, noisy ? l->n_online : l->zero_noise);
-  int rc = act_forward_single(l, state_dev, on, noisy, (hipStream_t)stream);
+  int rc = act_forward_single(l, state_dev, on, noisy, (hipStream_t)stream, action_dev, q_dev);
+  if (rc == 1) return RB_OK;                                                          // one launch, head included
   if (rc == RB_ERR_STATE) rc = forward(l, 1, 0, src, on, on, (hipStream_t)stream);   // geometry outside the act path
   if (rc != RB_OK) return rc;
   RB_LAUNCH(k_head_act, dim3(1), dim3(256), stream, L.Z, L.A, (const float*)l->logits, 0, (const float*)l->support,

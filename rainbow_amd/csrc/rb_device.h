@@ -139,6 +139,42 @@ __device__ __forceinline__ void rb_chain_wait(const unsigned* counter, unsigned 
 #endif
 }
 
+// The same hand-off for ALL-TO-ALL boundaries of a persistent launch (every workgroup arrives, every workgroup waits): one
+// counter serialises its arrivals at ~12 ns each (256 workgroups: 3.3-4.4 us per boundary, tools/stamp/act_timeline.py), so
+// the arrivals are SHARDED over 8 counters in 8 different 128-byte lines (shard = workgroup index mod 8, i.e. its XCD) and a
+// waiter reads all eight in one batch.  `counters` = the boundary's 8 x 32 words; per_shard = arrivals per shard and launch.
+#define RB_FAN_SHARDS 8
+#define RB_FAN_STRIDE 32            // words between shards (128 bytes)
+__device__ __forceinline__ void rb_fan_signal(unsigned* counters, int wg) {           // all threads of the workgroup call
+#if defined(RB_HOST_INTERP)
+  __syncthreads();
+  if (threadIdx.x == 0) counters[(wg % RB_FAN_SHARDS) * RB_FAN_STRIDE] += 1u;
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's (write-through) stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(counters + (wg % RB_FAN_SHARDS) * RB_FAN_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned target_per_shard, unsigned* err) {   // all threads call
+#if defined(RB_HOST_INTERP)
+  __syncthreads();                                                          // (one launch per phase there: nothing to wait for)
+  (void)counters; (void)target_per_shard; (void)err;
+#else
+  if (threadIdx.x < 64) {                                                   // wave 0: lanes 0..7 poll one shard each
+    const int lane = (int)threadIdx.x;
+    unsigned spins = 0;
+    for (;;) {
+      unsigned v = target_per_shard;
+      if (lane < RB_FAN_SHARDS) v = __hip_atomic_load(counters + lane * RB_FAN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all((int)(v - target_per_shard) >= 0)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+#endif
+}
+
 // 16-byte global/LDS accesses (pointers must be 16-byte aligned)
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
