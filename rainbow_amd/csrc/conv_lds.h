@@ -1021,6 +1021,28 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
 }
 
 // (RB_STAMP: end-of-kernel stamps are written by the host-visible tail below)
+// ---- the input-gradient kernels' weight operand, made once per step -------------------------------------------------------
+// wT[phase][tile][k'][32]: element (co, c, ky, kx) of a layer's [cout][cin][KS][KS] weights goes to phase (ky % S, kx % S),
+// channel tile c / 32, row k' = co * taps(phase) + (ky / S) * ntx(phase) + kx / S, column c % 32.  Runtime geometry (one
+// body for every layer); `nblk` workgroups of any size share the elements.
+struct ConvWtJob {
+  const float* w;
+  float* wT;
+  int cin, cout, KS, S, kpad;
+};
+__device__ __forceinline__ void rb_conv_wt_block(const ConvWtJob& j, int blk, int nblk) {
+  const int KK = j.KS * j.KS, total = j.cout * j.cin * KK, ntiles = (j.cin + 31) / 32;
+  for (int e = blk * (int)blockDim.x + (int)threadIdx.x; e < total; e += nblk * (int)blockDim.x) {
+    const int co = e / (j.cin * KK), r = e - co * (j.cin * KK);
+    const int c = r / KK, tap = r - c * KK;
+    const int ky = tap / j.KS, kx = tap - ky * j.KS;
+    const int py = ky % j.S, px = kx % j.S, ty = ky / j.S, tx = kx / j.S;
+    const int nty = (j.KS - py + j.S - 1) / j.S, ntx = (j.KS - px + j.S - 1) / j.S;
+    const int kp = co * (nty * ntx) + ty * ntx + tx;
+    j.wT[(((int64_t)(py * j.S + px) * ntiles + (c >> 5)) * j.kpad + kp) * 32 + (c & 31)] = j.w[e];
+  }
+}
+
 // ========================================================================= data gradient ==
 // dX[img][c][y][x] = relu'(x_act) * sum_{co,ky,kx} W[co][c][ky][kx] * dY[img][co][(y-ky)/S][(x-kx)/S]
 // decomposed by phase (y % S, x % S) so only real taps are visited.  The whole dY image sits in LDS.
@@ -1028,6 +1050,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
 struct ConvLdsDxArgs {
   int cin, cout;
   const float* w;        // [cout][cin][KS][KS]
+  const float* wT;       // the same weights as the kernel wants them: [phase][32-channel tile][KPAD rows k' = (co, tap)][32]
+                         // (rb_conv_wt_block below writes it earlier in the step, as tenant workgroups of the head launch)
   const float* dy;       // [B][cout][P]
   const float* x_act;    // [NI][cin][IP] (rows [0,B))
   float* dx;             // [B][cin][IP]
@@ -1059,7 +1083,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   // the stride-1 staging stores are not: a thread holds 4 consecutive elements of a (c, tap) run, lanes 4 elements apart, and
   // with 33 the bank is (tap + c) mod 32 — 8.8 lanes per bank on average (SQ_LDS_BANK_CONFLICT: 61 % of the kernel's LDS
   // cycles); 38 spreads them to 2.0 per bank
-  constexpr int WLD = (G::S == 1 && G::KK == 9) ? 38 : 33;
+  constexpr int WLD = 36;      // (16-byte aligned rows: the slab is a straight copy of a.wT, 16-byte loads -> 16-byte LDS stores)
   constexpr int OPS = KPAD * WLD + COUT * PP;
   constexpr int WSZ = MULTI ? OPS + RED : (OPS > RED ? OPS : RED);
   __shared__ __attribute__((aligned(16))) float s_all[WSZ];
@@ -1191,106 +1215,32 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   RB_WGT(WK + 3, wgi, 0);
 #endif
   // (the weight slab is staged AFTER the first image's dY loads have been issued: its own loads then share their round
-  // trip instead of preceding it — tools/wg_timeline.py showed the two as 1.8 + 2.8 us in sequence in the forward kernels)
+  // trip instead of preceding it)
   {
-    // The slab W[co][c0 .. c0+31][taps of this phase] is read with COALESCED 16-byte loads (per-workgroup timeline: the
-    // former one-scalar-load-per-(co, tap) pattern — lanes 36 or 64 bytes apart — took 6.6-7.0 us of a 10.3 us workgroup,
-    // three times the MFMA loop and its reduction together):
-    //   stride 1 (every tap belongs to the single phase): the 32 channels x KK taps of one co are one contiguous run;
-    //   4x4 kernel, stride 2: the two kernel rows of the phase are one float4 each, half of whose elements are taps.
-    // Every load is issued before the first LDS store.  Other geometries keep the scalar pattern.
-    const int cvalid = a.cin - c0 < 32 ? a.cin - c0 : 32;
-    if constexpr (G::S == 1 && (G::KK * 32) % 4 == 0) {
-      constexpr int RUN4 = G::KK * 32 / 4;                 // float4s per output channel
-      constexpr int NLD = (COUT * RUN4 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;
-      const bool full = cvalid == 32 && ((a.cin * G::KK) & 3) == 0 && ((c0 * G::KK) & 3) == 0;   // runs complete and 16-byte aligned
-      if (full) {
-        float4 v[NLD];
+    // The slab [k' = (co, tap of this phase)][32 channels c0 ..] arrives READY-MADE from a.wT — written once per step by
+    // tenant workgroups of the head launch (rb_conv_wt_block), rows >= K and channels >= cin zero — as 16-byte loads and
+    // 16-byte LDS stores.  Gathering it here from the [co][c][ky][kx] weights cost every workgroup 3.8-4.3 us of its
+    // 7.4-7.7 (tools/wg_timeline.py: ~2000 VALU instructions of index arithmetic per thread in front of the first MFMA).
+    constexpr int NQ = (KPAD * 8 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;     // float4s of the slab per thread
+    const int ntiles = (a.cin + 31) / 32;
+    const float* src = a.wT + ((int64_t)(phase * ntiles + (int)blockIdx.y) * KPAD) * 32;
+    float4 v[NQ];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          const int n = t + i * RB_CONV_THREADS;
-          const int co = n / RUN4, f = n - co * RUN4;
-          v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (co < a.cout) v[i] = rb_ld4(a.w + ((int64_t)co * a.cin + c0) * G::KK + 4 * f);
-        }
+    for (int i = 0; i < NQ; ++i) {
+      int e = t + i * RB_CONV_THREADS;
+      if (e > KPAD * 8 - 1) e = KPAD * 8 - 1;
+      v[i] = rb_ld4(src + 4 * e);
+    }
 #if defined(RB_STAMP) && defined(RB_STAMP_FINE)
-        RB_WGT(WK + 3, wgi, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        RB_WGT(WK + 3, wgi, 2);
+    RB_WGT(WK + 3, wgi, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RB_WGT(WK + 3, wgi, 2);
 #endif
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          const int n = t + i * RB_CONV_THREADS;
-          const int co = n / RUN4, f = n - co * RUN4;
-          if (co < a.cout) {
-            const float vv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            int m = (4 * f) / G::KK, tap = 4 * f - m * G::KK;                   // one division per quad, then carry
-            int adr = (co * G::KK + tap) * WLD + m;                              // phase 0 of stride 1: tap index == (ty, tx)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              s_w[adr] = vv[e];
-              ++tap;
-              const bool wrap = tap == G::KK;
-              adr += wrap ? 1 - (G::KK - 1) * WLD : WLD;                          // next tap of this channel, or tap 0 of the next one
-              tap = wrap ? 0 : tap;
-            }
-          }
-        }
-      } else {                                             // partial channel tile / unaligned: element by element
-        for (int n = t; n < a.cout * cvalid * G::KK; n += RB_CONV_THREADS) {
-          const int co = n / (cvalid * G::KK), r = n - co * (cvalid * G::KK);
-          const int m = r / G::KK, tap = r - m * G::KK;
-          s_w[(co * taps + tap) * WLD + m] = a.w[((int64_t)co * a.cin + c0 + m) * G::KK + tap];
-        }
-        for (int n = t; n < a.cout * taps * (32 - cvalid); n += RB_CONV_THREADS)
-          s_w[(n / (32 - cvalid)) * WLD + cvalid + n % (32 - cvalid)] = 0.0f;
-      }
-    } else if constexpr (G::S == 2 && G::KS == 4) {
-      constexpr int NLD = (COUT * 64 + RB_CONV_THREADS - 1) / RB_CONV_THREADS;     // (co, c, ty): one kernel row each
-      float4 v[NLD];
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int n = t + i * RB_CONV_THREADS;
-        const int co = n >> 6, m = (n >> 1) & 31, ty = n & 1;
-        v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (co < a.cout && m < cvalid) v[i] = rb_ld4(a.w + ((int64_t)co * a.cin + c0 + m) * 16 + (py + 2 * ty) * 4);
-      }
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int n = t + i * RB_CONV_THREADS;
-        const int co = n >> 6, m = (n >> 1) & 31, ty = n & 1;
-        if (co < a.cout) {                                 // (ntx == nty == 2 for every phase of this geometry)
-          s_w[(co * 4 + ty * 2 + 0) * WLD + m] = px ? v[i].y : v[i].x;
-          s_w[(co * 4 + ty * 2 + 1) * WLD + m] = px ? v[i].w : v[i].z;
-        }
-      }
-    } else {
-    // thread = (c, co mod 16), no divisions
-    const int m = t & 31;
-    const bool cv = c0 + m < a.cin;
-    constexpr int TAPS_MAX = TMAX * TMAX, CO_STEP = RB_CONV_THREADS / 32, CO_IT = (COUT + CO_STEP - 1) / CO_STEP;
-    float v[CO_IT][TAPS_MAX];                          // every load of this thread is issued before the first LDS store
-#pragma unroll
-    for (int it = 0; it < CO_IT; ++it) {
-      const int co = (t >> 5) + it * CO_STEP;
-      const float* src = a.w + ((int64_t)(co < a.cout ? co : 0) * a.cin + c0 + (cv ? m : 0)) * G::KK;
-#pragma unroll
-      for (int ty = 0; ty < TMAX; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < TMAX; ++tx)
-          v[it][ty * TMAX + tx] = (cv && co < a.cout && ty < nty && tx < ntx) ? src[(py + ty * G::S) * G::KS + px + tx * G::S] : 0.0f;
+    for (int i = 0; i < NQ; ++i) {
+      const int e = t + i * RB_CONV_THREADS;
+      if (e < KPAD * 8) rb_st4(s_w + (e >> 3) * WLD + 4 * (e & 7), v[i]);
     }
-#pragma unroll
-    for (int it = 0; it < CO_IT; ++it) {
-      const int co = (t >> 5) + it * CO_STEP;
-#pragma unroll
-      for (int ty = 0; ty < TMAX; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < TMAX; ++tx)
-          if (co < a.cout && ty < nty && tx < ntx) s_w[(co * taps + ty * ntx + tx) * WLD + m] = v[it][ty * TMAX + tx];
-    }
-    }
-    for (int e = t; e < (KPAD - K) * 32; e += RB_CONV_THREADS) s_w[(K + (e >> 5)) * WLD + (e & 31)] = 0.0f;
   }
 
 #if defined(RB_STAMP) && defined(RB_STAMP_FINE)

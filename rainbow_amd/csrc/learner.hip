@@ -166,6 +166,8 @@ struct rb_learner {
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   float* dw_part[3];    // [ws_l][cout][K+1]
+  float* conv_wT[3];    // layers >= 1: the input-gradient kernels' weight operand [S*S phases][cin / 32 tiles][kpad][32], rewritten
+                        // every step by tenant workgroups of the head launch (conv_lds.h rb_conv_wt_block); pad rows stay zero
   float* log_ps_a;      // [B][Z]
   float* pns_a;         // [B][Z]
   float* m;             // [B][Z]
@@ -425,6 +427,10 @@ struct HeadWave {
   }
 };
 
+struct HeadTenants {
+  ConvWtJob job[2];
+  int per_job;           // workgroups per job (0: no tenants)
+};
 #define RB_HEAD_THREADS 1024      // launch bound; the launch uses 64 x min(16, max(8, 2A + 1)) threads
 template <int ZI>
 __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, const float* logits, const int64_t* actions,
@@ -432,7 +438,16 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
                                                const float* support, float v_min, float v_max, float gamma_n,
                                                float delta_z, float* log_ps_a_out, float* pns_a_out, float* m_out,
                                                int32_t* a_star_out, float* loss_out, float* dlogits, long long* step_ctr,
-                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT) {
+                                               const int32_t* batch_status, int32_t* status_copy, float* dlogitsT, HeadTenants tn) {
+  // tenant workgroups behind the B samples: the conv input-gradient kernels' weight operand of THIS step (conv_lds.h
+  // rb_conv_wt_block) — independent of the head, on CUs this launch leaves idle (32 of 256 busy), two launches ahead of its
+  // first reader
+  if ((int)blockIdx.x >= B) {
+    const int tb = (int)blockIdx.x - B;
+    if (tb < tn.per_job) rb_conv_wt_block(tn.job[0], tb, tn.per_job);
+    else rb_conv_wt_block(tn.job[1], tb - tn.per_job, tn.per_job);
+    return;
+  }
   __shared__ float s_lg[3][RB_MAX_NZ];               // rows: online(states), online(next), target(next)
   __shared__ float s_pt[RB_MAX_NZ];                  // target(next) probabilities of EVERY action: [a][z] at a * Z + z
   __shared__ float s_lo[RB_MAX_ATOMS], s_hi[RB_MAX_ATOMS], s_m[RB_MAX_ATOMS], s_logp[RB_MAX_ATOMS], s_sup[RB_MAX_ATOMS];
@@ -1058,12 +1073,13 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
   if (!(mode & 2)) return RB_OK;
   if constexpr (G::IH == 84) {
     // first-layer geometries never need a data gradient (frames are not differentiated)
-  } else if (layer > 0 && l->fast_conv && ((l->lazy_dfeat && layer == L.nconv - 1) == RB_LAST_CONV_GEOM(G))) {
+  } else if (layer > 0 && l->fast_conv && l->conv_wT[layer] && ((l->lazy_dfeat && layer == L.nconv - 1) == RB_LAST_CONV_GEOM(G))) {
     // (the last layer's LDS kernel exists in its LAZY form only — dY summed from the hidden layer's row-split partials while
     // it is staged; when those are not what the step produced, i.e. the generic FC path ran, the generic kernel below runs)
     ConvLdsDxArgs a;
     a.cin = c.cin; a.cout = c.cout;
     a.w = l->p_online + L.conv_w[layer]; a.dy = l->dact[layer]; a.x_act = l->act[layer - 1]; a.dx = l->dact[layer - 1];
+    a.wT = l->conv_wT[layer];
     constexpr bool lazy = RB_LAST_CONV_GEOM(G);
     a.dy_part = l->dfeat_part; a.dy_mask = l->act[layer]; a.dy_stride = (int64_t)L.B * L.F; a.dy_splits = lazy ? l->lazy_splits : 0;
     constexpr int NPOS = ((G::IH + G::S - 1) / G::S) * ((G::IH + G::S - 1) / G::S);
@@ -1255,6 +1271,7 @@ int rb_learner_destroy(rb_learner_t* l) {
   if (!l) return RB_OK;
   float** owned[] = {&l->feat_b, &l->h_b, &l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
                      &l->logits, &l->dlogits, &l->dlogitsT, &l->dh, &l->dhT, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
+                     &l->conv_wT[0], &l->conv_wT[1], &l->conv_wT[2],
                      &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
   for (float** p : owned)
     if (*p) rb_dev_free(*p);
@@ -1341,6 +1358,12 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
       int64_t slices = l->ws[i];
       if (slices < (int64_t)B * 5) slices = (int64_t)B * 5;   // LDS weight-grad kernels: B images x <=5 row chunks
       RB_ALLOC(l->dw_part[i], slices * c.cout * (c.K() + 1));
+    }
+    if (i > 0 && l->fast_conv && c.cin % 32 == 0) {
+      const int tmax = (c.ks + c.s - 1) / c.s;
+      const int64_t n = (int64_t)c.s * c.s * (c.cin / 32) * (rb_div_up(c.cout * tmax * tmax, 16) * 16) * 32;
+      RB_ALLOC(l->conv_wT[i], n);
+      RB_HIP_TRY(hipMemset(l->conv_wT[i], 0, (size_t)n * 4));
     }
   }
   l->rows_cap = NI;
@@ -1676,10 +1699,23 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     int hwaves = 2 * L.A + 1;
     if (hwaves < 8) hwaves = 8;
     if (hwaves > 16) hwaves = 16;
-    const dim3 hgrid((unsigned)B), hblock((unsigned)(64 * hwaves));
+    HeadTenants tn;
+    memset(&tn, 0, sizeof(tn));
+    int n_jobs = 0;
+    if (l->fast_conv) {
+      for (int layer = 1; layer < L.nconv && n_jobs < 2; ++layer) {
+        if (!l->conv_wT[layer]) continue;
+        const ConvLayer& c = L.conv[layer];
+        const int tmax = (c.ks + c.s - 1) / c.s;
+        tn.job[n_jobs++] = ConvWtJob{on.conv_w[layer], l->conv_wT[layer], c.cin, c.cout, c.ks, c.s, (int)rb_div_up(c.cout * tmax * tmax, 16) * 16};
+      }
+      if (n_jobs == 1) tn.job[1] = tn.job[0];
+      tn.per_job = n_jobs > 0 ? 8 : 0;
+    }
+    const dim3 hgrid((unsigned)(B + (n_jobs > 0 ? 2 * tn.per_job : 0))), hblock((unsigned)(64 * hwaves));
 #define RB_HEAD_ARGS B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev, nonterminals_dev, weights_dev, (const float*)l->support, \
     l->cfg.v_min, l->cfg.v_max, l->gamma_n, l->delta_z, l->log_ps_a, l->pns_a, l->m, l->a_star, loss_dev, l->dlogits, l->step_ctr,          \
-    l->batch_status, l->status_copy, l->dlogitsT
+    l->batch_status, l->status_copy, l->dlogitsT, tn
     if (L.Z <= 64) { RB_LAUNCH_T("head:k_head", k_head<1>, hgrid, hblock, stream, RB_HEAD_ARGS); }
     else if (L.Z <= 128) { RB_LAUNCH_T("head:k_head", k_head<2>, hgrid, hblock, stream, RB_HEAD_ARGS); }
     else { RB_LAUNCH_T("head:k_head", k_head<4>, hgrid, hblock, stream, RB_HEAD_ARGS); }

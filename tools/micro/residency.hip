@@ -15,6 +15,20 @@ __global__ void k_spin(Rec* out, long long ticks) {
   if (SG == 3) asm volatile("v_mov_b32 v40, 0" ::: "v40");      // 41+ VGPRs
   if (SG == 4) asm volatile("v_mov_b32 v80, 0" ::: "v80");      // 81+ VGPRs
   lds[threadIdx.x] = (char)threadIdx.x;
+  if (SG == 5) {                                                 // fill the whole allocation with 16-byte stores first
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < LDSB / 16; i += blockDim.x) l4[i] = make_float4((float)i, 1.0f, 2.0f, 3.0f);
+  }
+  if (SG == 6) {                                                 // ... with 4-byte stores
+    float* l1 = reinterpret_cast<float*>(lds);
+    for (int i = threadIdx.x; i < LDSB / 4; i += blockDim.x) l1[i] = (float)i;
+  }
+  if (SG == 7) {                                                 // a kernel that uses the matrix cores
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)threadIdx.x, 1.0f, acc, 0, 0, 0);
+    if (acc[0] == 123.0f) lds[1] = 1;
+  }
   __syncthreads();
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
@@ -49,6 +63,11 @@ int main() {
   for (int th : {512, 640}) run<30000>(th, 768);
   for (int th : {256, 512, 640}) run<60160, 1>(th, 512);
   for (int th : {256, 512, 640}) run<60160, 2>(th, 512);
+  printf("LDS filled before the spin (SG 5: 16-byte stores, 6: 4-byte stores), 5 us, 480 blocks:\n");
+  for (int th : {512, 640}) run<60160, 5>(th, 480, 500LL);
+  for (int th : {512, 640}) run<60160, 6>(th, 480, 500LL);
+  printf("with an MFMA in the kernel (SG 7), 5 us, 480 blocks:\n");
+  for (int th : {512, 640}) run<60160, 7>(th, 480, 500LL);
   printf("short kernels (5 us), 480 blocks:\n");
   for (int th : {512, 640}) run<60160, 3>(th, 480, 500LL);
   for (int th : {512, 640}) run<60160, 3>(th, 480, 500LL, dim3(96, 1, 5));
