@@ -122,6 +122,12 @@ def kernel_table(cfg, n_params, hosted_update=False):
         # dW and dX are B x F x 2H MACs each
         "fc_h_bwd": binding(2 * wh + (0 if fused_dw else 2 * wh) + B * (F + 2 * H) * 4, 2 * 2 * B * F * 2 * H),
     }
+    # the output-layer / head tail (three small launches; HBM-bound by their bytes, latency-bound in fact: DESIGN.md §3)
+    NZ = 51 * (cfg["actions"] + 1)
+    wz = NZ * H * 4                         # one of mu / sigma of the output layer, bytes
+    t["fc_z_fwd"] = dict(bound="hbm", work=2 * 2 * wz + 3 * B * (2 * H + NZ) * 4, unit="GB/s")
+    t["head"] = dict(bound="hbm", work=3 * B * NZ * 4 + 2 * B * NZ * 4, unit="GB/s")
+    t["fc_z_bwd"] = dict(bound="hbm", work=2 * wz + 2 * wz + B * (NZ + 2 * 2 * H) * 4, unit="GB/s")
     dw = 0
     for i, (cin, cout, ks, _s, _ih, oh) in enumerate(conv):
         K, P = cin * ks * ks, oh * oh

@@ -1710,7 +1710,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         tn.job[n_jobs++] = ConvWtJob{on.conv_w[layer], l->conv_wT[layer], c.cin, c.cout, c.ks, c.s, (int)rb_div_up(c.cout * tmax * tmax, 16) * 16};
       }
       if (n_jobs == 1) tn.job[1] = tn.job[0];
-      tn.per_job = n_jobs > 0 ? 8 : 0;
+      tn.per_job = n_jobs > 0 ? 48 : 0;                  // (one element or two per thread: the tenants must stay shorter than the head)
     }
     const dim3 hgrid((unsigned)(B + (n_jobs > 0 ? 2 * tn.per_job : 0))), hblock((unsigned)(64 * hwaves));
 #define RB_HEAD_ARGS B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev, nonterminals_dev, weights_dev, (const float*)l->support, \

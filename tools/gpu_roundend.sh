@@ -1,10 +1,16 @@
 # usage: bash tools/gpu_roundend.sh <tag>: the evidence set committed under profiles/ at the end of a round —
-# GPU test log, smoke, and per bench config: bench line (with cpu_baseline), rocprofv3 kernel stats, PMC traffic; the loop bench
+# GPU test log, smoke, and per bench config: bench line (with cpu_baseline), rocprofv3 kernel stats, PMC traffic; the per-kernel
+# trace of the headline config (durations + idle gaps), the loop bench, the per-workgroup timeline (RB_STAMP build when present)
 TAG=$1
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log; tail -2 gpurun_out/${TAG}_pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log; grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" gpurun_out/${TAG}_pytest_gpu.log | tail -2
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/${TAG}_smoke.log; tail -2 gpurun_out/${TAG}_smoke.log
 bash tools/gpu_evidence.sh ${TAG}_cfg2 pong-canonical-b32
+bash tools/gpu_trace_gaps.sh pong-canonical-b32 > gpurun_out/${TAG}_trace.txt 2>&1; grep "n/step" gpurun_out/${TAG}_trace.txt | cut -c1-120
 bash tools/gpu_evidence.sh ${TAG}_cfg3 breakout-canonical-b256
 bash tools/gpu_evidence.sh ${TAG}_cfg4 data-efficient-b32
 timeout 600 python tools/loop_bench.py > gpurun_out/${TAG}_loop_bench.json.log 2>&1; tail -1 gpurun_out/${TAG}_loop_bench.json.log | cut -c1-600
+if [ -f rainbow_amd/librainbow_hip_stamp.so ]; then
+  RAINBOW_AMD_LIB=$PWD/rainbow_amd/librainbow_hip_stamp.so timeout 200 python tools/wg_timeline.py > gpurun_out/${TAG}_wg_timeline.txt 2>&1
+  RAINBOW_AMD_LIB=$PWD/rainbow_amd/librainbow_hip_stamp.so timeout 100 python tools/stamp/act_timeline.py > gpurun_out/${TAG}_act_timeline.txt 2>&1
+fi

@@ -33,7 +33,10 @@ def tag_of(name, grid, biggest):
         return "conv_dw_all"
     if "k_sample" in name:
         return "sample"
-    for kind, suffix in (("k_conv_fwd_lds", "fwd"), ("k_conv_fwd_multi", "fwd"), ("k_conv_fwd_full", "fwd"), ("k_conv_dx_lds", "dx")):
+    if "k_head<" in name:
+        return "head"
+    for kind, suffix in (("k_conv_fwd_lds", "fwd"), ("k_conv_fwd_t16", "fwd"), ("k_conv_fwd_multi", "fwd"), ("k_conv_fwd_full", "fwd"),
+                         ("k_conv_dx_lds", "dx")):
         if kind in name:
             geo = name.split("ConvGeom<")[1].split(">")[0].replace(" ", "")
             layer = {"8,4,84,20": 1, "4,2,20,9": 2, "3,1,9,7": 3, "5,5,84,16": 1, "5,5,16,3": 2}.get(geo)
