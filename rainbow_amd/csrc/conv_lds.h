@@ -163,7 +163,12 @@ struct ConvFwdLdsSize {
 template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, bool F32SRC = false, int T16 = 0>
 struct ConvFwdWaves {
   static constexpr int PT = (PCH + 15) / 16;
-  static constexpr int NWV = T16 == 1 ? 2 * PT : T16 == 2 ? PT : RB_CONV_WAVES;     // T16 = channel tiles per wave
+  // T16 = channel tiles per wave.  The wave count is rounded up to a multiple of 4 — an even share per SIMD: a 10-wave workgroup
+  // puts 3 waves on two SIMDs, and the compiler, which sizes the register allocation for the AVERAGE waves per SIMD its LDS
+  // footprint allows (next_free_vgpr is raised to the smallest count that still gives that occupancy), then leaves no room
+  // for the second workgroup the LDS would admit (profiles/round4_experiments.txt §5); the spare waves help staging and leave
+  static constexpr int TILE_WAVES = T16 == 1 ? 2 * PT : PT;
+  static constexpr int NWV = T16 == 0 ? RB_CONV_WAVES : (TILE_WAVES + 3) / 4 * 4;
 };
 template <class G, int KMAX, int PLANE, int RP, int SUB>
 __device__ __forceinline__ constexpr int rb_t16_off(int j) {            // step j of a lane's K quarter -> offset in the patch
@@ -462,6 +467,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     // CTW channel tiles per wave: 1 = a wave per (position tile, channel tile); 2 = a wave per position tile, both channel
     // tiles of the slab from ONE patch operand per step (the first layer: five waves instead of ten per workgroup)
     constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4, CTW = T16;
+    if (wave >= ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, T16>::TILE_WAVES) return;   // spare staging waves (no barrier follows)
     const int pt = wave % PT, ct0 = (wave / PT) * CTW;      // wave-uniform: position tile, first channel tile
     const int x = lane & 15, kq = lane >> 4;
     int p = p0 + pt * 16 + x;
@@ -622,7 +628,8 @@ __global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX>::
 
 // the t16 variant (rb_conv_fwd_body<..., T16 = CTW>): grid as k_conv_fwd_lds, block = 64 * ConvFwdWaves<..., CTW>::NWV threads
 template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, int CTW = 1>
-__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, CTW>::NWV)) void k_conv_fwd_t16(ConvLdsFwdArgs a) {
+__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, CTW>::NWV))
+void k_conv_fwd_t16(ConvLdsFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, CTW>::FLOATS];
   if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, false, CTW>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
   else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, false, CTW>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);

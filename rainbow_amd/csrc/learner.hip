@@ -1322,7 +1322,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);
-  l->opt_t16 = rb_opt("t16", 6);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
+  l->opt_t16 = rb_opt("t16", 7);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
     // input-gradient row splits: 256 weight rows per workgroup (64 per wave = 4 sixteen-row iterations); measured
