@@ -24,7 +24,7 @@ extern __device__ long long g_cstamp[64];
 #define RB_CSTAMP_LAST(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) g_cstamp[i] = wall_clock64(); } while (0)
 // per-workgroup timeline: g_wgt[kernel id][workgroup][slot] = wall_clock64 (100 MHz) at phase boundaries, slot 7 = where
 // it ran (XCC id << 16 | HW_ID bits) — tools/wg_timeline.py draws the schedule of a launch from it
-#define RB_WGT_KERNELS 12
+#define RB_WGT_KERNELS 14
 #define RB_WGT_WGS 2048
 extern __device__ long long g_wgt[RB_WGT_KERNELS][RB_WGT_WGS][8];
 #define RB_WGT(kid, wg, slot) do { if (threadIdx.x == 0 && (wg) < RB_WGT_WGS) g_wgt[kid][wg][slot] = wall_clock64(); } while (0)

@@ -18,6 +18,7 @@
 #include "adam_body.h"
 #include "learner_problems.h"
 #include "noisy_linear.h"
+#include "fc_gemm.h"
 #include "act_path.h"
 #include "rb_common.h"
 
@@ -165,6 +166,9 @@ struct rb_learner {
   int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_img_fast;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
+  int opt_fc_gemm;      // hidden layer on the LDS-tiled GEMMs of fc_gemm.h: -1 = from 128 rows per net on (default), 1 = always, 0 = never
+  float* gemm_part;     // split-K partial tiles of k_fc_gemm_fwd: one 64 KB tile per workgroup slot (n_cu of them)
+  unsigned* gemm_ctr;   // its per-tile arrival counters (self-resetting)
   float* dw_part[3];    // [ws_l][cout][K+1]
   float* conv_wT[3];    // layers >= 1: the input-gradient kernels' weight operand [S*S phases][cin / 32 tiles][kpad][32], rewritten
                         // every step by tenant workgroups of the head launch (conv_lds.h rb_conv_wt_block); pad rows stay zero
@@ -997,7 +1001,21 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     const unsigned mch32 = (unsigned)rb_div_up(m_max, wide ? 64 : RB_FWD2_MROWS);
     // (16-row m-chunks — 384 workgroups, every CU busy — measured 20.8 us against 16.2: the tiles are re-read four times)
     const dim3 hg((unsigned)(2 * ht16), 1, 2 * mch32), hb(64 * RB_NL_FWD_WAVES);
-    if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
+    // from 128 rows per net on the layer is a GEMM, not a weight stream: 128 x 128 LDS tiles, split-K over the idle CUs (fc_gemm.h)
+    const bool gemm = l->gemm_part && (l->opt_fc_gemm == 1 || (l->opt_fc_gemm < 0 && m_max >= 128));
+    if (gemm) {
+      FcGemmFwdArgs ga;
+      ga.f = a;
+      ga.mt[0] = (int)rb_div_up(n_on, RB_TG_T); ga.mt[1] = (int)rb_div_up(n_tg, RB_TG_T);
+      ga.nt = (int)rb_div_up(2 * L.H, RB_TG_T);
+      const int tiles = (ga.mt[0] + ga.mt[1]) * ga.nt;
+      int S = l->n_cu / tiles;
+      if (S > 8) S = 8;
+      if (S > L.F / RB_TG_KS) S = L.F / RB_TG_KS;
+      if (S < 1 || tiles > 1024) S = 1;
+      ga.S = S; ga.part = l->gemm_part; ga.ctr = l->gemm_ctr;
+      RB_LAUNCH_T("fc_h_fwd:k_fc_gemm_fwd", k_fc_gemm_fwd, dim3((unsigned)(tiles * S)), dim3(RB_TG_THREADS), stream, ga);
+    } else if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
     else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a); }
     RB_LAUNCH_CHECK();
     // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
@@ -1272,12 +1290,13 @@ int rb_learner_destroy(rb_learner_t* l) {
   float** owned[] = {&l->feat_b, &l->h_b, &l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
                      &l->logits, &l->dlogits, &l->dlogitsT, &l->dh, &l->dhT, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
                      &l->conv_wT[0], &l->conv_wT[1], &l->conv_wT[2],
-                     &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part};
+                     &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part, &l->gemm_part};
   for (float** p : owned)
     if (*p) rb_dev_free(*p);
   if (l->a_star) rb_dev_free(l->a_star);
   if (l->noise_ctr) rb_dev_free(l->noise_ctr);
   if (l->act_ctr) rb_dev_free(l->act_ctr);
+  if (l->gemm_ctr) rb_dev_free(l->gemm_ctr);
   if (l->job_dev) rb_dev_free(l->job_dev);
   if (l->status_copy) rb_dev_free(l->status_copy);
   if (l->adam_args_dev) rb_dev_free(l->adam_args_dev);
@@ -1323,6 +1342,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_t16 = rb_opt("t16", 7);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
+  l->opt_fc_gemm = rb_opt("fc_gemm", -1);             // hidden layer as LDS-tiled GEMMs (fc_gemm.h): -1 = from 128 rows on
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
     // input-gradient row splits: 256 weight rows per workgroup (64 per wave = 4 sixteen-row iterations); measured
@@ -1401,6 +1421,13 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     l->n_cu = cus;
   }
 #endif
+  if (l->fast_fc && l->opt_fc_gemm != 0) {
+    // split-K scratch of k_fc_gemm_fwd: tiles * S <= n_cu whenever S > 1, one 128 x 128 partial tile each
+    hipError_t e = rb_dev_malloc((void**)&l->gemm_part, (size_t)l->n_cu * RB_TG_T * RB_TG_T * 4);
+    if (e == hipSuccess) e = rb_dev_malloc((void**)&l->gemm_ctr, 1024 * 4);
+    if (e != hipSuccess) { rb_set_error("rb_learner_create: hipMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
+    RB_HIP_TRY(hipMemset(l->gemm_ctr, 0, 1024 * 4));
+  }
   RB_HIP_TRY(hipMemset(l->noise_ctr, 0, 16));
   RB_HIP_TRY(hipMemset(l->status_copy, 0, 16));
   float sup[RB_MAX_ATOMS];
@@ -1737,6 +1764,10 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const int z_ct = pipe ? 2 : 0, h_ct = pipe ? 4 : 0;
     FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
     FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, feat, B, h_ct);
+    // batch >= 128: the hidden layer's two gradients as LDS-tiled GEMMs in one launch (fc_gemm.h k_fc_gemm_bwd)
+    const bool gemm_bwd = !exch && l->gemm_part && (l->opt_fc_gemm == 1 || (l->opt_fc_gemm < 0 && B >= 128));
+    const int g_nt = (int)rb_div_up(2 * L.H, RB_TG_T), g_kt = (int)rb_div_up(L.F, RB_TG_T);
+    if (gemm_bwd) hp.slots = 8 * g_nt * g_kt;             // one sum-of-squares slot per wave of a weight-gradient tile
     int64_t conv_out = 0;
     for (int layer = 0; layer < L.nconv; ++layer) conv_out += (int64_t)L.conv[layer].cout * (L.conv[layer].K() + 1);
     const int c_slots = (int)rb_div_up(conv_out, 64);
@@ -1803,7 +1834,15 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
       // the priority write-back (a single-workgroup latency chain of ~11 us) rides in the LONGER of the two backward
       // launches: as a tenant of the output layer's launch (~8 us of real work) it was that launch's long pole
       const unsigned h_blocks = (unsigned)(hg.dw_x * hg.dw_y + hg.dx_x * hg.dx_y * hg.dx_z + (up.enabled ? 1 : 0));
-      if (h_blocks > 0) { RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd<false>, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up); }
+      if (gemm_bwd) {
+        FcGemmBwdGrid gg;
+        gg.first = up.enabled ? 8 : 0;
+        gg.dx_mt = (int)rb_div_up(B, RB_TG_T); gg.dx_kt = g_kt; gg.dx_splits = hsplits;
+        gg.dx_combos = (int)rb_div_up(g_kt * hsplits, 8) * 8;
+        gg.dw_nt = g_nt; gg.dw_kt = g_kt;
+        const unsigned gb = (unsigned)(gg.first + gg.dx_mt * gg.dx_combos + g_nt * g_kt);
+        RB_LAUNCH_T("fc_h_bwd:k_fc_gemm_bwd", k_fc_gemm_bwd, dim3(gb), dim3(RB_TG_THREADS), stream, hw_, hx, gg, up);
+      } else if (h_blocks > 0) { RB_LAUNCH_T("fc_h_bwd:k_nl_bwd", k_nl_bwd<false>, dim3(h_blocks), dim3(256), stream, hw_, hx, hg, up); }
     }
     l->sink_done = up.enabled ? 1 : 0;
     RB_LAUNCH_CHECK();

@@ -94,6 +94,21 @@ def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, fu
     ad.close()
 
 
+@pytest.mark.parametrize("name,steps", [("canon", 1), ("dataeff", None), ("atoms21", None)])
+def test_tiled_gemm_hidden_layer_matches_golden(emu, monkeypatch, name, steps):
+    """From 128 rows per net on (BASELINE config 3: batch 256) the hidden NoisyLinear layer runs as LDS-tiled f32 MFMA GEMMs
+    (fc_gemm.h): forward with split-K + last-arriver sum, input gradient into the row-split partial slices, weight gradient
+    with the sigma / bias / sum-of-squares epilogue.  RB_OPTS fc_gemm=1 forces them onto the small fixtures: ragged tiles in
+    every dimension (M = 16 / 8, N = 128 / 64 / 96, K = 3136 / 576), both streams inside one 128-row tile."""
+    monkeypatch.setenv("RB_OPTS", "fc_gemm=1")
+    ad = CAbiLearnAdapter(emu, NumpyMem(), name)
+    trace = scenarios.learn_scenario(ad, name, O, steps=steps)
+    golden = load_golden("learn_%s.npz" % name)
+    assert_learn_trace_matches(trace, {k: v for k, v in golden.items() if k in trace}, label="emu-fc-gemm/" + name)
+    assert any("_grad/fc_h" in k for k in trace)
+    ad.close()
+
+
 @pytest.mark.parametrize("name", ["dataeff"])     # (the canonical stack runs the same test on the GPU: 2.5 min on the interpreter)
 def test_fused_weight_gradient_in_optimiser_pass_matches_golden(emu, name):
     """RB_LEARNER_FUSE_FC_H_DW (what rainbow_amd.agent.Agent runs): the hidden layer's weight gradient is not stored by the
@@ -144,10 +159,14 @@ def test_unit_conversion_is_exact():
     assert np.array_equal(q2, x / np.float32(255))
 
 
-def test_zero_copy_windows_equals_gathered_stacks(emu):
+@pytest.mark.parametrize("fc_gemm", ["-1", "1"], ids=["streamed-fc", "tiled-gemm-fc"])
+def test_zero_copy_windows_equals_gathered_stacks(emu, monkeypatch, fc_gemm):
     """rb_learner_learn_windows (conv1 reads the replay ring through the sampler's window table) must give
-    bit-identical loss and gradients to rb_learner_learn on the gathered stacks, incl. blanked frames."""
+    bit-identical loss and gradients to rb_learner_learn on the gathered stacks, incl. blanked frames.  Second half: the
+    priority write-back as a tenant of the hidden layer's backward launch — k_nl_bwd (256 threads) and, with RB_OPTS
+    fc_gemm=1, k_fc_gemm_bwd (512 threads, block 0 of a launch whose tiles start at block 8)."""
     import ctypes as C
+    monkeypatch.setenv("RB_OPTS", "fc_gemm=" + fc_gemm)
     from cabi_adapter import CAbiReplayAdapter
     from rainbow_amd import _lib as L
     name = "dataeff"

@@ -11,7 +11,7 @@ cfg = dict(bench.CONFIGS["pong-canonical-b32"])
 args = bench.make_args(cfg, dev)
 agent = Agent(args, types.SimpleNamespace(action_space=lambda: cfg["actions"]))
 lib = L.load()
-K, W = 12, 2048
+K, W = 14, 2048
 buf = (C.c_longlong * (K * W * 8))()
 lib.rb_debug_wgtrace.argtypes = [C.c_void_p, C.c_int]
 st = torch.rand(4, 84, 84, device=dev)

@@ -26,7 +26,7 @@ agent = Agent(args, env)
 mem = ReplayMemory(args, cfg["capacity"], seed=7)
 bench.fill_replay(mem, cfg["capacity"], cfg["actions"], seed=0)
 lib = L.load()
-K, W = 12, 2048
+K, W = 14, 2048
 buf = (C.c_longlong * (K * W * 8))()
 lib.rb_debug_wgtrace.argtypes = [C.c_void_p, C.c_int]
 for it in range(40):
