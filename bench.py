@@ -403,6 +403,7 @@ def main():
     for _ in range(per_iters):
         o = mem.sample_device(B)
         mem.update_priorities(o["tree_idxs"], fake_loss)
+    mem.flush()                      # update_priorities is lazy (it rides in the next sampler launch): the last one runs inside the timed region
     torch.cuda.synchronize(dev)
     per_rate = per_iters * B / (time.perf_counter() - t1)
 
@@ -430,8 +431,9 @@ def main():
         out["roofline_per"] = {"bound": "hbm", "achieved": per_rate * per_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": per_rate * per_bytes / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_sample": per_bytes,
                                "batch": B, "us_per_batch": 1e6 * B / per_rate,
-                               "binding": "latency: one batch in flight = 3 dependent launches (sample, gather, update) of "
-                                          "single-workgroup dependent-load chains; bytes are 0.1% of what HBM moves in that time"}
+                               "binding": "latency: one batch in flight = 2 dependent launches (update of batch k + draw of batch k + 1 "
+                                          "as one single-workgroup chain, then the frame gather); up to 64 leaves per write-back, "
+                                          "else 3 launches; bytes are 0.1% of what HBM moves in that time"}
         # counter traffic: only from a PMC pass of THIS config that is committed under profiles/ (tools/gpu_pmc.sh);
         # null otherwise — never a number measured on another workload
         import glob

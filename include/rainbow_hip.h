@@ -188,6 +188,17 @@ int rb_replay_update_leaves(rb_replay_t* r, const int64_t* tree_idx_dev, const f
 int rb_replay_update_priorities(rb_replay_t* r, const int64_t* tree_idx_dev,
                                 const float* losses_dev, int32_t n, rb_stream_t stream);
 
+/* ReplayMemory.update_priorities(idx, loss) of learn step k (agent.py:100, memory.py:157-159) followed by
+ * ReplayMemory.sample(batch) of step k + 1 (agent.py:62, memory.py:148-155) as ONE launch of one workgroup: the update's
+ * writes to the top of the tree go straight into the LDS copy the search starts from.  Results (tree, header, batch) are
+ * bit-identical to rb_replay_update_priorities followed by rb_replay_sample with the same arguments; upd_n above 64 or batch
+ * above 256 take exactly those two calls.  states_dev / next_states_dev may be NULL as in rb_replay_sample.                 */
+int rb_replay_update_sample(rb_replay_t* r, const int64_t* upd_tree_idx_dev, const float* upd_losses_dev, int32_t upd_n,
+                            int32_t batch, double priority_weight, const double* unit_uniforms_dev, int32_t max_attempts,
+                            int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
+                            int64_t* actions_dev, float* returns_dev, float* nonterminals_dev,
+                            float* weights_dev, rb_stream_t stream);
+
 /* ReplayMemory.__next__ (memory.py:167-178): blanked history stack for data index i,
  * as f32 /255, out_dev f32[history][7056].                                          */
 int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_stream_t stream);

@@ -82,6 +82,8 @@ SIGNATURES = {
                                              c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(NoiseJob), c_void_p]),
     "rb_replay_update_leaves": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "rb_replay_update_priorities": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "rb_replay_update_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double, c_void_p, c_int32, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rb_replay_state_at": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rb_replay_states_at": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "rb_u8_to_unit_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -449,6 +449,12 @@ __device__ long long g_stamp[32];
 #ifndef RB_HOST_AU_WIDE
 #define RB_HOST_AU_WIDE 4      // quadruples per hosted thread under the 1024-thread variant (5 spills under its 128-register cap)
 #endif
+template <int MAXT>
+__device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batch, float neg_beta_arg, const float* neg_beta_ptr,
+                                               const double* unit_uniforms, int32_t max_attempts, uint64_t seed, const float* scaling,
+                                               int64_t* tree_idx_out, int32_t* win, int64_t* actions_out, float* returns_out,
+                                               float* nonterminals_out, float* weights_out, int32_t* fail_count, int32_t lds_top,
+                                               int* s_flag, float* s_red, float* s_top, bool top_staged);
 template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
@@ -477,6 +483,18 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
+  rb_sample_main<MAXT>(v, batch, neg_beta_arg, neg_beta_ptr, unit_uniforms, max_attempts, seed, scaling, tree_idx_out, win, actions_out,
+                       returns_out, nonterminals_out, weights_out, fail_count, lds_top, s_flag, s_red, s_top, false);
+}
+
+// The sampler proper (one workgroup, thread i = sample i): shared by k_sample (block 0) and k_update_sample.  top_staged: the
+// caller has already copied the tree top into s_top (and kept it current).
+template <int MAXT>
+__device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batch, float neg_beta_arg, const float* neg_beta_ptr,
+                                               const double* unit_uniforms, int32_t max_attempts, uint64_t seed, const float* scaling,
+                                               int64_t* tree_idx_out, int32_t* win, int64_t* actions_out, float* returns_out,
+                                               float* nonterminals_out, float* weights_out, int32_t* fail_count, int32_t lds_top,
+                                               int* s_flag, float* s_red, float* s_top, bool top_staged) {
   RB_STAMP_AT(0);
   const int i = (int)threadIdx.x;
   const bool active = i < batch;
@@ -485,7 +503,7 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
   const float neg_beta_f32 = neg_beta_ptr ? *neg_beta_ptr : neg_beta_arg;
 
   const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
-  if (lds_top) {
+  if (lds_top && !top_staged) {
     for (int t = 4 * i; t < n_cached; t += 4 * (int)blockDim.x) {        // 16-byte loads (the tree buffer is 16-byte aligned)
       if (t + 3 < n_cached) {
         *reinterpret_cast<float4*>(&s_top[t]) = *reinterpret_cast<const float4*>(&v.tree[t]);
@@ -601,7 +619,68 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
                                                   int32_t apply_pow, double omega) {
   __shared__ float lds[UpdateLds<2048, 1024>::WORDS];
+  if (n <= 64) {                                            // block-uniform: is this a sampler's batch (sorted leaves)?
+    __shared__ int s_sorted;
+    UpdateOperand op;
+    if (threadIdx.x < 64) {
+      op = rb_update_load(v, tree_idx, values, n);           // every first load of the kernel in one batch
+      if (threadIdx.x == 0) s_sorted = op.sorted;
+    }
+    __syncthreads();
+    if (s_sorted) {
+      if (threadIdx.x < 64) rb_update_sorted_wave(v, op, n, apply_pow, omega, nullptr, 0);
+      return;
+    }
+  }
   rb_update_body<2048, 1024>(v, tree_idx, values, n, apply_pow, omega, lds);
+}
+
+// ------------------------------------------------------------ update + sample --
+// update_priorities(idx_k, loss_k) followed by sample(k + 1) — the PER loop of memory.py:148-159 / agent.py:62,100 — as ONE
+// launch of one workgroup: the two are a dependent pair of single-workgroup latency chains, and as two launches the second
+// pays a launch boundary, re-reads the header and stages the 16 KB tree top that the first has just rewritten.  Here the top
+// is staged while the update's operands are in flight, the sorted-batch update (rb_update_sorted_wave, one wave) patches that
+// LDS copy as it writes the tree, and the search starts from it.  Unsorted or longer batches (<= 256) take the hashed body
+// and the top is staged afterwards.  Same arithmetic, same order: tree, header and batch are bit-identical to the two calls.
+__global__ __launch_bounds__(256) void k_update_sample(ReplayView v, const int64_t* upd_idx, const float* upd_val, int32_t upd_n,
+                                                        int32_t apply_pow, double omega, int32_t batch, float neg_beta_arg,
+                                                        const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts,
+                                                        uint64_t seed, const float* scaling, int64_t* tree_idx_out, int32_t* win,
+                                                        int64_t* actions_out, float* returns_out, float* nonterminals_out,
+                                                        float* weights_out, int32_t* fail_count) {
+  __shared__ int s_flag[16];
+  __shared__ float s_red[16];
+  __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
+  __shared__ float lds_upd[UpdateLds<512, 256>::WORDS];
+  __shared__ int s_sorted;
+  const int i = (int)threadIdx.x;
+  const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
+  UpdateOperand op;
+  op.node = -1; op.val = 0.0f; op.status = 0; op.sorted = 0;
+  if (upd_n <= 64) {
+    if (i < 64) op = rb_update_load(v, upd_idx, upd_val, upd_n);
+    if (i == 0) s_sorted = op.sorted;
+  } else if (i == 0) {
+    s_sorted = 0;
+  }
+  for (int t = 4 * i; t < n_cached; t += 4 * (int)blockDim.x) {          // (same staging as rb_sample_main)
+    if (t + 3 < n_cached) {
+      *reinterpret_cast<float4*>(&s_top[t]) = *reinterpret_cast<const float4*>(&v.tree[t]);
+    } else {
+      for (int u = t; u < n_cached; ++u) s_top[u] = v.tree[u];
+    }
+  }
+  __syncthreads();
+  const bool sorted = s_sorted != 0;                                       // block-uniform
+  if (sorted) {
+    if (i < 64) rb_update_sorted_wave(v, op, upd_n, apply_pow, omega, s_top, n_cached);
+  } else {
+    rb_update_body<512, 256>(v, upd_idx, upd_val, upd_n, apply_pow, omega, lds_upd);
+  }
+  __threadfence_block();               // the tree this workgroup wrote, read back by the same workgroup (as in k_rebuild_top)
+  __syncthreads();
+  rb_sample_main<256>(v, batch, neg_beta_arg, neg_beta_ptr, unit_uniforms, max_attempts, seed, scaling, tree_idx_out, win, actions_out,
+                      returns_out, nonterminals_out, weights_out, fail_count, 1, s_flag, s_red, s_top, sorted);
 }
 
 // -------------------------------------------------------------- validation view --
@@ -993,6 +1072,37 @@ int rb_replay_update_leaves(rb_replay_t* r, const int64_t* tree_idx_dev, const f
 int rb_replay_update_priorities(rb_replay_t* r, const int64_t* tree_idx_dev, const float* losses_dev, int32_t n,
                                 rb_stream_t stream) {
   return rb_update_impl(r, tree_idx_dev, losses_dev, n, 1, stream);
+}
+
+int rb_replay_update_sample(rb_replay_t* r, const int64_t* upd_tree_idx_dev, const float* upd_losses_dev, int32_t upd_n,
+                            int32_t batch, double priority_weight, const double* unit_uniforms_dev, int32_t max_attempts,
+                            int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev, int64_t* actions_dev,
+                            float* returns_dev, float* nonterminals_dev, float* weights_dev, rb_stream_t stream) {
+  RB_REQUIRE(r && upd_tree_idx_dev && upd_losses_dev, "rb_replay_update_sample: NULL argument");
+  RB_REQUIRE(upd_n >= 1 && upd_n <= 1024, "rb_replay_update_sample: upd_n must be in [1,1024]");
+  // one launch for what a PER loop at the reference's batch sizes produces (a sorted write-back of at most 64 leaves rides on
+  // one wave); longer write-backs want the 1024-thread hashed kernel (batch 256: 34 us as two launches, 50 us fused)
+  if (upd_n > 64 || batch > 256) {
+    const int rc = rb_update_impl(r, upd_tree_idx_dev, upd_losses_dev, upd_n, 1, stream);
+    if (rc != RB_OK) return rc;
+    return sample_impl(r, batch, priority_weight, unit_uniforms_dev, max_attempts, tree_idx_dev, states_dev, next_states_dev,
+                       actions_dev, returns_dev, nonterminals_dev, weights_dev, nullptr, stream);
+  }
+  RB_REQUIRE(tree_idx_dev && actions_dev && returns_dev && nonterminals_dev && weights_dev, "rb_replay_update_sample: NULL argument");
+  RB_REQUIRE(batch >= 1, "rb_replay_update_sample: batch must be in [1,%d]", r->max_batch);
+  RB_REQUIRE(max_attempts >= 1, "rb_replay_update_sample: max_attempts must be >= 1");
+  RB_REQUIRE(r->capacity > (int64_t)r->history + r->n, "rb_replay_update_sample: capacity must exceed history + multi_step");
+  const ReplayView v = view_of(r);
+  const float neg_beta = (float)(-priority_weight);
+  RB_LAUNCH_T("sample:k_update_sample", k_update_sample, dim3(1), dim3(256), stream, v, upd_tree_idx_dev, upd_losses_dev, upd_n, 1, r->omega,
+              batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed, r->scaling_dev, tree_idx_dev, r->win, actions_dev,
+              returns_dev, nonterminals_dev, weights_dev, r->fail_host);
+  RB_LAUNCH_CHECK();
+  if (states_dev && next_states_dev) {
+    RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win, states_dev, next_states_dev);
+    RB_LAUNCH_CHECK();
+  }
+  return RB_OK;
 }
 
 int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_stream_t stream) {

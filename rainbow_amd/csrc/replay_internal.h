@@ -211,5 +211,107 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
 }
 
 
+// ---- the same update for a SORTED batch of at most 64 leaves, by ONE wave and without LDS: what ReplayMemory.sample hands to
+// update_priorities (stratified draws: sample i lies in stratum i of the cumulative priorities, so the leaf indices never
+// decrease, memory.py:125-130).  Sorted leaves stay sorted on every level, so the only place a path can meet another updated
+// path is its NEIGHBOUR among the lanes that are still alive: a left child looks at the next alive lane, a right child at the
+// previous one (two ballot-mask bit scans and four lane reads per level instead of a hashed LDS table with a workgroup
+// barrier per level).  Where two alive siblings meet, both form the same parent value and the left one retires.  Duplicate
+// leaves: the last lane of the run wins (memory.py:45) and the others retire before the walk.  All 64 lanes call.
+struct UpdateOperand { int node; float val; int status; int sorted; };
+// first loads of the sorted-batch update, all independent (one round trip): leaf index, value, the sampler's status word
+__device__ __forceinline__ UpdateOperand rb_update_load(const ReplayView& v, const int64_t* tree_idx, const float* values, int32_t n) {
+  const int lane = (int)(threadIdx.x & 63u);
+  UpdateOperand op;
+  op.status = v.hdr->last_status;
+  op.node = lane < n ? (int)tree_idx[lane] : -1;
+  op.val = lane < n ? values[lane] : 0.0f;
+  const int before = __shfl(op.node, lane > 0 ? lane - 1 : 0, 64);
+  op.sorted = __all(lane == 0 || lane >= n || op.node >= before) ? 1 : 0;
+  return op;
+}
+// s_top (optional): an LDS copy of the first n_top nodes of the tree that the caller staged BEFORE this update (the sampler's
+// search top, k_update_sample): every node written below n_top is written there as well.
+//
+// WHO meets WHOM on which level depends on the leaf indices alone, so it is worked out for all levels up front, off the
+// value chain: with a = leaf + 1 (heap numbering from 1) the ancestor lv levels up is (a >> lv) - 1, and lanes i, i + 1 become
+// siblings on level Lr_i = the highest bit in which a_i and a_(i+1) differ (equal leaves: -1, no right neighbour: never).
+// On level lv the lanes fall into groups of equal node — the boundaries are the lanes with Lr >= lv, one ballot — every
+// lane of a group carries the group's value, and a group's sibling, if it is in the batch at all, is the neighbouring
+// group: to the right for a left child (met iff the boundary lane r of my group has Lr_r == lv), to the left for a right
+// child.  What remains per level on the dependent chain is one lane read, one select, one add (a first version that looked
+// for its neighbour among the surviving lanes inside the chain ran ~0.25 us per level on this lone wave: 5 us for 20 levels).
+template <int MAXL>
+__device__ __forceinline__ void rb_update_sorted_levels(const ReplayView& v, unsigned a, float val, float vmax, const float (&sib)[RB_MAX_LEVELS],
+                                                        int Lr, bool active, int lane, float* s_top, int n_top) {
+  const int levels = v.levels;
+  float lvl_val[MAXL];
+  unsigned long long store_mask[MAXL];
+  unsigned long long bge = __ballot(Lr >= 0 ? 1 : 0);
+#pragma unroll
+  for (int lv = 0; lv < MAXL; ++lv) {
+    const unsigned long long beq = __ballot(Lr == lv ? 1 : 0);
+    const unsigned long long bge_up = __ballot(Lr >= lv + 1 ? 1 : 0);
+    const bool is_left = ((a >> lv) & 1u) == 0u;            // node (a >> lv) - 1 odd = left child (2p + 1)
+    const int r = lane + __builtin_ctzll((bge >> lane) | (1ull << (63 - lane)));          // last lane of my group
+    const unsigned long long below = bge & ((1ull << lane) - 1ull);
+    const int l = below ? 63 - __builtin_clzll(below) : 0;                                 // last lane of the group before mine
+    const bool met = is_left ? (((beq >> r) & 1ull) != 0ull) : (below != 0ull && ((beq >> l) & 1ull) != 0ull);
+    const int src = is_left ? (r < 63 ? r + 1 : r) : l;
+    const float other = __shfl(val, src, 64);
+    const float sv = met ? other : sib[lv];
+    val = is_left ? __fadd_rn(val, sv) : __fadd_rn(sv, val);                               // memory.py:25: left + right
+    lvl_val[lv] = val;
+    store_mask[lv] = bge_up;
+    bge = bge_up;
+  }
+  // one writer per node: the last lane of each group of the level written
+#pragma unroll
+  for (int lv = 0; lv < MAXL; ++lv) {
+    if (lv < levels) {                                      // wave-uniform
+      const int node = (int)(a >> (lv + 1)) - 1;
+      if (active && ((store_mask[lv] >> lane) & 1ull)) {
+        v.tree[node] = lvl_val[lv];
+        if (node < n_top) s_top[node] = lvl_val[lv];
+        if (lv + 1 == levels) {                             // the root: one lane (every pair has met by now)
+          v.hdr->max = fmaxf(vmax, v.hdr->max);             // memory.py:48
+          v.hdr->total = lvl_val[lv];
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void rb_update_sorted_wave(ReplayView v, const UpdateOperand& op, int32_t n, int32_t apply_pow, double omega,
+                                                      float* s_top, int n_top) {
+  const int lane = (int)(threadIdx.x & 63u);
+  if (apply_pow && op.status != 0) return;                 // (the draw was not a legal batch: see rb_update_body)
+  const bool active = lane < n;
+  const unsigned a = active ? (unsigned)op.node + 1u : 1u;
+  float sib[RB_MAX_LEVELS];
+#pragma unroll
+  for (int lv = 0; lv < RB_MAX_LEVELS; ++lv) {
+    const int q = (int)(a >> lv) - 1;
+    const int sb = (q & 1) ? q + 1 : q - 1;
+    sib[lv] = (active && lv < v.levels) ? v.tree[sb > 0 ? sb : 0] : 0.0f;
+  }
+  const unsigned a_next = __shfl(a, lane < 63 ? lane + 1 : lane, 64);
+  int Lr = 99;                                             // no right neighbour in the batch: never meets
+  if (active && lane + 1 < n) Lr = (a ^ a_next) ? 31 - __builtin_clz(a ^ a_next) : -1;
+  float val = op.val;
+  if (active && apply_pow) val = val > 0.0f ? (float)exp(omega * log((double)val)) : (float)pow((double)val, omega);   // memory.py:158
+  const float vmax = rb_wave_max(active ? val : -INFINITY);                                                              // memory.py:47
+  {                                                         // equal leaves: the last lane of the run wins (memory.py:45)
+    const unsigned long long b0 = __ballot(Lr >= 0 ? 1 : 0);
+    const int r0 = lane + __builtin_ctzll((b0 >> lane) | (1ull << (63 - lane)));
+    val = __shfl(val, r0, 64);
+    if (active && ((b0 >> lane) & 1ull)) {
+      v.tree[op.node] = val;
+      if (op.node < n_top) s_top[op.node] = val;
+    }
+  }
+  if (v.levels <= 20) rb_update_sorted_levels<20>(v, a, val, vmax, sib, Lr, active, lane, s_top, n_top);
+  else rb_update_sorted_levels<RB_MAX_LEVELS>(v, a, val, vmax, sib, Lr, active, lane, s_top, n_top);
+}
+
 // host side (replay.hip): kernel view + priority exponent of a handle
 int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega);

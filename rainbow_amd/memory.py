@@ -12,6 +12,7 @@ Two ways to consume a batch:
     what rainbow_amd.agent.Agent.learn uses.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -59,6 +60,32 @@ class ReplayMemory:
     # too small for the batch).  Then the batch gets zero importance weights (a zero-gradient step) and
     # failed_samples() counts it; Agent.learn raises on the next call.
     MAX_ATTEMPTS = 1024
+    # update_priorities() is LAZY (RAINBOW_AMD_LAZY_PRIORITIES=0: immediate): the write-back of learn step k and the draw of
+    # step k + 1 are a dependent pair of single-workgroup launches, so the call only records its operands and the next
+    # sample_device() issues both as ONE launch (rb_replay_update_sample: bit-identical tree, header and batch).  Anything
+    # else that reads or writes the tree — append, the header, state dumps, the raw handle `_h` — applies the pending
+    # write-back first.  numpy operands (the reference's call site, agent.py:100) are copied at the call; DEVICE tensors are
+    # read when the write-back runs: do not overwrite them before the next sample_device() / flush().
+    _pending = None
+    _handle = None
+    _lazy = os.environ.get("RAINBOW_AMD_LAZY_PRIORITIES", "1") != "0"
+
+    @property
+    def _h(self):
+        if self._pending is not None:
+            self.flush()
+        return self._handle
+
+    @_h.setter
+    def _h(self, value):
+        self._handle = value
+
+    def flush(self):
+        """Apply a pending update_priorities() now (a launch of its own)."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            L.check(self._lib, self._lib.rb_replay_update_priorities(self._handle, pend[0].data_ptr(), pend[1].data_ptr(),
+                                                                     int(pend[0].numel()), self._stream()))
 
     def __init__(self, args, capacity, seed=None):
         self.device = torch.device(args.device)
@@ -74,6 +101,8 @@ class ReplayMemory:
         self.priority_exponent = float(args.priority_exponent)
         self.t = 0                                              # episode timestep counter (memory.py:100)
         self._seed = int(seed if seed is not None else np.random.randint(0, 2 ** 31 - 1))
+        self._lazy = os.environ.get("RAINBOW_AMD_LAZY_PRIORITIES", "1") != "0"
+        self._pending = None
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib, self._lib.rb_replay_create(C.byref(self._h), self.capacity, self.history, self.n,
@@ -88,7 +117,7 @@ class ReplayMemory:
         # -beta lives in HBM so a captured hipGraph sees main.py:161's annealing (by-value kernel arguments freeze)
         self._neg_beta_dev = torch.full((1,), -float(self.priority_weight), dtype=torch.float32, device=self.device)
         self._neg_beta_val = float(self.priority_weight)
-        L.check(self._lib, self._lib.rb_replay_set_beta_source(self._h, self._neg_beta_dev.data_ptr()))
+        L.check(self._lib, self._lib.rb_replay_set_beta_source(self._handle, self._neg_beta_dev.data_ptr()))
 
     def _sync_beta(self):
         if float(self.priority_weight) != self._neg_beta_val:
@@ -98,9 +127,10 @@ class ReplayMemory:
     # ------------------------------------------------------------------ plumbing
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                self._lib.rb_replay_destroy(self._h)
-                self._h = None
+            self._pending = None
+            if getattr(self, "_handle", None):
+                self._lib.rb_replay_destroy(self._handle)
+                self._handle = None
         except Exception:
             pass
 
@@ -159,12 +189,12 @@ class ReplayMemory:
         """Sampler launches completed so far that found no valid batch within MAX_ATTEMPTS (read from pinned host memory
         the kernel writes: no synchronisation)."""
         n = C.c_int64(0)
-        L.check(self._lib, self._lib.rb_replay_failed_samples(self._h, C.byref(n)))
+        L.check(self._lib, self._lib.rb_replay_failed_samples(self._handle, C.byref(n)))
         return int(n.value)
 
     def reset_failed_samples(self):
         """Zero that counter (the failure has been reported to the caller)."""
-        L.check(self._lib, self._lib.rb_replay_reset_failed_samples(self._h))
+        L.check(self._lib, self._lib.rb_replay_reset_failed_samples(self._handle))
 
     def frame_source(self):
         """(frames_ptr, windows_ptr, window_len): lets the learner read frames straight from the ring (zero-copy)."""
@@ -197,11 +227,17 @@ class ReplayMemory:
             self._ptr_cache[key] = ptrs
         if stream is None:
             stream = self._stream()
+        pend = self._pending
         if noise_job is not None:
             rc = self._lib.rb_replay_sample_fused_noise(self._h, key[0], float(self.priority_weight), uu_ptr, attempts, *ptrs,
                                                         C.byref(noise_job), stream)
+        elif pend is not None:        # the pending write-back and this draw as one launch
+            self._pending = None
+            rc = self._lib.rb_replay_update_sample(self._handle, pend[0].data_ptr(), pend[1].data_ptr(), int(pend[0].numel()), key[0],
+                                                   float(self.priority_weight), uu_ptr, attempts, *ptrs, stream)
+            self._applied = pend      # (its operands stay alive until the launch after this one)
         else:
-            rc = self._lib.rb_replay_sample(self._h, key[0], float(self.priority_weight), uu_ptr, attempts, *ptrs, stream)
+            rc = self._lib.rb_replay_sample(self._handle, key[0], float(self.priority_weight), uu_ptr, attempts, *ptrs, stream)
         if rc != 0:
             L.check(self._lib, rc)
         return o
@@ -230,9 +266,14 @@ class ReplayMemory:
             idxs = torch.as_tensor(np.asarray(idxs, dtype=np.int64))
         if not torch.is_tensor(priorities):
             priorities = torch.as_tensor(np.asarray(priorities, dtype=np.float32))
+        if self._pending is not None:
+            self.flush()
         self._upd = (idxs.to(device=d, dtype=torch.int64).contiguous(),
                      priorities.to(device=d, dtype=torch.float32).contiguous())
-        L.check(self._lib, self._lib.rb_replay_update_priorities(self._h, self._upd[0].data_ptr(),
+        if self._lazy and not torch.cuda.is_current_stream_capturing():
+            self._pending = self._upd
+            return
+        L.check(self._lib, self._lib.rb_replay_update_priorities(self._handle, self._upd[0].data_ptr(),
                                                                  self._upd[1].data_ptr(), int(self._upd[0].numel()),
                                                                  self._stream()))
 
@@ -245,7 +286,7 @@ class ReplayMemory:
         if self.current_idx == self.capacity:
             raise StopIteration
         out = torch.empty(self.history, 84, 84, dtype=torch.float32, device=self.device)
-        L.check(self._lib, self._lib.rb_replay_state_at(self._h, int(self.current_idx), out.data_ptr(), self._stream()))
+        L.check(self._lib, self._lib.rb_replay_state_at(self._handle, int(self.current_idx), out.data_ptr(), self._stream()))
         self.current_idx += 1
         return out
 
@@ -260,7 +301,7 @@ class ReplayMemory:
             raise IndexError("states_at: index out of range")
         out = torch.empty(n, self.history, 84, 84, dtype=torch.float32, device=self.device)
         self._idx_keep = idx
-        L.check(self._lib, self._lib.rb_replay_states_at(self._h, idx.data_ptr(), n, out.data_ptr(), self._stream()))
+        L.check(self._lib, self._lib.rb_replay_states_at(self._handle, idx.data_ptr(), n, out.data_ptr(), self._stream()))
         return out
 
     # ------------------------------------------------------------------ streaming dump / restore
@@ -360,11 +401,12 @@ class ReplayMemory:
                     header=bytes(hdr))
 
     def __getstate__(self):
+        dump = self._dump()       # (applies a pending priority write-back first)
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("_lib", "_h", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev", "_neg_beta_val", "_bufs",
-                           "_idx_keep")}
+              if k not in ("_lib", "_h", "_handle", "_pending", "_applied", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev",
+                           "_neg_beta_val", "_bufs", "_idx_keep")}
         st["device"] = str(self.device)
-        st["_dump"] = self._dump()
+        st["_dump"] = dump
         return st
 
     def __setstate__(self, st):

@@ -130,6 +130,33 @@ class CAbiReplayAdapter:
                     nonterminals=m.download(nonterm)[:, None], weights=m.download(weights),
                     attempts=hdr.last_attempts)
 
+    def update_sample(self, upd_tree_idxs, upd_losses, batch, unit_uniforms, beta, check_status=True):
+        """rb_replay_update_sample: update_priorities(upd_*) + sample(batch) as one call (one launch up to 256 / 256)."""
+        m = self.mem
+        h = self.history
+        ti = m.upload(np.asarray(upd_tree_idxs, dtype=np.int64))
+        lo = m.upload(np.asarray(upd_losses, dtype=np.float32))
+        uu = m.upload(np.asarray(unit_uniforms, dtype=np.float64)) if unit_uniforms is not None else None
+        attempts = int(np.asarray(unit_uniforms).shape[0]) if unit_uniforms is not None else 16
+        tree_idx = m.empty((batch,), np.int64)
+        states = m.empty((batch, h, 84, 84), np.uint8)
+        next_states = m.empty((batch, h, 84, 84), np.uint8)
+        actions = m.empty((batch,), np.int64)
+        returns = m.empty((batch,), np.float32)
+        nonterm = m.empty((batch,), np.float32)
+        weights = m.empty((batch,), np.float32)
+        L.check(self.lib, self.lib.rb_replay_update_sample(self.h, m.ptr(ti), m.ptr(lo), len(upd_tree_idxs), batch, float(beta), m.ptr(uu),
+                                                           attempts, m.ptr(tree_idx), m.ptr(states), m.ptr(next_states), m.ptr(actions),
+                                                           m.ptr(returns), m.ptr(nonterm), m.ptr(weights), m.stream))
+        m.sync()
+        hdr = self.raw_header()
+        if check_status:
+            assert hdr.last_status == 0, "device sampler gave up after %d attempts" % hdr.last_attempts
+        return dict(tree_idxs=m.download(tree_idx), states=m.download(states), next_states=m.download(next_states),
+                    actions=m.download(actions), returns=m.download(returns),
+                    nonterminals=m.download(nonterm)[:, None], weights=m.download(weights),
+                    attempts=hdr.last_attempts)
+
     def update_priorities(self, tree_idxs, losses):
         m = self.mem
         ti = m.upload(np.asarray(tree_idxs, dtype=np.int64))

@@ -314,3 +314,58 @@ def sampler_gives_up_check(lib, mem):
     L.check(lib, lib.rb_replay_position(ad.h, C.byref(idx), C.byref(full)))
     assert (idx.value, full.value) == (0, 1)
     return ad
+
+
+def update_sample_twin_check(make_adapter, capacity=6000, history=4, n=3, rounds=6, seed=11):
+    """rb_replay_update_sample (update_priorities of step k + sample of step k + 1 as ONE launch) against the two calls on a twin
+    replay: tree, header and every output of the batch bit-identical, round after round (the one-launch sampler searches from
+    an LDS tree top that the update patched).  Batches: sorted (the sampler's own indices, the one-wave update), shuffled (the
+    hashed body inside the launch), 200 leaves (hashed), 300 leaves (the two-launch fallback of the entry point)."""
+    rs = np.random.RandomState(seed)
+    a, b = make_adapter(capacity, history, n), make_adapter(capacity, history, n)
+    total = capacity + capacity // 4
+    term = rs.random_sample(total) < 0.02
+    ts = np.zeros(total, dtype=np.int32)
+    t = 0
+    for i in range(total):
+        ts[i] = t
+        t = 0 if term[i] else t + 1
+    actions = rs.randint(0, 6, total).astype(np.int32)
+    rewards = rs.choice([-1.0, 0.0, 1.0], size=total).astype(np.float32)
+    pool = rs.randint(0, 256, size=(32, 84, 84)).astype(np.uint8)
+    step = min(2000, capacity // 2)
+    for lo in range(0, total, step):
+        hi = min(total, lo + step)
+        frames = pool[(np.arange(lo, hi) * 5) % 32]
+        for ad in (a, b):
+            ad.append_batch(frames, ts[lo:hi], actions[lo:hi], rewards[lo:hi], (~term[lo:hi]).astype(np.uint8))
+    tree_start = a.bufs.tree_start
+    spread = rs.randint(0, capacity, 1024) + tree_start
+    vals = (rs.random_sample(1024) * 4 + 1e-3).astype(np.float32)
+    for ad in (a, b):
+        ad.update_leaves(spread, vals)
+    B = 32
+    uu = rs.random_sample((16, B))
+    prev = a.sample(B, uu, 0.5)
+    assert np.array_equal(prev["tree_idxs"], b.sample(B, uu, 0.5)["tree_idxs"])
+    upd_idx = prev["tree_idxs"]
+    for r in range(rounds):
+        kind = ("sorted", "sorted", "shuffled", "many", "fallback", "sorted")[r % 6]
+        if kind == "shuffled":
+            upd_idx = upd_idx[rs.permutation(len(upd_idx))]
+        elif kind == "many":
+            upd_idx = np.sort(rs.randint(0, capacity, 200)) + tree_start
+        elif kind == "fallback":
+            upd_idx = rs.randint(0, capacity, 300) + tree_start
+        loss = (rs.random_sample(len(upd_idx)) * 2 + 1e-3).astype(np.float32)
+        uu = rs.random_sample((16, B))
+        a.update_priorities(upd_idx, loss)
+        want = a.sample(B, uu, 0.5)
+        got = b.update_sample(upd_idx, loss, B, uu, 0.5)
+        assert np.array_equal(a.tree(), b.tree()), (r, kind)
+        ha, hb = a.raw_header(), b.raw_header()
+        assert (ha.max, ha.total, ha.last_attempts, ha.last_status, ha.rng_counter) == (hb.max, hb.total, hb.last_attempts, hb.last_status, hb.rng_counter)
+        for k in want:
+            assert np.array_equal(np.asarray(want[k]), np.asarray(got[k])), (r, kind, k)
+        upd_idx = want["tree_idxs"]
+    a.close(); b.close()

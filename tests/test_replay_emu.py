@@ -78,6 +78,65 @@ def test_sampler_deep_tree_matches_oracle(emu, capacity):
     ad.close()
 
 
+@pytest.mark.parametrize("capacity", [64, 1000, 6000, 70000])
+def test_sorted_small_batch_update_matches_oracle(emu, capacity):
+    """k_update's one-wave path for SORTED batches of at most 64 leaves (what ReplayMemory.sample hands to update_priorities:
+    stratified draws never decrease) — replay_internal.h rb_update_sorted_wave — against SegmentTree.update (memory.py:44-48):
+    runs of duplicate leaves (last write wins), sibling pairs, clusters that merge a few levels up, one leaf, 64 leaves, the
+    first and the last leaf of the tree; then the same leaves shuffled (the hashed workgroup path) on a twin.  Tree, max and
+    total bit-exact after every call."""
+    from oracle.replay_oracle import ReplayOracle
+    rs = np.random.RandomState(capacity + 1)
+    ad = CAbiReplayAdapter(emu, NumpyMem(), capacity, 4, 3, 0.99, 0.5)
+    twin = CAbiReplayAdapter(emu, NumpyMem(), capacity, 4, 3, 0.99, 0.5)
+    ora, ora2 = ReplayOracle(capacity), ReplayOracle(capacity)
+    tree_start = ora.transitions.tree_start
+    every = np.arange(capacity) + tree_start
+    for lo in range(0, capacity, 1024):                    # a non-trivial tree first (update_leaves takes up to 1024)
+        idx = every[lo:lo + 1024]
+        vals = (rs.random_sample(len(idx)) * 3 + 1e-3).astype(np.float32)
+        for a in (ad, twin):
+            a.update_leaves(idx, vals)
+        for o in (ora, ora2):
+            o.transitions.set_leaves(idx, vals)
+    assert np.array_equal(ad.tree(), ora.transitions.tree)
+    cases = [np.array([0]), np.array([capacity - 1]), np.array([0, 1]), np.array([0, capacity - 1]),
+             np.array([5, 5, 5, 6, 6, 7]) % capacity, np.arange(64) % capacity, np.full(64, capacity // 2)]
+    for n in (1, 2, 7, 32, 33, 64):
+        cases.append(np.sort(rs.randint(0, capacity, n)))                                   # spread out
+        c0 = int(rs.randint(0, capacity))
+        cases.append(np.sort((c0 + rs.randint(0, min(capacity, 2 * n), n)) % capacity))     # clustered: paths meet early
+    unsorted_calls = 0
+    for data_idx in cases:
+        idx = np.sort(np.asarray(data_idx, dtype=np.int64)) + tree_start
+        vals = (rs.random_sample(len(idx)) * 5 + 1e-3).astype(np.float32)
+        ad.update_leaves(idx, vals)
+        ora.transitions.set_leaves(idx, vals)
+        assert np.array_equal(ad.tree(), ora.transitions.tree), data_idx
+        hdr = ad.raw_header()
+        assert hdr.max == ora.transitions.max and hdr.total == ora.transitions.total()
+        # the same leaves in another order: the hashed workgroup path (and another winner among duplicates)
+        perm = rs.permutation(len(idx))
+        unsorted_calls += int(not np.all(np.diff(idx[perm]) >= 0))
+        twin.update_leaves(idx[perm], vals[perm])
+        ora2.transitions.set_leaves(idx[perm], vals[perm])
+        assert np.array_equal(twin.tree(), ora2.transitions.tree), data_idx
+    assert unsorted_calls >= 8
+    # priorities (loss ** omega) through the sorted path
+    idx = np.sort(rs.randint(0, capacity, 32)) + tree_start
+    loss = (rs.random_sample(32) + 1e-2).astype(np.float32)
+    ad.update_priorities(idx, loss)
+    ora.update_priorities(idx, loss)
+    np.testing.assert_allclose(ad.tree(), ora.transitions.tree, rtol=4 * 2.0 ** -23)
+    ad.close(); twin.close()
+
+
+@pytest.mark.parametrize("capacity,n", [(6000, 3), (2000, 20)])
+def test_update_and_sample_in_one_launch_equals_the_two_calls(emu, capacity, n):
+    """k_update_sample (replay.hip) against rb_replay_update_priorities + rb_replay_sample on a twin (scenarios.py)."""
+    scenarios.update_sample_twin_check(lambda c, h, nn: CAbiReplayAdapter(emu, NumpyMem(), c, h, nn, 0.99, 0.5), capacity=capacity, n=n)
+
+
 def test_create_rejects_what_the_reference_cannot_run(emu):
     """Odd capacities crash the reference's sum-tree walk (IndexError in _propagate_index) and a window
     longer than 64 slots does not fit the sampler's masks: both are refused with an error code and a message."""

@@ -55,6 +55,75 @@ def _fill(mem, oracle, count, seed, p_term=0.02):
             oracle.append(st, a, r, term)
 
 
+@pytest.mark.parametrize("capacity,n", [(6000, 3), (100000, 20)])
+def test_update_and_sample_in_one_launch_equals_the_two_calls_on_device(hip, capacity, n):
+    """k_update_sample on hardware: tree, header and batch bit-identical to rb_replay_update_priorities + rb_replay_sample on a
+    twin replay, six rounds (sorted / shuffled / 200 / 300 leaves) — the same scenario the host interpreter runs."""
+    from cabi_adapter import CAbiReplayAdapter, TorchMem
+    scenarios.update_sample_twin_check(lambda c, h, nn: CAbiReplayAdapter(hip, TorchMem(), c, h, nn, 0.99, 0.5), capacity=capacity, n=n)
+
+
+def test_lazy_update_priorities_equals_immediate(hip, monkeypatch):
+    """ReplayMemory.update_priorities is lazy (the next sample_device issues write-back + draw as ONE launch); everything that
+    looks at the tree in between applies it first.  Twin memories — one lazy, one with RAINBOW_AMD_LAZY_PRIORITIES=0 — through
+    sample / update / append / header / find / a numpy-operand update: batches, trees and headers bit-identical throughout."""
+    from rainbow_amd import _lib as L
+    from rainbow_amd.memory import ReplayMemory
+    monkeypatch.setenv("RAINBOW_AMD_LAZY_PRIORITIES", "0")
+    eager = ReplayMemory(_args(), 4096, seed=3)
+    monkeypatch.setenv("RAINBOW_AMD_LAZY_PRIORITIES", "1")
+    lazy = ReplayMemory(_args(), 4096, seed=3)
+    assert lazy._lazy and not eager._lazy
+    for m in (eager, lazy):
+        _fill(m, None, 4500, seed=5)
+    rs = np.random.RandomState(9)
+
+    def tree_of(m):
+        return m._grab("tree")
+
+    def same():
+        he, hl = eager._header(), lazy._header()
+        assert (he.index, he.full, he.max, he.total, he.last_attempts, he.last_status) == (hl.index, hl.full, hl.max, hl.total, hl.last_attempts, hl.last_status)
+        assert np.array_equal(tree_of(eager), tree_of(lazy))
+
+    B = 32
+    for r in range(8):
+        uu = torch.from_numpy(rs.random_sample((8, B))).cuda()
+        oe, ol = eager.sample_device(B, unit_uniforms=uu), lazy.sample_device(B, unit_uniforms=uu)
+        assert lazy._pending is None
+        for k in oe:
+            assert torch.equal(oe[k], ol[k]), (r, k)
+        loss = torch.from_numpy((rs.random_sample(B) + 1e-2).astype(np.float32)).cuda()
+        if r % 4 == 3:         # the reference's call site: numpy operands (agent.py:100)
+            eager.update_priorities(oe["tree_idxs"].cpu().numpy(), loss.cpu().numpy())
+            lazy.update_priorities(ol["tree_idxs"].cpu().numpy(), loss.cpu().numpy())
+        else:
+            eager.update_priorities(oe["tree_idxs"], loss)
+            lazy.update_priorities(ol["tree_idxs"], loss)
+        assert lazy._pending is not None and eager._pending is None
+        if r == 1:             # an append in between applies the pending write-back first (it rewrites leaves and ancestors)
+            for m in (eager, lazy):
+                _fill(m, None, 3, seed=100 + r)
+            assert lazy._pending is None
+        elif r == 2:           # so does the header
+            same()
+            assert lazy._pending is None
+        elif r == 4:           # ... and the raw handle (external C callers)
+            v = torch.from_numpy(rs.random_sample(64) * lazy.transitions.total()).cuda()
+            outs = []
+            for m in (eager, lazy):
+                p, di, ti = (torch.empty(64, dtype=torch.float32, device="cuda"), torch.empty(64, dtype=torch.int64, device="cuda"),
+                             torch.empty(64, dtype=torch.int64, device="cuda"))
+                L.check(hip, hip.rb_replay_find(m._h, v.data_ptr(), 64, p.data_ptr(), di.data_ptr(), ti.data_ptr(), m._stream()))
+                outs.append((p, ti))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        elif r == 5:           # two updates in a row: the first is applied before the second is recorded
+            loss2 = loss * 0.5 + 0.1
+            eager.update_priorities(oe["tree_idxs"], loss2)
+            lazy.update_priorities(ol["tree_idxs"], loss2)
+    same()
+
+
 def test_python_class_sample_tuple_matches_oracle(hip):
     """ReplayMemory.sample() keeps the reference's 7-tuple contract."""
     from rainbow_amd.memory import ReplayMemory

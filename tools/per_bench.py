@@ -23,6 +23,7 @@ def loop(n, gather=True, update=True):
     for _ in range(n):
         o = mem.sample_device(B, gather=gather)
         if update: mem.update_priorities(o["tree_idxs"], loss)
+    mem.flush()
     t1 = time.perf_counter()
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
