@@ -25,10 +25,14 @@ def tag_of(name, grid, biggest):
     """bench.py tag of a kernel instance; the hidden layer's launches are the larger grid of k_nl_fwd2 / k_nl_bwd."""
     if "k_clip_adam" in name:
         return "clip_adam"
+    if "k_fc_gemm_fwd" in name:            # the hidden layer as tiled GEMMs (fc_gemm.h, from 128 rows per net on)
+        return "fc_h_fwd"
+    if "k_fc_gemm_bwd" in name:
+        return "fc_h_bwd"
     if "k_nl_fwd" in name:
-        return "fc_h_fwd" if grid == biggest["k_nl_fwd"] else "fc_z_fwd"
+        return "fc_h_fwd" if grid == biggest["k_nl_fwd"] and not biggest.get("gemm") else "fc_z_fwd"
     if "k_nl_bwd" in name:
-        return "fc_h_bwd" if grid == biggest["k_nl_bwd"] else "fc_z_bwd"
+        return "fc_h_bwd" if grid == biggest["k_nl_bwd"] and not biggest.get("gemm") else "fc_z_bwd"
     if "k_conv_dw_all" in name:
         return "conv_dw_all"
     if "k_sample" in name:
@@ -52,6 +56,8 @@ def main():
         for k in ("k_nl_fwd", "k_nl_bwd"):
             if k in name:
                 biggest[k] = max(biggest.get(k, 0), grid)
+        if "k_fc_gemm" in name:
+            biggest["gemm"] = 1
     res = {}
     for key in sorted(fetch):
         tag = tag_of(key[0], key[1], biggest)
