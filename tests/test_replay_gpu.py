@@ -319,6 +319,60 @@ def test_sampler_indices_match_oracle_at_1m(hip, full_mem):
     _check_sampler_against_oracle(hip, mem, (32, 256), seed=77)
 
 
+def test_per_loop_at_1m_keeps_the_tree_exact(hip, full_mem):
+    """The PER-only loop of BASELINE's second metric on the 1M replay, as the bench runs it (device RNG, lazy write-backs: every
+    update_priorities rides in the next sampler launch — k_update_sample on the 20-level tree, its one-wave sorted update and
+    the LDS tree top it patches), with appends in between (they apply the pending write-back first): afterwards EVERY internal
+    node is fl32(left + right) of its children, the leaves are what a numpy replay of the same write-backs holds (last write
+    wins), and header.max / total agree.  Runs last among the full-size tests (it moves the write head)."""
+    mem, _ = full_mem
+    cap = mem.capacity
+    levels, tree_start, tree_len = tree_geometry(cap)
+    leaves = mem._grab("tree")[tree_start:].copy()
+    vmax = float(mem._header().max)
+    g = torch.Generator(device="cuda").manual_seed(123)
+    rs = np.random.RandomState(5)
+    B = 32
+    pending = None
+    for it in range(300):
+        o = mem.sample_device(B)                       # applies the previous round's write-back in the same launch
+        if pending is not None:
+            idx, pr = pending
+            for j in range(B):                          # memory.py:45,158: p = loss ** 0.5, last write wins
+                leaves[idx[j] - tree_start] = pr[j]
+            vmax = max(vmax, float(pr.max()))
+        loss = torch.rand(B, device="cuda", generator=g) * 2 + 1e-3
+        idx = o["tree_idxs"].cpu().numpy()
+        assert np.all(np.diff(idx) >= 0), "a stratified draw never decreases"
+        mem.update_priorities(o["tree_idxs"], loss)
+        assert mem._pending is not None
+        pending = (idx, np.power(loss.cpu().numpy(), np.float32(0.5)))
+        if it % 25 == 24:                               # an append in between: the pending write-back goes first
+            fr = torch.randint(0, 256, (7, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+            idx0 = mem.transitions.index
+            mem.append_batch(fr, rs.randint(0, 6, 7), np.zeros(7), np.zeros(7, dtype=bool))
+            assert mem._pending is None
+            for j in range(B):
+                leaves[idx[j] - tree_start] = pending[1][j]
+            vmax = max(vmax, float(pending[1].max()))
+            pending = None
+            for k in range(7):                          # memory.py:52-61: new transitions enter with the running maximum
+                leaves[(idx0 + k) % cap] = np.float32(vmax)
+    mem.flush()
+    if pending is not None:
+        for j in range(B):
+            leaves[pending[0][j] - tree_start] = pending[1][j]
+        vmax = max(vmax, float(pending[1].max()))
+    tree = mem._grab("tree")
+    np.testing.assert_allclose(tree[tree_start:], leaves, rtol=F32_ULP_RTOL)      # (loss ** 0.5: 1 ulp, helpers.py)
+    internal = np.arange(0, tree_start)
+    p = internal[2 * internal + 2 < tree_len]
+    assert np.array_equal(tree[p], tree[2 * p + 1] + tree[2 * p + 2])
+    hdr = mem._header()
+    assert hdr.total == tree[0] and hdr.last_status == 0
+    np.testing.assert_allclose(hdr.max, vmax, rtol=F32_ULP_RTOL)
+
+
 def test_sampler_indices_match_oracle_at_100k_nstep20(hip):
     """BASELINE config 4's replay: C = 100k (tree depth 17: one 5-level trip + one 1-level trip), n = 20 windows."""
     from rainbow_amd.memory import ReplayMemory
