@@ -149,7 +149,7 @@ def declare(lib, strict=True):
     return lib
 
 
-LEARNER_FUSE_FC_H_DW, LEARNER_WRITE_FUSED_GRADS, LEARNER_DEFER_UPDATE = 1, 2, 4
+LEARNER_FUSE_FC_H_DW, LEARNER_WRITE_FUSED_GRADS, LEARNER_DEFER_UPDATE, LEARNER_IMPLICIT_SIGMA = 1, 2, 4, 8
 
 
 class RainbowError(RuntimeError):

@@ -166,6 +166,7 @@ struct rb_learner {
   int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_img_fast;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
+  int opt_implicit_small;
   int opt_fc_gemm;      // hidden layer on the LDS-tiled GEMMs of fc_gemm.h: -1 = from 128 rows per net on (default), 1 = always, 0 = never
   float* gemm_part;     // split-K partial tiles of k_fc_gemm_fwd: one 64 KB tile per workgroup slot (n_cu of them)
   unsigned* gemm_ctr;   // its per-tile arrival counters (self-resetting)
@@ -218,6 +219,11 @@ struct rb_learner {
   ClipAdamArgs* adam_args_dev;   // the pending pass's arguments in device memory (rewritten only when they change)
   ClipAdamArgs adam_args_host;   // ... and what that memory holds
   int adam_args_valid, adam_pending, adam_blocks;
+  // RB_LEARNER_IMPLICIT_SIGMA: the hidden layer's sigma-weight gradient is not stored by the backward; the hosted optimiser
+  // pass forms it from g_mu and the noise the backward used (adam_body.h rb_adam_hosted_pairs).  sigma_implicit = the flat
+  // gradient lacks that range right now; every other consumer of the gradient materialises it first (materialize_sigma)
+  int sigma_implicit;
+  float* noise_snap;        // [n_noise] the online noise of the learn call in flight, copied by its last backward launch
   int32_t* status_copy;     // this learn call's batch_status, copied by its head kernel: the hosted pass shares a launch with
                             // the NEXT call's sampler, which overwrites the replay header's word
   float gamma_n;        // float32(discount ** n)        agent.py:79
@@ -313,6 +319,12 @@ struct ReduceAllArgs {
   // the conv segment of this rank's exchange block
   const float* grads_base;
   float* copy_base;
+  // tenant blocks behind the reduction's own: copy snap_n floats (the learn call's online noise, for the optimiser pass that
+  // forms the hidden layer's sigma gradient itself: the launch hosting that pass resamples the noise)
+  const float* snap_src;
+  float* snap_dst;
+  int snap_n;
+  int32_t* snap_clear;      // ... and clear this word (ClipAdamArgs::pair_clipped: no scaled gradient has been stored for this step yet)
 };
 template <int N>
 __device__ __forceinline__ float rb_sum_slices(const float* part, int64_t per, int64_t j, int slices) {
@@ -326,6 +338,12 @@ __device__ __forceinline__ float rb_sum_slices(const float* part, int64_t per, i
 }
 __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((a.total + 63) / 64) * 64) {                  // block-uniform: a snapshot tenant
+    const int64_t j = i - ((a.total + 63) / 64) * 64;
+    if (j < a.snap_n) a.snap_dst[j] = a.snap_src[j];
+    if (j == 0 && a.snap_clear) *a.snap_clear = 0;
+    return;
+  }
   float my = 0.0f;
   if (i < a.total) {
   int li = 0;
@@ -760,7 +778,10 @@ __device__ __forceinline__ void rb_fused_dw_adam_tile(const ClipAdamArgs& a, con
 #endif
 template <int RB_ADAM_UNROLL, bool WT, bool FUSED>   // float4 quadruples (p, g, m, v) in flight per thread; WT: write-through stores
 __global__ __launch_bounds__(256, RB_ADAM_MINWAVES) void k_clip_adam(ClipAdamArgs a, FusedDwAdamArgs f) {
-  __shared__ float s_red[16];
+  __shared__ float s_red[18];      // [0, 16) rb_block_sum's wave slots; [16], [17] the bias-correction scalars (slots of their own:
+                                   // thread 0 writes them while other waves may still be reading the wave slots of the sum —
+                                   // the host interpreter's schedule turned that into a wrong clip coefficient for every thread
+                                   // but thread 0 whenever the clip bit and the step number came from the device counter)
   const bool tile_block = FUSED && (int)blockIdx.x < f.n_tile_blocks;
   const int64_t n4 = (a.n >> 2) - (FUSED ? a.skip_len4 : 0);
   const int eb = FUSED ? (int)blockIdx.x - f.n_tile_blocks : (int)blockIdx.x;
@@ -792,12 +813,12 @@ __global__ __launch_bounds__(256, RB_ADAM_MINWAVES) void k_clip_adam(ClipAdamArg
     if (threadIdx.x == 0) {
       const double t = (double)*a.step_dev;
       const double bc1 = 1.0 - pow(a.beta1, t), bc2 = 1.0 - pow(a.beta2, t);
-      s_red[0] = (float)(-(a.lr / bc1));
-      s_red[1] = (float)sqrt(bc2);
+      s_red[16] = (float)(-(a.lr / bc1));
+      s_red[17] = (float)sqrt(bc2);
     }
     __syncthreads();
-    a.neg_step_size = s_red[0];
-    a.bc2_sqrt = s_red[1];
+    a.neg_step_size = s_red[16];
+    a.bc2_sqrt = s_red[17];
   }
   if (tile_block) {
     rb_fused_dw_adam_tile<WT>(a, f, (int)blockIdx.x, coef);
@@ -1290,7 +1311,7 @@ int rb_learner_destroy(rb_learner_t* l) {
   float** owned[] = {&l->feat_b, &l->h_b, &l->act[0], &l->act[1], &l->act[2], &l->dact[0], &l->dact[1], &l->dact[2], &l->hpart, &l->h,
                      &l->logits, &l->dlogits, &l->dlogitsT, &l->dh, &l->dhT, &l->dfeat_part, &l->dw_part[0], &l->dw_part[1], &l->dw_part[2],
                      &l->conv_wT[0], &l->conv_wT[1], &l->conv_wT[2],
-                     &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part, &l->gemm_part};
+                     &l->log_ps_a, &l->pns_a, &l->m, &l->support, &l->zero_noise, &l->norm_part, &l->gemm_part, &l->noise_snap};
   for (float** p : owned)
     if (*p) rb_dev_free(*p);
   if (l->a_star) rb_dev_free(l->a_star);
@@ -1342,6 +1363,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_t16 = rb_opt("t16", 7);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
+  l->opt_implicit_small = rb_opt("implicit_small", 0);   // test hook: RB_LEARNER_IMPLICIT_SIGMA on hidden layers of any size
   l->opt_fc_gemm = rb_opt("fc_gemm", -1);             // hidden layer as LDS-tiled GEMMs (fc_gemm.h): -1 = from 128 rows on
   if (l->fast_fc) {
     l->hs = pick_splits(2 * rb_div_up(L.H, 32) * 2 * rb_div_up(2 * B, 64), L.F / 16 / RB_NL_FWD_WAVES, 512);
@@ -1403,6 +1425,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_ALLOC(l->a_star, (int64_t)B);
   RB_ALLOC(l->support, (int64_t)L.Z);
   RB_ALLOC(l->zero_noise, L.n_noise);
+  RB_ALLOC(l->noise_snap, L.n_noise);
   RB_ALLOC(l->norm_part, 16384);
   RB_ALLOC(l->noise_ctr, 4);
   RB_ALLOC(l->status_copy, 4);
@@ -1658,7 +1681,7 @@ static FcDwPlan fc_dw_plan(rb_learner* l, const NetPtrs& on, int which, const fl
   NlDwArgs& w = p.a;
   memset(&w, 0, sizeof(w));
   w.dy = dy; w.x = x; w.M = M; w.n_prob = 2; w.ct = ct; w.rpb = 0; w.bstride = 0; w.scale = 1.0f; w.sq_part = nullptr;
-  w.noise_blocks = nullptr; w.eout_noff = 0; w.ein_noff = 0; w.norm_only = 0;
+  w.noise_blocks = nullptr; w.eout_noff = 0; w.ein_noff = 0; w.norm_only = 0; w.no_sigma = 0;
   if (which == 0) {
     const int vt = (int)rb_div_up(L.Z, 16), at = (int)rb_div_up(L.NZ - L.Z, 16);
     w.ldy = L.NZ; w.ldx = 2 * L.H; w.K = L.H;
@@ -1777,6 +1800,14 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const bool defer_dw = (l->flags & RB_LEARNER_FUSE_FC_H_DW) && pipe && h_ct > 0 && fuse_norm && l->fast_conv;
     hw_.norm_only = defer_dw ? 1 : 0;
     l->dw_deferred = defer_dw ? 1 : 0;
+    // RB_LEARNER_IMPLICIT_SIGMA: g_sigma = g_mu * (eps_out x eps_in) is left to the optimiser pass (its square still enters
+    // the norm here).  Needs the pipelined weight-gradient body (batch <= 32), the fused norm and adjacent mu | sigma arrays
+    const bool implicit_sigma = (l->flags & RB_LEARNER_IMPLICIT_SIGMA) && pipe && h_ct > 0 && fuse_norm && !defer_dw &&
+                                L.h_sigma == L.h_mu + (int64_t)2 * L.H * L.F && (L.F % 4) == 0 && (L.h_mu % 4) == 0 &&
+                                ((int64_t)2 * L.H * L.F >= ((int64_t)1 << 20) || l->opt_implicit_small);   // (the data-efficient
+                                // net's 0.3 M-element layer: +0.8 us per step with the pairing — it pays from megabytes on)
+    hw_.no_sigma = implicit_sigma ? 1 : 0;
+    l->sigma_implicit = implicit_sigma ? 1 : 0;
     zw.sq_part = fuse_norm ? l->norm_part : nullptr;
     hw_.sq_part = fuse_norm ? l->norm_part + zp.slots : nullptr;
     l->norm_slots = fuse_norm ? zp.slots + hp.slots + c_slots : 0;
@@ -1919,7 +1950,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     ra.sq_part = l->norm_slots > 0 ? l->norm_part + l->norm_conv_base : nullptr;
     ra.grads_base = l->grads;
     ra.copy_base = exch ? l->fact_local + l->fact_off[5] : nullptr;
-    RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(off, 64)), dim3(64), stream, ra);
+    ra.snap_src = nullptr; ra.snap_dst = nullptr; ra.snap_n = 0; ra.snap_clear = nullptr;
+    if (l->sigma_implicit) { ra.snap_src = l->n_online; ra.snap_dst = l->noise_snap; ra.snap_n = (int)L.n_noise; ra.snap_clear = l->status_copy + 2; }
+    RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)(rb_div_up(off, 64) + rb_div_up(ra.snap_n, 64))), dim3(64), stream, ra);
     RB_LAUNCH_CHECK();
   }
   return RB_OK;
@@ -1930,11 +1963,51 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
 
 // The pending optimiser pass (RB_LEARNER_DEFER_UPDATE) as a launch of its own: every entry point that reads or writes
 // parameters, moments, gradients or the norm calls this first — only the next rb_learner_train_step hosts it instead.
+// g_sigma = g_mu * (eps_out[n] * eps_in[k]) for the hidden layer, from the noise snapshot of the learn call that produced g_mu:
+// what RB_LEARNER_IMPLICIT_SIGMA's backward left out, for every consumer of the flat gradient other than the hosted pass
+__global__ __launch_bounds__(256) void k_materialize_sigma(float* g, int64_t mu4, int64_t len4, int f4, int split_row,
+                                                            const float* eout, const float* ein, const int32_t* clipped) {
+  if (*clipped != 0) return;          // the optimiser pass has stored the scaled gradients already (block-uniform)
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len4; j += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(j / f4), cq = (int)(j - (int64_t)row * f4);
+    const float eo = eout[row];
+    const float4 e = rb_ld4(ein + 4 * (int64_t)(cq + (row >= split_row ? f4 : 0)));
+    const float4 gm = rb_ld4(g + 4 * (mu4 + j));
+    float4 gs;
+    gs.x = gm.x * (eo * e.x); gs.y = gm.y * (eo * e.y); gs.z = gm.z * (eo * e.z); gs.w = gm.w * (eo * e.w);
+    rb_st4(g + 4 * (mu4 + len4 + j), gs);
+  }
+}
+static int materialize_sigma(rb_learner* l, hipStream_t stream) {
+  if (!l->sigma_implicit) return RB_OK;
+  const Layout& L = l->L;
+  const NetPtrs sn = net_ptrs(L, l->p_online, l->noise_snap);
+  const int64_t len4 = (int64_t)2 * L.H * L.F / 4;
+  RB_LAUNCH(k_materialize_sigma, dim3((unsigned)rb_div_up(len4, 256 * 4)), dim3(256), stream, l->grads, L.h_mu / 4, len4, L.F / 4, L.H,
+            sn.h_eout, sn.h_ein, (const int32_t*)(l->status_copy + 2));
+  RB_LAUNCH_CHECK();
+  l->sigma_implicit = 0;
+  return RB_OK;
+}
+#define RB_MATERIALIZE_SIGMA(l, stream)                             \
+  do {                                                              \
+    const int rcm_ = materialize_sigma((l), (hipStream_t)(stream)); \
+    if (rcm_ != RB_OK) return rcm_;                                 \
+  } while (0)
+
 static int flush_update(rb_learner* l, hipStream_t stream) {
   if (!l->adam_pending) return RB_OK;
   FusedDwAdamArgs f;
   memset(&f, 0, sizeof(f));
-  RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3((unsigned)l->adam_blocks), dim3(256), stream, l->adam_args_host, f);
+  ClipAdamArgs a = l->adam_args_host;
+  int blocks = l->adam_blocks;
+  if (a.pair_len4 > 0) {        // the pending pass forms the sigma gradient itself: the hosted body as a launch of its own
+    const int rc = rb_launch_adam_pending(l->adam_args_dev, blocks, stream);      // (its arguments are in device memory already)
+    if (rc != RB_OK) return rc;
+    l->adam_pending = 0;
+    return RB_OK;
+  }
+  RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3((unsigned)blocks), dim3(256), stream, a, f);
   RB_LAUNCH_CHECK();
   l->adam_pending = 0;
   return RB_OK;
@@ -1942,7 +2015,9 @@ static int flush_update(rb_learner* l, hipStream_t stream) {
 
 int rb_learner_flush(rb_learner_t* l, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_flush: NULL handle");
-  return flush_update(l, (hipStream_t)stream);
+  const int rc = flush_update(l, (hipStream_t)stream);
+  if (rc != RB_OK) return rc;
+  return materialize_sigma(l, (hipStream_t)stream);      // (a caller about to read grads_dev: RB_LEARNER_IMPLICIT_SIGMA)
 }
 
 // The same hosting for a caller that issues the step's entry points one by one (Agent's eager path, the replica exchange):
@@ -2017,6 +2092,7 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
 int rb_learner_clip_grad(rb_learner_t* l, float max_norm, float* norm_dev, rb_stream_t stream) {
   RB_REQUIRE(l != nullptr, "rb_learner_clip_grad: NULL handle");
   RB_FLUSH_UPDATE(l, stream);
+  RB_MATERIALIZE_SIGMA(l, stream);
   if (l->dw_deferred) {
     rb_set_error("rb_learner_clip_grad: the last learn call left the hidden layer's weight gradient to the fused optimiser "
                  "pass (RB_LEARNER_FUSE_FC_H_DW); call rb_learner_clip_adam, or clear the flag before learning");
@@ -2100,8 +2176,23 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
     RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, true>), dim3(grid), dim3(256), stream, a, f);
     l->dw_deferred = 0;
   } else {
-    const unsigned grid = (unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4);
-    if (defer && a.step_dev != nullptr && a.nparts > 0 && l->adam_args_dev != nullptr) {
+    unsigned grid = (unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4);
+    const bool will_defer = defer && a.step_dev != nullptr && a.nparts > 0 && l->adam_args_dev != nullptr;
+    if (l->sigma_implicit && will_defer) {
+      // the hosted pass updates (mu, sigma) quads of the hidden layer together and forms g_sigma itself (adam_body.h)
+      const Layout& L = l->L;
+      const NetPtrs sn = net_ptrs(L, l->p_online, l->noise_snap);
+      a.pair_mu4 = L.h_mu / 4; a.pair_len4 = (int64_t)2 * L.H * L.F / 4;
+      a.pair_f4 = L.F / 4; a.pair_split_row = L.H; a.pair_eout = sn.h_eout; a.pair_ein = sn.h_ein;
+      a.pair_clipped = l->status_copy + 2;
+      a.hole_lo4 = (unsigned)a.pair_mu4; a.hole4 = (unsigned)(2 * a.pair_len4);
+      a.pair_blk0 = (int)rb_div_up(n4 - 2 * a.pair_len4 > 0 ? n4 - 2 * a.pair_len4 : 1, 256 * 4);
+      grid = (unsigned)(a.pair_blk0 + rb_div_up(a.pair_len4, 256 * 2));   /* adam_body.h rb_adam_hosted_pairs: 2 pairs per thread */
+    } else if (l->sigma_implicit) {
+      const int rcm = materialize_sigma(l, stream);
+      if (rcm != RB_OK) return rcm;
+    }
+    if (will_defer) {
       // left pending: the next train_step's sampler launch hosts these workgroups (or flush_update launches them).  The
       // arguments are all step-invariant (the step number and the norm partials live on the device): uploaded on change only
       if (!l->adam_args_valid || memcmp(&a, &l->adam_args_host, sizeof(a)) != 0) {
@@ -2128,7 +2219,7 @@ int rb_learner_set_step_counter(rb_learner_t* l, int64_t* step_dev) {
 
 int rb_learner_set_flags(rb_learner_t* l, int32_t flags) {
   RB_REQUIRE(l != nullptr, "rb_learner_set_flags: NULL handle");
-  RB_REQUIRE((flags & ~(RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS | RB_LEARNER_DEFER_UPDATE)) == 0,
+  RB_REQUIRE((flags & ~(RB_LEARNER_FUSE_FC_H_DW | RB_LEARNER_WRITE_FUSED_GRADS | RB_LEARNER_DEFER_UPDATE | RB_LEARNER_IMPLICIT_SIGMA)) == 0,
              "rb_learner_set_flags: unknown flag bits");
   l->flags = flags;
   return RB_OK;
@@ -2353,6 +2444,11 @@ int rb_learner_grads_modified(rb_learner_t* l) {
   RB_REQUIRE(l != nullptr, "rb_learner_grads_modified: NULL handle");
   if (l->dw_deferred) {
     rb_set_error("rb_learner_grads_modified: the hidden layer's weight gradient was not materialised (RB_LEARNER_FUSE_FC_H_DW)");
+    return RB_ERR_STATE;
+  }
+  if (l->sigma_implicit) {
+    rb_set_error("rb_learner_grads_modified: the hidden layer's sigma gradient was not materialised (RB_LEARNER_IMPLICIT_SIGMA): "
+                 "call rb_learner_flush before reading or modifying grads_dev");
     return RB_ERR_STATE;
   }
   l->norm_slots = 0;

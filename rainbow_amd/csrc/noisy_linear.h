@@ -537,6 +537,8 @@ struct NlDwArgs {
                              // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
   int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave;
                              // < 0: the LDS-shared 64 x 64 tile body for large M (rb_nl_dw_body_wide)
+  int no_sigma;              // 1: g_sigma is formed for the sum of squares only and NOT stored (the hosted optimiser pass forms it
+                             // again from g_mu and the same noise, adam_body.h; pipelined body only)
   int norm_only;             // 1: the weight-gradient tiles are computed for their sum of squares only and NOT stored (the
                              // optimiser pass recomputes each tile while it streams the parameters, k_clip_adam<FUSED>);
                              // the bias gradients are still written
@@ -827,7 +829,7 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
           gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
           if (!a.norm_only) {                            // wave-uniform
             rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
-            rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+            if (!a.no_sigma) rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
           }
           sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
           sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);

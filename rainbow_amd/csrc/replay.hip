@@ -1145,3 +1145,11 @@ int rb_u8_to_unit_f32(const uint8_t* src_dev, float* dst_dev, int64_t n, rb_stre
 }
 
 }  // extern "C"
+
+// (C++ linkage: called by learner.hip flush_update, not part of the C ABI)
+int rb_launch_adam_pending(const ClipAdamArgs* args_dev, int blocks, void* stream) {
+  RB_LAUNCH_T("clip_adam:k_adam_pending", k_adam_pending, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, args_dev);
+  RB_LAUNCH_CHECK();
+  return RB_OK;
+}
+

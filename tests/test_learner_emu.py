@@ -362,7 +362,7 @@ def _ts_snapshot(mem, rp, ad, out):
                 tree=rp.tree().copy(), norm=mem.download(out["norm"]).copy(), grads=mem.download(ad.grads).copy())
 
 
-def _ts_args(name, mem, rp, ad, o, job, beta, step):
+def _ts_args(name, mem, rp, ad, o, job, beta, step, max_norm=None):
     import ctypes as C
     from rainbow_amd import _lib as L
     hy = scenarios.LEARN_HYPER
@@ -372,7 +372,7 @@ def _ts_args(name, mem, rp, ad, o, job, beta, step):
                        noise_job=C.addressof(job), frames_dev=rp.bufs.frames_dev, windows_dev=rp.bufs.window_dev,
                        loss_dev=mem.ptr(o["loss"]), exp_avg_dev=mem.ptr(ad.adam_m), exp_avg_sq_dev=mem.ptr(ad.adam_v),
                        norm_dev=mem.ptr(o["norm"]), lr=hy["lr"], beta1=0.9, beta2=0.999, eps=hy["adam_eps"], step=step,
-                       max_norm=hy["norm_clip"])
+                       max_norm=hy["norm_clip"] if max_norm is None else max_norm)
 
 
 def test_train_step_entry_point_equals_its_three_calls(emu):
@@ -410,8 +410,14 @@ def test_train_step_entry_point_equals_its_three_calls(emu):
     ad1.close(); ad2.close(); rp1.close(); rp2.close()
 
 
-def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
-    """RB_LEARNER_DEFER_UPDATE: rb_learner_train_step leaves clip + Adam (agent.py:97-98) pending and the NEXT train_step's
+@pytest.mark.parametrize("implicit_sigma,max_norm", [(False, None), (True, None), (False, 0.02), (True, 0.02)],
+                         ids=["stored-sigma-grad", "implicit-sigma-grad", "stored-sigma-grad-clip-bites", "implicit-sigma-grad-clip-bites"])
+def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu, monkeypatch, implicit_sigma, max_norm):
+    """RB_LEARNER_IMPLICIT_SIGMA on top (second and third case): the backward does not store the hidden layer's sigma-weight
+    gradient, the hosted pass forms it from g_mu and the noise snapshot while it updates the (mu, sigma) pairs, and whatever runs
+    the pass as a launch of its own (act, flush) materialises it first — with a clip that bites (max_norm 0.02) the scaled
+    gradients it stores back include sigma's.  Same twin, same bit-identity, the stored gradient included.
+    RB_LEARNER_DEFER_UPDATE: rb_learner_train_step leaves clip + Adam (agent.py:97-98) pending and the NEXT train_step's
     sampler launch carries it as extra workgroups (adam_body.h).  Against a twin without the flag, five steps with the
     device-resident step number: after every train_step the deferred handle's parameters are exactly ONE update behind;
     rb_learner_act (any entry point that reads parameters) runs the pending pass first and returns the twin's action; after
@@ -421,6 +427,7 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
     from rainbow_amd import _lib as L
     name = "dataeff"
     c = scenarios.LEARN_CONFIGS[name]
+    monkeypatch.setenv("RB_OPTS", "implicit_small=1")          # (the library enables the pairing from 1 M-element layers on)
     h1 = _ts_build(emu, name)
     h2 = _ts_build(emu, name)
     ctrs = []
@@ -428,7 +435,7 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
         ctr = mem.upload(np.zeros(1, np.int64))
         L.check(emu, emu.rb_learner_set_step_counter(ad.h, mem.ptr(ctr)))
         ctrs.append(ctr)
-    L.check(emu, emu.rb_learner_set_flags(h1[2].h, L.LEARNER_DEFER_UPDATE))
+    L.check(emu, emu.rb_learner_set_flags(h1[2].h, L.LEARNER_DEFER_UPDATE | (L.LEARNER_IMPLICIT_SIGMA if implicit_sigma else 0)))
     state = h1[0].upload(scenarios.synth_state(np.random.RandomState(9), c["history"], 0).astype(np.float32) / 255.0)
     state2 = h2[0].upload(h1[0].download(state).copy())
     prev_twin = None
@@ -436,10 +443,13 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
         beta = 0.4 + 0.05 * step
         snaps = []
         for (mem, rp, ad, o, job) in (h1, h2):
-            ts = _ts_args(name, mem, rp, ad, o, job, beta, 0)
+            ts = _ts_args(name, mem, rp, ad, o, job, beta, 0, max_norm)
             L.check(emu, emu.rb_learner_train_step(ad.h, C.byref(ts), None))
             snaps.append(_ts_snapshot(mem, rp, ad, o))
         a, b = snaps
+        if implicit_sigma:      # the hidden layer's sigma gradient of THIS step is not in the flat gradient (its mu part is)
+            sg = h1[2].layout["fc_h_v.weight_sigma"][0]
+            assert not np.array_equal(a["grads"][sg:sg + 512], b["grads"][sg:sg + 512])
         for k in ("idx", "loss", "w", "noise", "tree"):             # the step itself never waits for the pending pass' results
             assert np.array_equal(a[k], b[k]), (step, k)            # ... because it has run by then (same launch as the sampler)
         if prev_twin is not None:                                   # one update behind, exactly
@@ -453,6 +463,8 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu):
                 L.check(emu, emu.rb_learner_act(ad.h, mem.ptr(st), 1, mem.ptr(act), mem.ptr(q), None))
                 outs.append((int(mem.download(act)[0]), float(mem.download(q)[0])))
             assert outs[0] == outs[1]
+            if implicit_sigma:  # act ran the pending pass (pairing included) as a launch of its own; a READER of grads_dev flushes,
+                L.check(emu, emu.rb_learner_flush(h1[2].h, None))   # which forms the sigma gradient the backward left out
             a = _ts_snapshot(*h1[:4])
             for k in a:
                 assert np.array_equal(a[k], b[k]), (step, k)

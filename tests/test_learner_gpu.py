@@ -415,6 +415,9 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
 
     def fresh(defer):
         monkeypatch.setenv("RAINBOW_AMD_DEFER_UPDATE", defer)
+        # RB_LEARNER_IMPLICIT_SIGMA rides on the deferral (the hosted pass forms the hidden layer's sigma gradient itself and
+        # updates (mu, sigma) pairs together); the library switches it on from 1 M-element layers: force it on this small net
+        monkeypatch.setenv("RB_OPTS", "implicit_small=1")
         # the deferring agent through rb_learner_train_step or through the step's entry points one by one
         # (rb_learner_attach_pending / rb_learner_clip_adam_deferred: the path the replica exchange uses as well)
         monkeypatch.setenv("RAINBOW_AMD_ONE_CALL", one_call if defer == "1" else "1")
@@ -456,6 +459,7 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
     a1, m1 = fresh("1")
     a2, m2 = fresh("0")
     assert a1._defer_update and not a2._defer_update
+    assert a1._implicit_sigma and not a2._implicit_sigma
     t1, p1 = run(a1, m1)
     t2, p2 = run(a2, m2)
     assert all(p1) and not any(p2)
