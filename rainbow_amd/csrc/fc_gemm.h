@@ -494,7 +494,7 @@ __device__ __forceinline__ void rb_fc_gemm_dw(const NlDwArgs& a, int ntile, int 
       float4 gs;
       gs.x = gm.x * (eo[it] * ei.x); gs.y = gm.y * (eo[it] * ei.y); gs.z = gm.z * (eo[it] * ei.z); gs.w = gm.w * (eo[it] * ei.w);
       rb_st4_wt(a.g_mu, (unsigned)(((int64_t)n * K + kcol4) * 4), gm);
-      rb_st4_wt(a.g_sigma, (unsigned)(((int64_t)n * K + kcol4) * 4), gs);
+      if (!a.no_sigma) rb_st4_wt(a.g_sigma, (unsigned)(((int64_t)n * K + kcol4) * 4), gs);   // (RB_LEARNER_IMPLICIT_SIGMA: norm only)
       sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
       sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
     }

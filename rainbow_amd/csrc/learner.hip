@@ -1801,8 +1801,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     hw_.norm_only = defer_dw ? 1 : 0;
     l->dw_deferred = defer_dw ? 1 : 0;
     // RB_LEARNER_IMPLICIT_SIGMA: g_sigma = g_mu * (eps_out x eps_in) is left to the optimiser pass (its square still enters
-    // the norm here).  Needs the pipelined weight-gradient body (batch <= 32), the fused norm and adjacent mu | sigma arrays
-    const bool implicit_sigma = (l->flags & RB_LEARNER_IMPLICIT_SIGMA) && pipe && h_ct > 0 && fuse_norm && !defer_dw &&
+    // the norm here).  Needs the pipelined weight-gradient body (batch <= 32) or the tiled GEMM (batch >= 128), the fused norm and
+    // adjacent mu | sigma arrays
+    const bool implicit_sigma = (l->flags & RB_LEARNER_IMPLICIT_SIGMA) && ((pipe && h_ct > 0) || gemm_bwd) && fuse_norm && !defer_dw &&
                                 L.h_sigma == L.h_mu + (int64_t)2 * L.H * L.F && (L.F % 4) == 0 && (L.h_mu % 4) == 0 &&
                                 ((int64_t)2 * L.H * L.F >= ((int64_t)1 << 20) || l->opt_implicit_small);   // (the data-efficient
                                 // net's 0.3 M-element layer: +0.8 us per step with the pairing — it pays from megabytes on)

@@ -410,9 +410,11 @@ def test_train_step_entry_point_equals_its_three_calls(emu):
     ad1.close(); ad2.close(); rp1.close(); rp2.close()
 
 
-@pytest.mark.parametrize("implicit_sigma,max_norm", [(False, None), (True, None), (False, 0.02), (True, 0.02)],
-                         ids=["stored-sigma-grad", "implicit-sigma-grad", "stored-sigma-grad-clip-bites", "implicit-sigma-grad-clip-bites"])
-def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu, monkeypatch, implicit_sigma, max_norm):
+@pytest.mark.parametrize("implicit_sigma,max_norm,gemm", [(False, None, False), (True, None, False), (False, 0.02, False), (True, 0.02, False),
+                                                          (True, None, True)],
+                         ids=["stored-sigma-grad", "implicit-sigma-grad", "stored-sigma-grad-clip-bites", "implicit-sigma-grad-clip-bites",
+                              "implicit-sigma-grad-tiled-gemm"])
+def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu, monkeypatch, implicit_sigma, max_norm, gemm):
     """RB_LEARNER_IMPLICIT_SIGMA on top (second and third case): the backward does not store the hidden layer's sigma-weight
     gradient, the hosted pass forms it from g_mu and the noise snapshot while it updates the (mu, sigma) pairs, and whatever runs
     the pass as a launch of its own (act, flush) materialises it first — with a clip that bites (max_norm 0.02) the scaled
@@ -427,7 +429,9 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu, monke
     from rainbow_amd import _lib as L
     name = "dataeff"
     c = scenarios.LEARN_CONFIGS[name]
-    monkeypatch.setenv("RB_OPTS", "implicit_small=1")          # (the library enables the pairing from 1 M-element layers on)
+    # (the library enables the pairing from 1 M-element layers on; last case: the weight gradient comes from the tiled GEMM of
+    # fc_gemm.h — batch 256's path — whose epilogue leaves the sigma gradient out the same way)
+    monkeypatch.setenv("RB_OPTS", "implicit_small=1" + (",fc_gemm=1" if gemm else ""))
     h1 = _ts_build(emu, name)
     h2 = _ts_build(emu, name)
     ctrs = []
