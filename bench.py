@@ -97,7 +97,7 @@ CONV_GEOM = {   # (cin, cout, kernel, stride, in, out) per layer, model.py:55-63
 }
 
 
-def kernel_table(cfg, n_params, hosted_update=False):
+def kernel_table(cfg, n_params, hosted_update=False, implicit_sigma=False):
     """Algorithmic work per launch of the kernels that can dominate a step, with the roofline that bounds
     each: the streamed hidden layer and the optimiser pass are HBM-bound, the conv kernels f32-MFMA-bound.
     Keys are the profiling tags of the launches (RB_LAUNCH_T in csrc/learner.hip)."""
@@ -106,6 +106,9 @@ def kernel_table(cfg, n_params, hosted_update=False):
     F = conv[-1][1] * conv[-1][5] ** 2
     wh = 2 * H * F * 4                      # one of mu / sigma of the fused hidden layer, bytes
     fused_dw = os.environ.get("RAINBOW_AMD_FUSED_DW", "0") == "1" and B <= 32   # fc_h weight gradient never stored
+    # RB_LEARNER_IMPLICIT_SIGMA (Agent default with the deferred pass; hidden layers from 1 M elements; batch <= 32 or >= 128): the
+    # hidden layer's sigma gradient is neither written by the backward nor read by the optimiser pass — wh bytes less in each
+    sig = wh if (implicit_sigma and hosted_update and not fused_dw and 2 * H * F >= (1 << 20) and (B <= 32 or B >= 128)) else 0
     def binding(nbytes, flops):
         """The roofline that binds a streamed noisy-linear launch: HBM at batch 32 (weights streamed once for a rank-32
         product), f32 MFMA at batch 256 (the same bytes carry 8x the FLOPs)."""
@@ -115,12 +118,12 @@ def kernel_table(cfg, n_params, hosted_update=False):
 
     t = {
         # clip + Adam over the flat buffers: reads p, g, m, v and writes p, m, v once (fused: no g read for the fc_h weights)
-        "clip_adam": dict(bound="hbm", work=7 * 4 * n_params - (2 * wh if fused_dw else 0), unit="GB/s"),
+        "clip_adam": dict(bound="hbm", work=7 * 4 * n_params - (2 * wh if fused_dw else 0) - sig, unit="GB/s"),
         # hidden layer forward: streams mu+sigma of BOTH nets once; activations are L2-resident; 3B rows x F x 2H MACs
         "fc_h_fwd": binding(2 * 2 * wh + 3 * B * F * 4 + 3 * B * 2 * H * 4 * 2, 2 * 3 * B * F * 2 * H),
         # hidden layer backward (one launch): streams mu+sigma of the online net once (dX), writes d_mu + d_sigma once (dW);
         # dW and dX are B x F x 2H MACs each
-        "fc_h_bwd": binding(2 * wh + (0 if fused_dw else 2 * wh) + B * (F + 2 * H) * 4, 2 * 2 * B * F * 2 * H),
+        "fc_h_bwd": binding(2 * wh + (0 if fused_dw else 2 * wh) - sig + B * (F + 2 * H) * 4, 2 * 2 * B * F * 2 * H),
     }
     # the output-layer / head tail (three small launches; HBM-bound by their bytes, latency-bound in fact: DESIGN.md §3)
     NZ = 51 * (cfg["actions"] + 1)
@@ -331,7 +334,8 @@ def main():
         step()
     drain()
 
-    ktab = kernel_table(cfg, int(agent.params.numel()), hosted_update=agent._defer_update)
+    ktab = kernel_table(cfg, int(agent.params.numel()), hosted_update=agent._defer_update,
+                        implicit_sigma=getattr(agent, "_implicit_sigma", False))
     # the kernel the roofline object reports = the step's DOMINANT kernel by time, found by a short bracketed pass over
     # every candidate before the timed region (or forced with --roofline-kernel)
     if opt.no_profile:
