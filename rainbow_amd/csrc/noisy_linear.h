@@ -901,6 +901,8 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
     if (TALL && threadIdx.x >= 256 && b == 0) return;    // (the write-back body is written for 256 threads)
     if (b == 0) {
       RB_SPAN_BEGIN(sb + 0);
+      // (the one-wave sorted write-back of k_update measured no faster HERE — same-box A/B of two builds on all three configs:
+      // 160.9 / 103.5 / 498.5 against 161.4 / 103.0 / 497.8 us per step — this block is not the launch's long pole)
       rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // n <= 256
       RB_SPAN_END(sb + 0);
       RB_WGT_ROLE(kid, wgb, 0);

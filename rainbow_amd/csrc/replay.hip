@@ -619,20 +619,7 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
                                                   int32_t apply_pow, double omega) {
   __shared__ float lds[UpdateLds<2048, 1024>::WORDS];
-  if (n <= 64) {                                            // block-uniform: is this a sampler's batch (sorted leaves)?
-    __shared__ int s_sorted;
-    UpdateOperand op;
-    if (threadIdx.x < 64) {
-      op = rb_update_load(v, tree_idx, values, n);           // every first load of the kernel in one batch
-      if (threadIdx.x == 0) s_sorted = op.sorted;
-    }
-    __syncthreads();
-    if (s_sorted) {
-      if (threadIdx.x < 64) rb_update_sorted_wave(v, op, n, apply_pow, omega, nullptr, 0);
-      return;
-    }
-  }
-  rb_update_body<2048, 1024>(v, tree_idx, values, n, apply_pow, omega, lds);
+  rb_update_auto<2048, 1024>(v, tree_idx, values, n, apply_pow, omega, lds);
 }
 
 // ------------------------------------------------------------ update + sample --

@@ -313,5 +313,31 @@ __device__ __forceinline__ void rb_update_sorted_wave(ReplayView v, const Update
   else rb_update_sorted_levels<RB_MAX_LEVELS>(v, a, val, vmax, sib, Lr, active, lane, s_top, n_top);
 }
 
+// The write-back of one workgroup, whichever way fits the batch: a sorted batch of at most 64 leaves (what the sampler hands
+// back) goes through rb_update_sorted_wave on wave 0 — the other waves leave — anything else through the hashed body.  All
+// threads of the workgroup call; `lds` as for rb_update_body<HS, NMAX> (its first word doubles as the "sorted" flag before the
+// body clears it).  Same tree, bit for bit, either way.
+template <int HS, int NMAX>
+__device__ __forceinline__ void rb_update_auto(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n, int32_t apply_pow,
+                                               double omega, float* lds) {
+  if (n <= 64) {                                            // block-uniform
+    int* s_sorted = reinterpret_cast<int*>(lds);
+    UpdateOperand op;
+    op.node = -1; op.val = 0.0f; op.status = 0; op.sorted = 0;
+    if (threadIdx.x < 64) {
+      op = rb_update_load(v, tree_idx, values, n);           // every first load of the chain in one batch
+      if (threadIdx.x == 0) *s_sorted = op.sorted;
+    }
+    __syncthreads();
+    const bool sorted = *s_sorted != 0;
+    __syncthreads();                                        // (the hashed body reuses the word)
+    if (sorted) {
+      if (threadIdx.x < 64) rb_update_sorted_wave(v, op, n, apply_pow, omega, nullptr, 0);
+      return;
+    }
+  }
+  rb_update_body<HS, NMAX>(v, tree_idx, values, n, apply_pow, omega, lds);
+}
+
 // host side (replay.hip): kernel view + priority exponent of a handle
 int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega);
