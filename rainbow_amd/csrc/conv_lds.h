@@ -246,7 +246,11 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
   const int v16 = per_c >> 4, total16 = cin * v16;
   const int v4 = per_c >> 2, total4 = cin * v4;
   const int total1 = cin * per_c;
+  // (a frame pointer is always one of the kernel's global arguments plus an offset and its validity a flag of its own: with
+  // nullptr as the "blank frame" marker the compiler could no longer tell the address space and the first layer's T16
+  // instantiation carried six FLAT loads — the library's only ones)
   const uint8_t* fp[x_dw ? XD : XU];
+  bool fok[x_dw ? XD : XU];
   uint4 xu[XU];
   unsigned xd[XD];
   const int dpc = per_c >> 2, total_dw = cin * dpc;   // x_dw: dwords per channel of the patch
@@ -288,10 +292,20 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     for (int i = 0; i < (x_dw ? XD : XU); ++i) {
       const int e = i * THREADS + t;
       const int c = x_dw ? e / dpc : e / v16;
-      fp[i] = nullptr;
-      if (x_dw ? e < total_dw : e < total16) {
-        if (a.src.ring) fp[i] = widx[i] < 0 ? nullptr : a.src.ring + (int64_t)widx[i] * G::IP;       // rb_frame_ptr, second half
-        else fp[i] = rb_frame_ptr(a.src, img, c, cin, G::IP);
+      fok[i] = false;
+      if (a.src.ring) {
+        fp[i] = a.src.ring;
+        if (x_dw ? e < total_dw : e < total16) {
+          fok[i] = widx[i] >= 0;
+          fp[i] = a.src.ring + (int64_t)(widx[i] < 0 ? 0 : widx[i]) * G::IP;                         // rb_frame_ptr, second half
+        }
+      } else {
+        fp[i] = a.src.u8_states;
+        if (x_dw ? e < total_dw : e < total16) {
+          fok[i] = true;
+          fp[i] = img < a.src.B ? a.src.u8_states + ((int64_t)img * cin + c) * G::IP
+                                : a.src.u8_next + ((int64_t)((img - a.src.B) % a.src.B) * cin + c) * G::IP;   // rb_frame_ptr, gathered stacks
+        }
       }
     }
   }
@@ -301,7 +315,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     for (int i = 0; i < XD; ++i) {
       const int e = i * THREADS + t;
       xd[i] = 0u;
-      if (e < total_dw && fp[i]) xd[i] = *reinterpret_cast<const unsigned*>(fp[i] + iy0 * G::IH + 4 * (e - (e / dpc) * dpc));
+      if (e < total_dw && fok[i]) xd[i] = rb_ldg_u32(fp[i] + iy0 * G::IH + 4 * (e - (e / dpc) * dpc));
     }
   } else if constexpr (x_u8) {
     if constexpr (FIRST) {
@@ -309,7 +323,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
       for (int i = 0; i < XU; ++i) {
         const int e = i * THREADS + t;
         xu[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (e < total16 && fp[i]) xu[i] = *reinterpret_cast<const uint4*>(fp[i] + iy0 * G::IH + (e - (e / v16) * v16) * 16);
+        if (e < total16 && fok[i]) xu[i] = *reinterpret_cast<const uint4*>(fp[i] + iy0 * G::IH + (e - (e / v16) * v16) * 16);
       }
     }
   } else if constexpr (x_vec) {

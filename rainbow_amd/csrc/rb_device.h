@@ -175,6 +175,17 @@ __device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned t
 #endif
 }
 
+// A 4-byte load through a pointer the CALLER knows to be global memory: where a pointer is a runtime choice among several
+// kernel arguments (the three frame sources of the first conv layer) the compiler may fall back to a generic pointer and a FLAT
+// load, which also probes the LDS and scratch apertures; the address-space cast pins it to global_load.
+__device__ __forceinline__ unsigned rb_ldg_u32(const void* p) {
+#if defined(RB_HOST_INTERP)
+  return *reinterpret_cast<const unsigned*>(p);
+#else
+  return *(const __attribute__((address_space(1))) unsigned*)(p);
+#endif
+}
+
 // 16-byte global/LDS accesses (pointers must be 16-byte aligned)
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -518,7 +518,9 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
   const float p_total_g = v.tree[0];
   if (lds_top) __syncthreads();
   RB_STAMP_AT(1);
-  const float p_total = lds_top ? s_top[0] : p_total_g;         // memory.py:149
+  const float p_top0 = s_top[0];                                // (an unconditional LDS read: as an operand of the select below the
+                                                                //  compiler formed a generic pointer and the kernel's only flat load)
+  const float p_total = lds_top ? p_top0 : p_total_g;           // memory.py:149
   // segment_length = p_total / batch_size: float32 / python int -> float32 (NEP 50)
   const float seg_f = __fdiv_rn(p_total, (float)batch);         // memory.py:125
   const double seg = (double)seg_f;

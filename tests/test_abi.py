@@ -57,3 +57,39 @@ def test_product_path_fails_loudly_without_gpu():
                                  priority_weight=0.4, priority_exponent=0.5)
     with pytest.raises(RuntimeError, match="HBM"):
         ReplayMemory(args, 128)
+
+
+def test_no_flat_or_scratch_instructions_in_the_gfx950_code():
+    """The device code of every translation unit, compiled to gfx950 assembly: no FLAT instruction (a pointer the compiler
+    could not place in an address space: the load also probes the LDS and scratch apertures) and no scratch segment (a
+    spilling kernel slows every kernel that shares the stream with it) — both crept in twice in round 4
+    (a select between an LDS value and a global one in the sampler; the hosted optimiser pass over its hosting kernel's
+    register budget) and cost up to 10 us per step before anybody looked."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "rainbow_amd", "csrc")
+    procs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for tu in ("learner", "replay", "common"):
+            out = os.path.join(tmp, tu + ".s")
+            procs.append((tu, out, subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                                     "--cuda-device-only", "-S", os.path.join(csrc, tu + ".hip"), "-o", out],
+                                                    stderr=subprocess.DEVNULL)))
+        for tu, out, pr in procs:
+            assert pr.wait() == 0, tu
+            kernel, offenders = None, []
+            for line in open(out):
+                m = re.match(r"^([_A-Za-z0-9]+):", line)
+                if m:
+                    kernel = m.group(1)
+                body = line.split(";")[0]
+                if re.search(r"\b(flat_load|flat_store|flat_atomic|scratch_load|scratch_store)", body):
+                    offenders.append((kernel, body.split()[0]))
+                m = re.match(r"^\s*\.amdhsa_private_segment_fixed_size\s+(\d+)", line)
+                if m and int(m.group(1)) != 0:
+                    offenders.append((kernel, "scratch segment of %s bytes" % m.group(1)))
+            assert not offenders, (tu, offenders[:5])
