@@ -22,3 +22,4 @@ for v in "RB_OPTS=fc_gemm=0" "RB_OPTS=fc_gemm=-1" "RB_OPTS=fc_gemm=0" "RB_OPTS=f
   env $v timeout 90 python bench.py --config breakout-canonical-b256 --steps 1000 --warmup 200 --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read() or '{\"ms_per_step\":0,\"value\":0}'); print('[$v]: %.2f us/step  %.0f steps/s' % (d['ms_per_step']*1e3, d['value']))"
 done > gpurun_out/${TAG}_fc_gemm_ab.txt
 bash tools/gpu_trace_gaps.sh breakout-canonical-b256 > gpurun_out/${TAG}_trace_b256.txt 2>&1
+timeout 120 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_20step_bench.json.log
