@@ -267,6 +267,46 @@ def test_learn_step_at_baseline_shapes_matches_oracle(hip, monkeypatch, shape, f
     ad.close()
 
 
+def test_tiled_gemm_hidden_layer_tracks_the_streamed_kernels_over_many_steps(hip, monkeypatch):
+    """BASELINE config 3's shape (canonical net, batch 256): 40 consecutive learn steps with the hidden layer on the tiled GEMMs
+    of fc_gemm.h (split-K partial tiles, the self-resetting arrival counters of 48 output tiles, two workgroups per CU in the
+    backward) against a twin on the streamed noisy-linear kernels (RB_OPTS fc_gemm=0) fed the same batches and noise: the two
+    differ only in the order of their f32 sums, so every per-sample loss, the norm and the parameters stay close all the way
+    (1e-3 / 2e-3 relative, 5e-5 absolute on the parameters) — a lost or doubly counted partial tile would show at once, and the
+    counters must come back to zero after every launch for the next one to work."""
+    from cabi_adapter import CAbiLearnAdapter, TorchMem
+    shape = "cfg3-canonical-h512-b256-a4"
+    cfgd = BASELINE_SHAPES[shape]
+    monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
+    cfg = O.Config(**cfgd)
+    online, target = O.init_params(cfg, 911), O.init_params(cfg, 912)
+    ads = []
+    for opts in ("fc_gemm=-1", "fc_gemm=0"):
+        monkeypatch.setenv("RB_OPTS", opts)
+        ad = CAbiLearnAdapter(hip, TorchMem(), shape)
+        ad.load(online, target)
+        ads.append(ad)
+    draws = O.noise_draw_count(cfg)
+    rs = np.random.RandomState(56)
+    for k in range(40):
+        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+        batch = scenarios.make_batch(cfgd, 800 + k)
+        outs = []
+        for ad in ads:
+            ad.reset_noise_online(raw_on)
+            outs.append(ad.learn_step(batch, raw_tg))
+        a, b = outs
+        # (two f32 summation orders drift apart as the steps feed on each other: 8.5e-5 on the norm after ten steps; a lost tile
+        # is an O(1) error in the same quantities)
+        np.testing.assert_allclose(a["loss"], b["loss"], rtol=1e-3, atol=1e-4, err_msg="step %d" % k)
+        np.testing.assert_allclose(a["grad_norm"], b["grad_norm"], rtol=2e-3, err_msg="step %d" % k)
+    pa, pb = ads[0].params(), ads[1].params()
+    for name in pa:
+        np.testing.assert_allclose(pa[name], pb[name], rtol=0, atol=5e-5, err_msg=name)   # (Adam turns a near-zero gradient of either sign into +-lr: 9e-6 seen)
+    for ad in ads:
+        ad.close()
+
+
 def test_device_rng_noise_statistics(hip):
     """The PRODUCTION noise path (rb_learner_reset_noise with raw = NULL: device Philox + Box-Muller, then
     f(x) = sign(x) sqrt|x|, model.py:32-40): >= 10^6 values, moments and a Kolmogorov-Smirnov distance against the exact
