@@ -165,13 +165,20 @@ int rb_replay_sample_fused_noise(rb_replay_t* r, int32_t batch, double priority_
 
 /* The reference's sampler retries until a batch is valid (memory.py:128-132); the device sampler is bounded by
  * max_attempts.  When the bound is hit it writes ZERO importance weights (the learn step that consumes the batch then
- * has an exactly zero gradient), sets last_status = 1 in the device header and increments a pinned host counter.
+ * has an exactly zero gradient), sets last_status = 1 in the device header, marks the draw's index buffer (tree_idx = -1
+ * everywhere) and increments a pinned host counter.
  * This call reads that counter WITHOUT synchronising: the number of failed sampler launches that have completed so far. */
 int rb_replay_failed_samples(rb_replay_t* r, int64_t* count_host);
 /* Zero that counter (after the caller has reported the failure and, e.g., appended more transitions).  A learn step that
  * consumed a failed batch left no trace: its priority write-back (rb_replay_update_priorities and the learner's fused
- * sink), the optimiser update and the optimiser's step number are all skipped on the device when last_status != 0.     */
+ * sink: by the mark in the index buffer, rb_replay_dropped_updates), the optimiser update and the optimiser's step number
+ * (by last_status of the draw the learn call consumes) are all skipped on the device.  Also zeroes the dropped-update count. */
 int rb_replay_reset_failed_samples(rb_replay_t* r);
+/* A draw that gave up marks its own index buffer (every tree index = -1).  ReplayMemory.update_priorities (memory.py:157-159)
+ * — rb_replay_update_priorities, rb_replay_update_sample and the learner's fused sink — drops exactly the write-back whose
+ * indices carry that mark and counts it here (pinned host word, read WITHOUT synchronising: completed launches so far).  The
+ * write-back of an earlier, valid batch is applied whatever happened to later draws.                                        */
+int rb_replay_dropped_updates(rb_replay_t* r, int64_t* count_host);
 /* SegmentTree.index / .full (memory.py:14,16) from the library's host mirror, without touching the device: exact as long
  * as every append went through this handle (a header restored with rb_copy_to_device is picked up as well).        */
 int rb_replay_position(rb_replay_t* r, int64_t* index_host, int32_t* full_host);

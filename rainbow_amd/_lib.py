@@ -77,6 +77,7 @@ SIGNATURES = {
     "rb_replay_set_beta_source": (c_int, [c_void_p, c_void_p]),
     "rb_replay_failed_samples": (c_int, [c_void_p, C.POINTER(c_int64)]),
     "rb_replay_reset_failed_samples": (c_int, [c_void_p]),
+    "rb_replay_dropped_updates": (c_int, [c_void_p, C.POINTER(c_int64)]),
     "rb_replay_position": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_int32)]),
     "rb_replay_sample_fused_noise": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(NoiseJob), c_void_p]),

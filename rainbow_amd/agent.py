@@ -335,22 +335,28 @@ class Agent:
         self._flush_noise()
         st = state.to(device=self.device, dtype=torch.float32).contiguous()
         act = self._act_np
-        act[0] = _ACT_PENDING
-        rc = self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0, self._act_pin.data_ptr(),
-                                      self._q_pin.data_ptr(), self._stream())
-        if rc != 0:
-            L.check(self._lib, rc)
-        # completion = the pinned action word changes (the head writes q, fences, then the action): polling it returns ~5 us
-        # before a stream synchronize would (46 -> 41 us per act, tools/stamp/act_host.py); bounded, then the synchronize
-        for _ in range(20000):
-            if act[0] != _ACT_PENDING:
-                break
-        else:
+        for attempt in range(2):
+            act[0] = _ACT_PENDING
+            rc = self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0, self._act_pin.data_ptr(),
+                                          self._q_pin.data_ptr(), self._stream())
+            if rc != 0:
+                L.check(self._lib, rc)
+            # completion = the pinned action word changes (the head writes q, fences, then the action): polling it returns
+            # ~5 us before a stream synchronize would (46 -> 41 us per act, tools/stamp/act_host.py); bounded, then the synchronize
+            for _ in range(20000):
+                if act[0] != _ACT_PENDING:
+                    break
+            else:
+                torch.cuda.current_stream(self.device).synchronize()
+            if act[0] >= 0:
+                return
             torch.cuda.current_stream(self.device).synchronize()
-        if act[0] < 0:
-            torch.cuda.current_stream(self.device).synchronize()
-            if act[0] < 0:
-                raise RuntimeError("rb_learner_act: the one-launch act path reported an expired in-launch wait (action %d)" % int(act[0]))
+            if act[0] >= 0:
+                return
+            # an in-launch wait of THAT launch expired (its workgroups were not co-resident: another process on the GPU, CU
+            # masking).  The failure is tagged with the launch number, so the next launch starts clean: try once more.
+        raise RuntimeError("rb_learner_act: the one-launch act path reported an expired in-launch wait twice (action %d); "
+                           "RB_OPTS=act_fused=0 selects the per-layer launches" % int(act[0]))
 
     def act(self, state):
         """agent.py:53-55: greedy action on the expected value of the (noisy) online distribution."""
@@ -455,6 +461,8 @@ class Agent:
         _learn_eager's three calls — without the interpreter between the launches (include/rainbow_hip.h says why)."""
         B = self.batch_size
         ts = self._ts
+        if mem._pending is not None:       # a caller's update_priorities() since the last draw: applied before this one
+            mem.flush()
         if ts is None or self._ts_mem is not mem or mem._out.get(B) is not self._ts_out:
             o = mem._buffers(B)
             frames, windows, wlen = mem.frame_source()
@@ -494,7 +502,8 @@ class Agent:
             L.check(self._lib, rc)
         self._update_pending = self._defer_update
         if not self._lib.rb_learner_priority_written(self._h):       # (cannot happen with a sink set; keeps agent.py:100)
-            mem.update_priorities(self._ts_out["tree_idxs"], self._loss)
+            # immediately: a lazy write-back would read tree_idxs / _loss after the next step has overwritten them
+            mem.update_priorities(self._ts_out["tree_idxs"], self._loss, _immediate=True)
 
     def _learn_eager(self, mem, _target_raw_normals=None, _unit_uniforms=None):
         B = self.batch_size
@@ -511,7 +520,17 @@ class Agent:
             if not (g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"]):
                 return self._learn_one_call(mem, stream)
         noise_job = None
-        if device_mem and _target_raw_normals is None:
+        overwrite_target = False
+        if device_mem and _target_raw_normals is not None and self._update_pending and not self._noise_pending:
+            # parity runs (injected normals) keep the product's launch shape: the sampler launch still hosts the pending
+            # optimiser pass, carried by a target-noise job whose device-RNG draw the injected normals overwrite below
+            noise_job = self._noise_jobs.get(1)
+            if noise_job is None:
+                noise_job = L.NoiseJob()
+                L.check(self._lib, self._lib.rb_learner_noise_job(self._h, 1, C.byref(noise_job)))
+                self._noise_jobs[1] = noise_job
+            overwrite_target = True
+        elif device_mem and _target_raw_normals is None:
             # the target-noise draw of this step (agent.py:74) — plus the deferred online draw (main.py:151) when one is
             # pending — rides along in the sampler's launch: it does not depend on the batch, only has to precede the
             # forwards, and the draws are the same Philox epochs as separate launches (online first, then target)
@@ -552,6 +571,8 @@ class Agent:
             else:
                 self._flush_noise()
                 self._reset_target_noise(_target_raw_normals)                              # agent.py:74
+        elif overwrite_target:
+            self._reset_target_noise(_target_raw_normals)                                  # agent.py:74 (injected draw)
         if (device_mem and self._fuse_update
                 and (getattr(self, "_sink_mem", None) is not mem or self._sink_idx is not idxs)):
             # the learner writes the new priorities into mem's sum-tree itself (one extra workgroup of its backward)
@@ -593,7 +614,7 @@ class Agent:
             self.optimiser.step()                                                          # agent.py:98
         if device_mem:
             if not fused_update:
-                mem.update_priorities(idxs, self._loss)                                    # agent.py:100, no D2H
+                mem.update_priorities(idxs, self._loss, _immediate=True)                   # agent.py:100, no D2H
         else:
             mem.update_priorities(idxs, self._loss.detach().cpu().numpy())                 # agent.py:100
 

@@ -169,9 +169,11 @@ __device__ __forceinline__ float rb_dueling_q(const float* lg, const float* mean
   return (lg[z] + lg[Z + a * Z + z]) - mean_a[z];
 }
 // Agent.act / evaluate_q head (agent.py:53-55, 110-112) for ONE image: `lg` = its logits row (global or LDS), s_mean [Z]
-// and s_ev [A] workgroup scratch.  All threads of a 256-thread workgroup call.  err (optional): a set word -> action -1.
+// and s_ev [A] workgroup scratch.  All threads of a 256-thread workgroup call.  err (optional): the word an expired in-launch
+// wait of launch number `err_epoch` sets to that number -> action -1 for THAT launch only (a later launch compares with its own
+// number: the failure state needs no reset and cannot stick).
 __device__ __forceinline__ void rb_head_act_body(int Z, int A, const float* lg, const float* support, float* s_mean, float* s_ev,
-                                                 int32_t* action_out, float* q_out, const unsigned* err) {
+                                                 int32_t* action_out, float* q_out, const unsigned* err, unsigned err_epoch = 0u) {
   const int t = (int)threadIdx.x;
   const int lane = rb_lane(), wave = rb_wave(), nw = (int)(blockDim.x >> 6);
   for (int z = t; z < Z; z += (int)blockDim.x) {
@@ -200,7 +202,11 @@ __device__ __forceinline__ void rb_head_act_body(int Z, int A, const float* lg, 
     float bv = s_ev[0];
     for (int a = 1; a < A; ++a)
       if (s_ev[a] > bv) { bv = s_ev[a]; best = a; }
-    if (err && *err != 0u) best = -1;                              // a bounded in-launch wait expired: no action
+#if defined(RB_HOST_INTERP)
+    if (err && err_epoch != 0u && *err == err_epoch) best = -1;
+#else
+    if (err && err_epoch != 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_epoch) best = -1;   // a bounded in-launch wait of THIS launch expired: no action
+#endif
     // q BEFORE the action, a system-scope fence in between: a host that polls the (pinned) action word for the value it
     // preset to change may read q right after (rainbow_amd/agent.py _forward_single)
     if (q_out) *q_out = bv;
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(256) void k_act_fused(ActFusedArgs a) {
   RB_WGT(11, wg, 0);                                             // ... kernel id 11: slot 1 + phase = the phase's wait is over
   for (int phase = a.phase_lo; phase < a.phase_hi; ++phase) {
     if (phase < 3 && phase >= a.nconv) continue;                 // (two conv layers: phase 2 does not exist)
-    if (prev >= 0) rb_fan_wait(a.ctr + prev * (RB_FAN_SHARDS * RB_FAN_STRIDE), a.epoch * (unsigned)(G / RB_FAN_SHARDS), a.err);
+    if (prev >= 0) rb_fan_wait(a.ctr + prev * (RB_FAN_SHARDS * RB_FAN_STRIDE), a.epoch * (unsigned)(G / RB_FAN_SHARDS), a.err, a.epoch);
     RB_WGT(11, wg, 1 + phase);
     if (phase < 3) {
       const ActConvArgs& c = a.conv[phase];
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(256) void k_act_fused(ActFusedArgs a) {
       float* s_mean = s_w;                                         // Z <= 256 <= RB_ACT_KMAX
       float* s_ev = &s_red[0][0];                                  // A <= 64
       __syncthreads();
-      rb_head_act_body(a.Z, a.A, lg, a.support, s_mean, s_ev, a.action_out, a.q_out, a.err);
+      rb_head_act_body(a.Z, a.A, lg, a.support, s_mean, s_ev, a.action_out, a.q_out, a.err, a.epoch);
     }
     RB_WGT(10, wg, 1 + phase);
     if (phase + 1 < a.phase_hi) rb_fan_signal(a.ctr + phase * (RB_FAN_SHARDS * RB_FAN_STRIDE), wg);

@@ -1576,13 +1576,16 @@ static int act_forward_single(rb_learner* l, const float* state_dev, const NetPt
       RB_LAUNCH(k_act_fused<0>, dim3((unsigned)G), dim3(256), stream, f);
     }
 #else
-    f.phase_lo = 0; f.phase_hi = 6; f.epoch = ++l->act_epoch;
+    f.phase_lo = 0; f.phase_hi = 6; f.epoch = l->act_epoch + 1;        // (counted below, once the launch is in the stream)
     const int hq = (int)rb_div_up(L.F, 256);
     if (hq <= 3) { RB_LAUNCH_T("act:k_act_fused", k_act_fused<3>, dim3((unsigned)G), dim3(256), stream, f); }
     else if (hq <= 13) { RB_LAUNCH_T("act:k_act_fused", k_act_fused<13>, dim3((unsigned)G), dim3(256), stream, f); }
     else { RB_LAUNCH_T("act:k_act_fused", k_act_fused<0>, dim3((unsigned)G), dim3(256), stream, f); }
 #endif
     RB_LAUNCH_CHECK();
+#if !defined(RB_HOST_INTERP)
+    ++l->act_epoch;       // only a launch that went out advances the monotonic arrival targets (a refused one signalled nothing)
+#endif
     return 1;                                              // the head ran inside the launch
   }
   for (int layer = 0; layer < L.nconv; ++layer) {

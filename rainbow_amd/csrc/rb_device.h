@@ -155,10 +155,12 @@ __device__ __forceinline__ void rb_fan_signal(unsigned* counters, int wg) {     
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counters + (wg % RB_FAN_SHARDS) * RB_FAN_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-__device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned target_per_shard, unsigned* err) {   // all threads call
+// err_tag: what an expired wait stores into *err (the launch number: the reader compares with its own, so one failed launch
+// does not poison the next)
+__device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned target_per_shard, unsigned* err, unsigned err_tag = 1u) {   // all threads call
 #if defined(RB_HOST_INTERP)
   __syncthreads();                                                          // (one launch per phase there: nothing to wait for)
-  (void)counters; (void)target_per_shard; (void)err;
+  (void)counters; (void)target_per_shard; (void)err; (void)err_tag;
 #else
   if (threadIdx.x < 64) {                                                   // wave 0: lanes 0..7 poll one shard each
     const int lane = (int)threadIdx.x;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned t
       if (lane < RB_FAN_SHARDS) v = __hip_atomic_load(counters + lane * RB_FAN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__all((int)(v - target_per_shard) >= 0)) break;
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 22)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > (1u << 22)) { if (lane == 0) __hip_atomic_store(err, err_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
   __syncthreads();

@@ -44,7 +44,8 @@ struct rb_replay {
   float* scaling_dev;
   int32_t max_batch;
   const float* neg_beta_dev;   // optional device-resident -beta (graph replay: no by-value argument may change)
-  int32_t* fail_host;          // pinned, device-mapped: number of sampler launches that found no valid batch (see k_sample)
+  int32_t* fail_host;          // pinned, device-mapped, two words: [0] sampler launches that found no valid batch (see k_sample),
+                               // [1] priority write-backs dropped because their indices came from such a draw (rb_update_body)
   // host mirror of the deterministic part of the header
   int64_t host_index;
   int32_t host_full;
@@ -56,6 +57,7 @@ static ReplayView view_of(const rb_replay* r) {
   v.tree_start = r->tree_start; v.tree_len = r->tree_len;
   v.tree = r->tree; v.frames = r->frames; v.timestep = r->timestep; v.action = r->action;
   v.reward = r->reward; v.nonterminal = r->nonterminal; v.hdr = r->hdr;
+  v.dropped = r->fail_host ? r->fail_host + 1 : nullptr;
   return v;
 }
 
@@ -449,6 +451,10 @@ __device__ long long g_stamp[32];
 #ifndef RB_HOST_AU_WIDE
 #define RB_HOST_AU_WIDE 4      // quadruples per hosted thread under the 1024-thread variant (5 spills under its 128-register cap)
 #endif
+// learner.hip sizes the pending pass for 4 quadruples per plain thread and 2 (mu, sigma) pairs per pair thread (pair_blk0 and
+// the pair grid in clip_adam_impl); the hosting launch rescales the block count by this constant — any other value would split
+// plain and pair workgroups differently from what the pass expects (parameters skipped or updated twice)
+static_assert(RB_HOST_AU_WIDE == 4, "the hosted optimiser pass is laid out for 4 quadruples per thread (learner.hip clip_adam_impl)");
 template <int MAXT>
 __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batch, float neg_beta_arg, const float* neg_beta_ptr,
                                                const double* unit_uniforms, int32_t max_attempts, uint64_t seed, const float* scaling,
@@ -570,7 +576,8 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
     else RB_WIN(8);                                  //  ... rb_replay_sample refuses batch > 256 with history + multi_step > 24)
 #undef RB_WIN
     nonterminals_out[i] = nt_f;
-    tree_idx_out[i] = leaf;
+    // a draw that gave up marks its own index buffer: the write-back of THIS buffer's batch is dropped (rb_update_body), no other
+    tree_idx_out[i] = ok ? leaf : (int64_t)-1;
   }
   RB_STAMP_AT(4);
   const float w_max = rb_block_max(active ? w : -INFINITY, s_red);
@@ -803,13 +810,13 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_ALLOC(r->scaling_dev, 64 * sizeof(float));
 #undef RB_ALLOC
   {
-    hipError_t e_ = hipHostMalloc((void**)&r->fail_host, sizeof(int32_t), hipHostMallocMapped);
+    hipError_t e_ = hipHostMalloc((void**)&r->fail_host, 2 * sizeof(int32_t), hipHostMallocMapped);
     if (e_ != hipSuccess) {
       rb_set_error("rb_replay_create: hipHostMalloc failed: %s", hipGetErrorString(e_));
       rb_replay_destroy(r);
       return RB_ERR_OOM;
     }
-    *r->fail_host = 0;
+    r->fail_host[0] = 0; r->fail_host[1] = 0;
   }
   // blank_trans everywhere (memory.py:8,19), zero tree (memory.py:18)
   RB_HIP_TRY(hipMemset(r->tree, 0, r->tree_len * sizeof(float)));
@@ -925,9 +932,16 @@ int rb_replay_failed_samples(rb_replay_t* r, int64_t* count) {
   return RB_OK;
 }
 
+int rb_replay_dropped_updates(rb_replay_t* r, int64_t* count) {
+  RB_REQUIRE(r && count, "rb_replay_dropped_updates: NULL argument");
+  *count = (int64_t)*(volatile int32_t*)(r->fail_host + 1);   // pinned host word: no synchronisation
+  return RB_OK;
+}
+
 int rb_replay_reset_failed_samples(rb_replay_t* r) {
   RB_REQUIRE(r != nullptr, "rb_replay_reset_failed_samples: NULL handle");
   *(volatile int32_t*)r->fail_host = 0;        // (a failed launch still in flight re-increments it when it completes)
+  *(volatile int32_t*)(r->fail_host + 1) = 0;
   return RB_OK;
 }
 

@@ -15,6 +15,7 @@ struct ReplayView {
   float* reward;
   uint8_t* nonterminal;
   rb_replay_header_t* hdr;
+  int32_t* dropped;     // pinned host word: write-backs dropped because their indices came from a failed draw (rb_replay_dropped_updates)
 };
 
 
@@ -94,11 +95,16 @@ __device__ __forceinline__ void rb_update_body(ReplayView v, const int64_t* tree
   float* s_red = lds + 8 * HS + NMAX;
   float* s_heap = lds + 8 * HS + NMAX + 16;
   const int i = (int)threadIdx.x;
-  // ReplayMemory.update_priorities after a sampler launch that gave up (no valid batch within max_attempts: the reference
-  // would still be spinning in memory.py:128-132): the tree indices of that draw are NOT a legal batch — a never-written
-  // leaf or one straddling the write head would receive a non-zero priority and defeat the `prob != 0` validity test of
-  // every later draw.  The write-back of such a batch is dropped (block-uniform).
-  if (apply_pow && v.hdr->last_status != 0) return;
+  // ReplayMemory.update_priorities on the indices of a sampler launch that gave up (no valid batch within max_attempts: the
+  // reference would still be spinning in memory.py:128-132): that draw was NOT a legal batch — a never-written leaf or one
+  // straddling the write head would receive a non-zero priority and defeat the `prob != 0` validity test of every later
+  // draw.  The sampler marks such a draw in its OWN index buffer (every tree index -1), so exactly the write-back that
+  // belongs to the failed draw is dropped (block-uniform) and counted; the write-back of an earlier, valid batch still
+  // applies whatever the header's status word says by now.
+  if (apply_pow && tree_idx[0] < 0) {
+    if (threadIdx.x == 0 && v.dropped) rb_atomic_inc_system(v.dropped);
+    return;
+  }
   // dense top: only when the tree is deeper than the top itself (block-uniform)
   const bool dense = v.levels > RB_UPD_TOP;
   const int path_levels = dense ? v.levels - RB_UPD_TOP : v.levels;
@@ -223,9 +229,9 @@ struct UpdateOperand { int node; float val; int status; int sorted; };
 __device__ __forceinline__ UpdateOperand rb_update_load(const ReplayView& v, const int64_t* tree_idx, const float* values, int32_t n) {
   const int lane = (int)(threadIdx.x & 63u);
   UpdateOperand op;
-  op.status = v.hdr->last_status;
   op.node = lane < n ? (int)tree_idx[lane] : -1;
   op.val = lane < n ? values[lane] : 0.0f;
+  op.status = __shfl(op.node, 0, 64) < 0 ? 1 : 0;          // the sampler's mark of a failed draw (see rb_update_body)
   const int before = __shfl(op.node, lane > 0 ? lane - 1 : 0, 64);
   op.sorted = __all(lane == 0 || lane >= n || op.node >= before) ? 1 : 0;
   return op;
@@ -284,7 +290,10 @@ __device__ __forceinline__ void rb_update_sorted_levels(const ReplayView& v, uns
 __device__ __forceinline__ void rb_update_sorted_wave(ReplayView v, const UpdateOperand& op, int32_t n, int32_t apply_pow, double omega,
                                                       float* s_top, int n_top) {
   const int lane = (int)(threadIdx.x & 63u);
-  if (apply_pow && op.status != 0) return;                 // (the draw was not a legal batch: see rb_update_body)
+  if (apply_pow && op.status != 0) {                       // (the draw was not a legal batch: see rb_update_body)
+    if (lane == 0 && v.dropped) rb_atomic_inc_system(v.dropped);
+    return;
+  }
   const bool active = lane < n;
   const unsigned a = active ? (unsigned)op.node + 1u : 1u;
   float sib[RB_MAX_LEVELS];

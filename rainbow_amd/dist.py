@@ -87,15 +87,16 @@ def _create_library_comm(lib, dev):
     loaded: the caller then keeps the collective in torch.distributed)."""
     ident = torch.zeros(128, dtype=torch.uint8, device=dev)
     ok = torch.ones(1, dtype=torch.int32, device=dev)
-    if dist.get_rank() == 0:
-        buf = (C.c_ubyte * 128)()
-        if lib.rb_comm_unique_id(buf) == 0:
-            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-        else:
-            ok.zero_()
-    dist.broadcast(ok, 0)
+    # EVERY rank probes librccl (rb_comm_unique_id resolves it with dlopen) and the flags are reduced before any rank enters
+    # ncclCommInitRank: a rank that cannot load the library must not leave the others blocked inside the collective init
+    buf = (C.c_ubyte * 128)()
+    if lib.rb_comm_unique_id(buf) != 0:
+        ok.zero_()
+    elif dist.get_rank() == 0:
+        ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
-        return None
+        return None       # on all ranks: the collective stays in torch.distributed
     dist.broadcast(ident, 0)
     raw = (C.c_ubyte * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
     comm = C.c_void_p()
@@ -143,6 +144,9 @@ class FactoredExchange:
         if self.h:
             self.lib.rb_learner_set_exchange(self.h, 1, None, None)
             self.h = None
+        if getattr(self, "comm", None):
+            self.lib.rb_comm_destroy(self.comm)
+            self.comm = None
 
     def run(self, stream_handle=None):
         """Call right after rb_learner_learn*: ONE all-gather of the per-rank blocks on the current stream (it follows the

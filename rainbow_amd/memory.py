@@ -64,9 +64,11 @@ class ReplayMemory:
     # step k + 1 are a dependent pair of single-workgroup launches, so the call only records its operands and the next
     # sample_device() issues both as ONE launch (rb_replay_update_sample: bit-identical tree, header and batch).  Anything
     # else that reads or writes the tree — append, the header, state dumps, the raw handle `_h` — applies the pending
-    # write-back first.  numpy operands (the reference's call site, agent.py:100) are copied at the call; DEVICE tensors are
-    # read when the write-back runs: do not overwrite them before the next sample_device() / flush().
+    # write-back first.  Operands are copied at the call — numpy arrays (the reference's call site, agent.py:100) by their
+    # upload, device tensors into a two-slot staging buffer this object owns (_stage_operands) — so the caller may reuse its
+    # loss / index tensors at once, as with the reference's immediate update.
     _pending = None
+    _stage = None
     _handle = None
     _lazy = os.environ.get("RAINBOW_AMD_LAZY_PRIORITIES", "1") != "0"
 
@@ -103,6 +105,7 @@ class ReplayMemory:
         self._seed = int(seed if seed is not None else np.random.randint(0, 2 ** 31 - 1))
         self._lazy = os.environ.get("RAINBOW_AMD_LAZY_PRIORITIES", "1") != "0"
         self._pending = None
+        self._stage = {}
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib, self._lib.rb_replay_create(C.byref(self._h), self.capacity, self.history, self.n,
@@ -192,6 +195,13 @@ class ReplayMemory:
         L.check(self._lib, self._lib.rb_replay_failed_samples(self._handle, C.byref(n)))
         return int(n.value)
 
+    def dropped_updates(self):
+        """Priority write-backs dropped so far because their indices came from a draw that gave up (pinned host word: no
+        synchronisation).  Zeroed by reset_failed_samples()."""
+        n = C.c_int64(0)
+        L.check(self._lib, self._lib.rb_replay_dropped_updates(self._handle, C.byref(n)))
+        return int(n.value)
+
     def reset_failed_samples(self):
         """Zero that counter (the failure has been reported to the caller)."""
         L.check(self._lib, self._lib.rb_replay_reset_failed_samples(self._handle))
@@ -229,6 +239,8 @@ class ReplayMemory:
             stream = self._stream()
         pend = self._pending
         if noise_job is not None:
+            if pend is not None:      # (the noise-carrying launch has no write-back slot: apply it first, in stream order)
+                self.flush()
             rc = self._lib.rb_replay_sample_fused_noise(self._h, key[0], float(self.priority_weight), uu_ptr, attempts, *ptrs,
                                                         C.byref(noise_job), stream)
         elif pend is not None:        # the pending write-back and this draw as one launch
@@ -259,8 +271,26 @@ class ReplayMemory:
         return (tree_idxs, states, o["actions"].clone(), o["returns"].clone(), next_states,
                 o["nonterminals"].clone().unsqueeze(1), o["weights"].clone())
 
-    def update_priorities(self, idxs, priorities):
-        """memory.py:157-159.  Accepts numpy arrays (reference call site agent.py:100) or device tensors."""
+    def _stage_operands(self, idxs, priorities):
+        """The operands of a deferred write-back in memory THIS object owns: `.to()` / `.contiguous()` hand a matching device
+        tensor back as it is, and the reference's semantics are immediate (memory.py:157-159) — a caller may reuse its loss
+        or index tensor right after the call.  Two slots per length, used in turn (the launch that applies a write-back may
+        still be reading slot k when the next call fills slot k + 1); an asynchronous device-to-device copy of <= 3 KB."""
+        n = int(idxs.numel())
+        ring = self._stage.get(n)
+        if ring is None:
+            ring = self._stage[n] = [[torch.empty(n, dtype=torch.int64, device=self.device),
+                                      torch.empty(n, dtype=torch.float32, device=self.device)] for _ in range(2)] + [0]
+        slot = ring[ring[2]]
+        ring[2] ^= 1
+        slot[0].copy_(idxs.reshape(-1), non_blocking=True)
+        slot[1].copy_(priorities.reshape(-1), non_blocking=True)
+        return slot[0], slot[1]
+
+    def update_priorities(self, idxs, priorities, _immediate=False):
+        """memory.py:157-159.  Accepts numpy arrays (reference call site agent.py:100) or device tensors.  By default the
+        write-back is recorded and rides in the next sample_device() launch (RAINBOW_AMD_LAZY_PRIORITIES); its operands are
+        copied at the call, so the caller's tensors are free again when this returns, as in the reference."""
         d = self.device
         if not torch.is_tensor(idxs):
             idxs = torch.as_tensor(np.asarray(idxs, dtype=np.int64))
@@ -268,11 +298,18 @@ class ReplayMemory:
             priorities = torch.as_tensor(np.asarray(priorities, dtype=np.float32))
         if self._pending is not None:
             self.flush()
+        lazy = self._lazy and not _immediate and not torch.cuda.is_current_stream_capturing()
+        if lazy:
+            own_i = idxs.device != d or idxs.dtype != torch.int64 or not idxs.is_contiguous()
+            own_p = priorities.device != d or priorities.dtype != torch.float32 or not priorities.is_contiguous()
+            i_d = idxs.to(device=d, dtype=torch.int64).contiguous()
+            p_d = priorities.to(device=d, dtype=torch.float32).contiguous()
+            if not (own_i and own_p):       # at least one operand is still the caller's own device tensor
+                i_d, p_d = self._stage_operands(i_d, p_d)
+            self._upd = self._pending = (i_d, p_d)
+            return
         self._upd = (idxs.to(device=d, dtype=torch.int64).contiguous(),
                      priorities.to(device=d, dtype=torch.float32).contiguous())
-        if self._lazy and not torch.cuda.is_current_stream_capturing():
-            self._pending = self._upd
-            return
         L.check(self._lib, self._lib.rb_replay_update_priorities(self._handle, self._upd[0].data_ptr(),
                                                                  self._upd[1].data_ptr(), int(self._upd[0].numel()),
                                                                  self._stream()))
@@ -403,7 +440,7 @@ class ReplayMemory:
     def __getstate__(self):
         dump = self._dump()       # (applies a pending priority write-back first)
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("_lib", "_h", "_handle", "_pending", "_applied", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev",
+              if k not in ("_lib", "_h", "_handle", "_pending", "_applied", "_stage", "transitions", "_out", "_uu", "_upd", "_neg_beta_dev",
                            "_neg_beta_val", "_bufs", "_idx_keep")}
         st["device"] = str(self.device)
         st["_dump"] = dump
@@ -429,5 +466,7 @@ class ReplayMemory:
         self.transitions = _TransitionsView(self)
         self._out = {}
         self._ptr_cache = {}
+        self._pending = None
+        self._stage = {}
         self._init_beta_source()
         self._header()   # resynchronise the library's host mirror of index/full

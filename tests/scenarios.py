@@ -277,6 +277,10 @@ def sampler_gives_up_check(lib, mem):
     L.check(lib, lib.rb_replay_update_priorities(ad.h, mem.ptr(outs["tree_idx"]), mem.ptr(losses), B, mem.stream))
     mem.sync()
     assert np.array_equal(ad.tree(), tree0), "update_priorities after a failed draw changed the sum-tree"
+    nd = C.c_int64(-1)
+    L.check(lib, lib.rb_replay_dropped_updates(ad.h, C.byref(nd)))
+    assert nd.value == 1, "the dropped write-back was not counted"
+    assert np.array_equal(mem.download(outs["tree_idx"]), np.full(B, -1, np.int64)), "a failed draw must mark its index buffer"
     # (b) a learner whose priority sink is this replay skips the fused write-back, the optimiser update and the
     # device-resident step number (Adam's momentum would otherwise move the parameters on a zero gradient)
     from cabi_adapter import CAbiLearnAdapter
@@ -314,6 +318,67 @@ def sampler_gives_up_check(lib, mem):
     L.check(lib, lib.rb_replay_position(ad.h, C.byref(idx), C.byref(full)))
     assert (idx.value, full.value) == (0, 1)
     return ad
+
+
+def earlier_valid_batch_survives_failed_draw_check(lib, mem):
+    """update_priorities of an EARLIER, valid batch after a LATER draw gave up (memory.py:157-159 has no notion of a failed draw:
+    the reference would still be spinning in memory.py:128-132).  Only the write-back whose indices the failed draw itself
+    produced is dropped (its index buffer is marked, rb_replay_dropped_updates counts it); the valid batch's priorities land in
+    the tree exactly as the oracle's SumTree puts them, although the header's status word says 'failed' by then.  Both the
+    one-wave sorted path (rb_replay_update_priorities, n <= 64) and the fused update + sample launch are exercised."""
+    import ctypes as C
+    from cabi_adapter import CAbiReplayAdapter
+    from oracle.replay_oracle import ReplayOracle
+    from rainbow_amd import _lib as L
+    cap, h, n = 32, 4, 3
+    ad = CAbiReplayAdapter(lib, mem, cap, h, n, 0.99, 0.5)
+    ora = ReplayOracle(cap, history=h, discount=0.99, multi_step=n, priority_weight=0.5, priority_exponent=0.5)
+    rs = np.random.RandomState(4)
+    for _ in range(cap + 5):
+        st = synth_state(rs, h, 0)
+        ad.append(st, 1, 0.0, False)
+        ora.append(st, 1, 0.0, False)
+    uu2 = rs.random_sample((32, 2))
+    good = ad.sample(2, uu2, 0.5)                         # two strata of 16 leaves: a valid batch exists (asserted inside)
+    want = ora.sample_with_uniforms(2, uu2)
+    assert np.array_equal(good["tree_idxs"], want["tree_idxs"])
+    B, attempts = 8, 6                                    # eight strata of 4 leaves: one lies inside the write head's zone
+    outs = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
+                nonterm=mem.empty((B,), np.float32), weights=mem.empty((B,), np.float32))
+    uu8 = mem.upload(rs.random_sample((attempts, B)))
+
+    def failing_draw():
+        L.check(lib, lib.rb_replay_sample(ad.h, B, 0.5, mem.ptr(uu8), attempts, mem.ptr(outs["tree_idx"]), None, None,
+                                          mem.ptr(outs["actions"]), mem.ptr(outs["returns"]), mem.ptr(outs["nonterm"]),
+                                          mem.ptr(outs["weights"]), mem.stream))
+        mem.sync()
+        assert ad.raw_header().last_status == 1
+        assert np.array_equal(mem.download(outs["tree_idx"]), np.full(B, -1, np.int64))
+
+    failing_draw()
+    loss = np.array([2.5, 0.7], np.float32)
+    ad.update_priorities(good["tree_idxs"], loss)         # the EARLIER valid batch: applied
+    ora.update_priorities(want["tree_idxs"], loss)
+    np.testing.assert_allclose(ad.tree(), ora.transitions.tree, rtol=4e-7)
+    nd = C.c_int64(-1)
+    L.check(lib, lib.rb_replay_dropped_updates(ad.h, C.byref(nd)))
+    assert nd.value == 0
+    tree1 = ad.tree()
+    bad = mem.upload(np.full(B, 1.5, np.float32))          # the failed draw's own buffer: dropped and counted
+    L.check(lib, lib.rb_replay_update_priorities(ad.h, mem.ptr(outs["tree_idx"]), mem.ptr(bad), B, mem.stream))
+    mem.sync()
+    assert np.array_equal(ad.tree(), tree1)
+    L.check(lib, lib.rb_replay_dropped_updates(ad.h, C.byref(nd)))
+    assert nd.value == 1
+    # the same through the fused update + sample launch (the draw inside it fails again; the update in front of it applies)
+    loss2 = np.array([0.3, 4.0], np.float32)
+    ad.update_sample(good["tree_idxs"], loss2, B, rs.random_sample((attempts, B)), 0.5, check_status=False)
+    ora.update_priorities(want["tree_idxs"], loss2)
+    np.testing.assert_allclose(ad.tree(), ora.transitions.tree, rtol=4e-7)
+    assert ad.raw_header().last_status == 1
+    L.check(lib, lib.rb_replay_dropped_updates(ad.h, C.byref(nd)))
+    assert nd.value == 1
+    ad.close()
 
 
 def update_sample_twin_check(make_adapter, capacity=6000, history=4, n=3, rounds=6, seed=11):

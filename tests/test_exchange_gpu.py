@@ -1,5 +1,6 @@
-"""GPU parity of BASELINE config 5's exchange kernels on ONE device (no RCCL needed): two learner handles stand for two
-replicas (own batch, own noise, identical parameters); the collectives are replaced by device-side copies — a torch.cat
+"""GPU parity of BASELINE config 5's exchange kernels on ONE device (no RCCL needed): N learner handles stand for N
+replicas (own batch, own noise, identical parameters) — N = 2, and N = 8 = config 5's world size (M = 8 x 32 = 256 gathered
+rows, scale 1/8, the 8-block rank-order fold of k_finish_grads); the collectives are replaced by device-side copies — a torch.cat
 for the all-gather of the per-rank blocks, an elementwise mean for the flat all-reduce — so that what runs on the GPU is exactly
 rb_learner_learn with the exchange armed (k_pack_factors, deferred FC weight gradients), rb_learner_finish_grads
 (k_finish_grads) and, in the 'allreduce' mode, rb_learner_grads_modified -> k_sumsq, followed by the one-pass clip + Adam.
@@ -27,8 +28,8 @@ def hip():
     return _lib.load()
 
 
-class PairFactoredExchange:
-    """What rainbow_amd.dist.FactoredExchange does per rank, for two handles in one process."""
+class LocalFactoredExchange:
+    """What rainbow_amd.dist.FactoredExchange does per rank, for N handles in one process."""
 
     def __init__(self, lib, ads):
         from rainbow_amd import _lib as L
@@ -56,19 +57,20 @@ class PairFactoredExchange:
 
 
 @pytest.mark.parametrize("mode", ["factored", "allreduce"])
-@pytest.mark.parametrize("shape", SHAPES)
-def test_replica_exchange_kernels_match_oracle_on_mean_gradient(hip, monkeypatch, shape, mode):
+@pytest.mark.parametrize("shape,world", [(SHAPES[0], 2), (SHAPES[1], 2), (SHAPES[0], 8)],
+                         ids=[SHAPES[0] + "-world2", SHAPES[1] + "-world2", SHAPES[0] + "-world8"])
+def test_replica_exchange_kernels_match_oracle_on_mean_gradient(hip, monkeypatch, shape, world, mode):
     from cabi_adapter import CAbiLearnAdapter, TorchMem
     from rainbow_amd import _lib as L
     cfgd = BASELINE_SHAPES[shape]
     monkeypatch.setitem(scenarios.LEARN_CONFIGS, shape, cfgd)
     cfg = O.Config(**cfgd)
     hy = scenarios.LEARN_HYPER
-    ads = [CAbiLearnAdapter(hip, TorchMem(), shape) for _ in range(2)]
+    ads = [CAbiLearnAdapter(hip, TorchMem(), shape) for _ in range(world)]
     online, target = O.init_params(cfg, 611), O.init_params(cfg, 612)
     for ad in ads:
         ad.load(online, target)
-    exch = PairFactoredExchange(hip, ads) if mode == "factored" else None
+    exch = LocalFactoredExchange(hip, ads) if mode == "factored" else None
     adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
     draws = O.noise_draw_count(cfg)
     got_t, want_t = {}, {}
@@ -84,27 +86,32 @@ def test_replica_exchange_kernels_match_oracle_on_mean_gradient(hip, monkeypatch
         if exch is not None:
             exch.run()
         else:
-            mean = (ads[0].grads + ads[1].grads) / 2                     # the flat all-reduce (mean)
+            mean = ads[0].grads.clone()                                  # the flat all-reduce (mean), rank order
+            for ad in ads[1:]:
+                mean += ad.grads
+            mean /= world
             for ad in ads:
                 ad.grads.copy_(mean)
                 L.check(hip, hip.rb_learner_grads_modified(ad.h))
         outs = [ad.finish_step() for ad in ads]
         # replicas: identical bits
-        assert torch.equal(ads[0].grads, ads[1].grads), "step %d: replica gradients differ" % k
-        assert torch.equal(ads[0].p_on.detach(), ads[1].p_on.detach()), "step %d: replica parameters differ" % k
-        assert outs[0]["grad_norm"] == outs[1]["grad_norm"]
+        for r in range(1, world):
+            assert torch.equal(ads[0].grads, ads[r].grads), "step %d: gradients of replica %d differ" % (k, r)
+            assert torch.equal(ads[0].p_on.detach(), ads[r].p_on.detach()), "step %d: parameters of replica %d differ" % (k, r)
+            assert outs[0]["grad_norm"] == outs[r]["grad_norm"]
         # oracle on the mean gradient
-        gmean = {n: (per_rank[0]["grads"][n] + per_rank[1]["grads"][n]) / np.float32(2) for n in per_rank[0]["grads"]}
+        gmean = {n: sum(pr["grads"][n].astype(np.float64) for pr in per_rank).astype(np.float32) / np.float32(world)
+                 for n in per_rank[0]["grads"]}
         total, clipped = O.clip_grads(gmean, hy["norm_clip"])
         online = adam.step(clipped)
-        for r in range(2):
+        for r in range(world):
             got_t["s%d_r%d_loss" % (k, r)], want_t["s%d_r%d_loss" % (k, r)] = outs[r]["loss"], per_rank[r]["loss"]
         got_t["s%d_grad_norm" % k], want_t["s%d_grad_norm" % k] = np.float32(outs[0]["grad_norm"]), np.float32(total)
         for name in clipped:
             got_t["s%d_grad/%s" % (k, name)], want_t["s%d_grad/%s" % (k, name)] = outs[0]["grads"][name], clipped[name]
         for name, p in ads[0].params().items():
             got_t["s%d_param/%s" % (k, name)], want_t["s%d_param/%s" % (k, name)] = p, online[name]
-    assert_learn_trace_matches(got_t, want_t, label="exchange-%s/%s" % (mode, shape))
+    assert_learn_trace_matches(got_t, want_t, label="exchange-%s/%s/world%d" % (mode, shape, world))
     if exch is not None:
         exch.close()
     for ad in ads:

@@ -585,3 +585,64 @@ def test_large_batch_fc_backward_matches_oracle(emu, monkeypatch):
         scale = float(np.max(np.abs(g))) if g.size else 0.0
         np.testing.assert_allclose(got["grads"][k], g, rtol=2e-4, atol=5e-6 * scale + 1e-9, err_msg=k)
     ad.close()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_replica_exchange_kernels_fold_more_than_two_blocks(emu, world):
+    """The replica exchange of SURVEY 8(e) (insert point agent.py:96-97) with MORE than two replicas on the host interpreter:
+    `world` learner handles with their own batch and noise, k_pack_factors in every learn call, a host concatenation for the
+    all-gather, k_finish_grads folding `world` blocks in rank order (M = world x B gathered rows, scale 1 / world), then
+    clip + Adam: every handle bit-identical, gradients and parameters == the oracle fed with the mean of the `world`
+    gradients.  (World 8 — BASELINE config 5 — runs at the canonical H = 512 / B = 32 shape on the GPU, tests/test_exchange_gpu.py.)"""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    name = "dataeff"
+    cfgd = scenarios.LEARN_CONFIGS[name]
+    cfg = O.Config(**cfgd)
+    hy = scenarios.LEARN_HYPER
+    ads = [CAbiLearnAdapter(emu, NumpyMem(), name) for _ in range(world)]
+    online, target = O.init_params(cfg, 811), O.init_params(cfg, 812)
+    for ad in ads:
+        ad.load(online, target)
+    f = C.c_int64(0)
+    L.check(emu, emu.rb_learner_exchange_layout(ads[0].h, C.byref(f), None, None))
+    local = [np.zeros(f.value, dtype=np.float32) for _ in ads]
+    gathered = [np.zeros(world * f.value, dtype=np.float32) for _ in ads]
+    for ad, lo, al in zip(ads, local, gathered):
+        L.check(emu, emu.rb_learner_set_exchange(ad.h, world, lo.ctypes.data, al.ctypes.data))
+    adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
+    draws = O.noise_draw_count(cfg)
+    got_t, want_t = {}, {}
+    for k in range(2):
+        per_rank = []
+        for r, ad in enumerate(ads):
+            rs = np.random.RandomState(500 + 10 * k + r)
+            raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+            batch = scenarios.make_batch(cfgd, 600 + 10 * k + r)
+            ad.reset_noise_online(raw_on)
+            ad.learn_only(batch, raw_tg)
+            per_rank.append(O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch))
+        cat = np.concatenate(local)
+        for ad, al in zip(ads, gathered):
+            al[:] = cat
+            L.check(emu, emu.rb_learner_finish_grads(ad.h, None))
+        outs = [ad.finish_step() for ad in ads]
+        for r in range(1, world):
+            assert np.array_equal(ads[0].grads, ads[r].grads), "step %d: gradients of replica %d differ" % (k, r)
+            assert np.array_equal(ads[0].params()["fc_h_v.weight_mu"], ads[r].params()["fc_h_v.weight_mu"])
+            assert outs[0]["grad_norm"] == outs[r]["grad_norm"]
+        gmean = {n: sum(pr["grads"][n].astype(np.float64) for pr in per_rank).astype(np.float32) / np.float32(world)
+                 for n in per_rank[0]["grads"]}
+        total, clipped = O.clip_grads(gmean, hy["norm_clip"])
+        online = adam.step(clipped)
+        got_t["s%d_grad_norm" % k], want_t["s%d_grad_norm" % k] = np.float32(outs[0]["grad_norm"]), np.float32(total)
+        for r in range(world):
+            got_t["s%d_r%d_loss" % (k, r)], want_t["s%d_r%d_loss" % (k, r)] = outs[r]["loss"], per_rank[r]["loss"]
+        for n in clipped:
+            got_t["s%d_grad/%s" % (k, n)], want_t["s%d_grad/%s" % (k, n)] = outs[0]["grads"][n], clipped[n]
+        for n, p in ads[0].params().items():
+            got_t["s%d_param/%s" % (k, n)], want_t["s%d_param/%s" % (k, n)] = p, online[n]
+    assert_learn_trace_matches(got_t, want_t, label="exchange-emu/world%d" % world)
+    for ad in ads:
+        emu.rb_learner_set_exchange(ad.h, 1, None, None)
+        ad.close()

@@ -148,6 +148,103 @@ def test_agent_and_memory_classes_end_to_end_vs_oracle(hip, tmp_path, hidden, ba
             assert torch.equal(v.cpu(), sd[k]), k
 
 
+AGENT_SHAPES = {
+    # name: (architecture, hidden, batch, actions, multi_step, replay capacity, appends)
+    "baseline-cfg2-h512-b32-a6": ("canonical", 512, 32, 6, 3, 4096, 6000),
+    "baseline-cfg3-h512-b256-a4": ("canonical", 512, 256, 4, 3, 8192, 12000),
+    "baseline-cfg4-dataeff-h256-n20": ("data-efficient", 256, 32, 6, 20, 16384, 20000),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(AGENT_SHAPES))
+def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape):
+    """The EXACT configuration bench.py times at BASELINE configs 2, 3 and 4, against the oracle (agent.py:61-100,
+    memory.py:124-159): `Agent` with its defaults — RB_LEARNER_DEFER_UPDATE (+ RB_LEARNER_IMPLICIT_SIGMA where the hidden
+    layer is large enough) — so that the clip + Adam pass of learn call k runs as tenant workgroups of call k + 1's SAMPLER
+    launch (k_sample<1024, 4> hosting the paired (mu, sigma) optimiser body; 256 samples at config 3, where the backward is
+    k_fc_gemm_bwd with the implicit sigma gradient; 24-slot windows at config 4, the hosting limit), zero-copy frames, fused
+    priority write-back.  Sampler uniforms and both nets' noise are injected (the injected target draw overwrites the
+    device-RNG draw the hosting launch carries).  Six consecutive learn() calls with one update_target_net():
+    per-sample loss and tree indices at every step; the parameters and the norm of step k are read RAW (no flush) after
+    call k + 1 has hosted that step's pass — reading them through the public names would run the pass as a launch of its
+    own and the hosted path would never be exercised; the tree at the end."""
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+    arch, hidden, B, A, n, cap, appends = AGENT_SHAPES[shape]
+    args = _args(architecture=arch, hidden_size=hidden, batch_size=B, multi_step=n)
+    env = types.SimpleNamespace(action_space=lambda: A)
+    torch.manual_seed(5)
+    agent = Agent(args, env)
+    assert agent._defer_update and agent._step_dev is not None
+    mem = ReplayMemory(args, cap, seed=13)
+    ora_mem = ReplayOracle(cap, multi_step=n)
+    rs = np.random.RandomState(31)
+    pool = rs.randint(0, 256, size=(64, 84, 84)).astype(np.uint8)
+    term = rs.random_sample(appends) < 0.01
+    ts = np.zeros(appends, dtype=np.int32)
+    t = 0
+    for i in range(appends):
+        ts[i] = t
+        t = 0 if term[i] else t + 1
+    acts = rs.randint(0, A, appends)
+    rews = rs.choice([-1.0, 0.0, 1.0], size=appends).astype(np.float32)
+    fidx = rs.randint(0, 64, appends)
+    for lo in range(0, appends, 2000):
+        hi = min(appends, lo + 2000)
+        mem.append_batch(torch.from_numpy(pool[fidx[lo:hi]]).cuda(), acts[lo:hi], rews[lo:hi], term[lo:hi])
+    for i in range(appends):
+        ora_mem.append_frame(pool[fidx[i]], int(acts[i]), float(rews[i]), bool(term[i]))
+    cfg = O.Config(batch=B, atoms=51, actions=A, history=4, hidden=hidden, architecture=arch, multi_step=n)
+    online = {k: v.cpu().numpy() for k, v in agent.state_dict().items() if "epsilon" not in k}
+    target = {k: v.copy() for k, v in online.items()}
+    adam = O.AdamOracle(online, args.learning_rate, args.adam_eps)
+    draws = O.noise_draw_count(cfg)
+
+    def raw_params():      # the borrowed flat buffer as it is NOW (a pending pass is NOT run)
+        torch.cuda.synchronize()
+        return {name: agent._view(agent._params, name).cpu().numpy() for name, _o, _s in agent._layout}
+
+    hosted = 0
+    prev = None            # (oracle parameters, oracle norm) after the previous step
+    steps = 6
+    for step in range(steps):
+        raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
+        uu = rs.random_sample((64, B))
+        beta = 0.4 + 0.05 * step
+        mem.priority_weight = beta
+        ora_mem.priority_weight = beta
+        agent.reset_noise(torch.from_numpy(raw_on))
+        was_pending = agent._update_pending
+        agent.learn(mem, _target_raw_normals=torch.from_numpy(raw_tg), _unit_uniforms=torch.from_numpy(uu))
+        if was_pending:
+            assert agent._update_pending, "step %d" % step
+            hosted += 1
+            got = raw_params()      # = the parameters after step - 1's update, which this call's sampler launch hosted
+            for k in prev[0]:
+                np.testing.assert_allclose(got[k], prev[0][k], rtol=0, atol=3e-7, err_msg="hosted pass of step %d: %s" % (step - 1, k))
+            np.testing.assert_allclose(float(agent._norm_buf.item()), prev[1], rtol=2e-5)
+        batch = ora_mem.sample_with_uniforms(B, uu)
+        want = O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch)
+        total, clipped = O.clip_grads(want["grads"], args.norm_clip)
+        online = adam.step(clipped)
+        ora_mem.update_priorities(batch["tree_idxs"], want["loss"])
+        prev = ({k: v.copy() for k, v in online.items()}, total)
+        torch.cuda.synchronize()
+        assert np.array_equal(mem._out[B]["tree_idxs"].cpu().numpy(), batch["tree_idxs"]), "step %d" % step
+        np.testing.assert_allclose(agent._loss.cpu().numpy(), want["loss"], rtol=2e-5, atol=1e-6, err_msg="step %d" % step)
+        if step == 2:      # update_target_net runs the pending pass as a launch of its own (every entry point does)
+            agent.update_target_net()
+            target = {k: v.copy() for k, v in online.items()}
+            agent._update_pending = False
+    assert hosted >= 4, hosted
+    got = {k: v.cpu().numpy() for k, v in agent.state_dict().items() if "epsilon" not in k}      # (flushes the last pass)
+    for k in online:
+        np.testing.assert_allclose(got[k], online[k], rtol=0, atol=3e-7, err_msg="final %s" % k)
+    np.testing.assert_allclose(float(agent._norm.item()), prev[1], rtol=2e-5)
+    np.testing.assert_allclose(mem._dump()["tree"], ora_mem.transitions.tree, rtol=2e-5)
+    assert int(agent.optimiser.state_dict()["state"][0]["step"]) == steps
+
+
 def test_compat_path_with_foreign_replay(hip):
     """Agent.learn(mem) with a replay object that only offers the reference's sample()/update_priorities()."""
     from rainbow_amd.agent import Agent

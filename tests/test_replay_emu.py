@@ -151,6 +151,11 @@ def test_create_rejects_what_the_reference_cannot_run(emu):
         L.check(emu, emu.rb_replay_create(C.byref(C.c_void_p()), 501, 4, 3, 0.99, 0.5, 1))
 
 
+def test_earlier_valid_batch_survives_a_failed_draw(emu):
+    """scenarios.earlier_valid_batch_survives_failed_draw_check on the host interpreter (the GPU runs the same check)."""
+    scenarios.earlier_valid_batch_survives_failed_draw_check(emu, NumpyMem())
+
+
 def test_sampler_gives_up_harmlessly(emu):
     """scenarios.sampler_gives_up_check on the host interpreter (the same check runs on the GPU in test_replay_gpu.py), plus:
     the host mirror of the write position follows a raw header restore."""

@@ -38,6 +38,13 @@ def test_sampler_gives_up_harmlessly_on_device(hip):
     scenarios.sampler_gives_up_check(hip, TorchMem()).close()
 
 
+def test_earlier_valid_batch_survives_a_failed_draw_on_device(hip):
+    """update_priorities of an earlier valid batch after a later draw gave up is APPLIED (== the oracle's tree); only the
+    write-back on the failed draw's own (marked) index buffer is dropped and counted (rb_replay_dropped_updates)."""
+    from cabi_adapter import TorchMem
+    scenarios.earlier_valid_batch_survives_failed_draw_check(hip, TorchMem())
+
+
 def _args(**kw):
     base = dict(device=torch.device("cuda:0"), history_length=4, discount=0.99, multi_step=3, priority_weight=0.4,
                 priority_exponent=0.5)
@@ -99,7 +106,12 @@ def test_lazy_update_priorities_equals_immediate(hip, monkeypatch):
             lazy.update_priorities(ol["tree_idxs"].cpu().numpy(), loss.cpu().numpy())
         else:
             eager.update_priorities(oe["tree_idxs"], loss)
-            lazy.update_priorities(ol["tree_idxs"], loss)
+            # the reference's update is immediate (memory.py:157-159): a caller may reuse its tensors as soon as the call
+            # returns.  The lazy write-back therefore keeps its own copy of device operands — overwrite the caller's at once
+            idx_l, loss_l = ol["tree_idxs"].clone(), loss.clone()
+            lazy.update_priorities(idx_l, loss_l)
+            loss_l.fill_(77.0)
+            idx_l.zero_()
         assert lazy._pending is not None and eager._pending is None
         if r == 1:             # an append in between applies the pending write-back first (it rewrites leaves and ancestors)
             for m in (eager, lazy):
