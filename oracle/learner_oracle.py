@@ -125,14 +125,18 @@ def noisy_linear(x, params, layer, noise):
     return x @ w.t() + b
 
 
-def forward(cfg, params, noise, x, log=False):
-    """DQN.forward (model.py:69-80).  x float32 [B,h,84,84] in [0,1]; params: torch tensors."""
+def forward(cfg, params, noise, x, log=False, probe=None):
+    """DQN.forward (model.py:69-80).  x float32 [B,h,84,84] in [0,1]; params: torch tensors.
+    probe (optional dict): receives 'hidden_relu_margin' = the smallest |pre-activation| of the two hidden layers (see learn)."""
     convs, feat = cfg.convs
     for i, (_c, _k, stride) in enumerate(convs):
         x = F.relu(F.conv2d(x, params["convs.%d.weight" % (2 * i)], params["convs.%d.bias" % (2 * i)], stride=stride))
     x = x.reshape(-1, feat)                                                    # model.py:71
-    v = noisy_linear(F.relu(noisy_linear(x, params, "fc_h_v", noise)), params, "fc_z_v", noise)   # model.py:72
-    a = noisy_linear(F.relu(noisy_linear(x, params, "fc_h_a", noise)), params, "fc_z_a", noise)   # model.py:73
+    pre_v, pre_a = noisy_linear(x, params, "fc_h_v", noise), noisy_linear(x, params, "fc_h_a", noise)
+    if probe is not None:
+        probe["hidden_relu_margin"] = float(torch.minimum(pre_v.detach().abs().min(), pre_a.detach().abs().min()))
+    v = noisy_linear(F.relu(pre_v), params, "fc_z_v", noise)                   # model.py:72
+    a = noisy_linear(F.relu(pre_a), params, "fc_z_a", noise)                   # model.py:73
     v = v.reshape(-1, 1, cfg.atoms)
     a = a.reshape(-1, cfg.actions, cfg.atoms)
     q = v + a - a.mean(1, keepdim=True)                                        # model.py:75
@@ -168,7 +172,12 @@ def learn(cfg, online, target, noise_online, noise_target, batch):
     """Agent.learn up to and including backward (agent.py:63-96).
     online/target: {name: np.float32 array}; batch: dict(states u8[B,h,84,84], next_states u8,
     actions i64[B], returns f32[B], nonterminals f32[B] or [B,1], weights f32[B]).
-    Returns numpy results incl. UNCLIPPED gradients."""
+    Returns numpy results incl. UNCLIPPED gradients, and `hidden_relu_margin`: the smallest |pre-activation| of the two
+    hidden layers in the forward that is differentiated.  relu'(x) is a step at 0: where a pre-activation (a 3136-term f32 dot
+    product, rounding noise ~1e-7) is closer to zero than that noise, its SIGN — and with it one sample's whole contribution
+    to that unit's gradients, up to 1/B of their magnitude — depends on the summation order; the reference itself (model.py:72-73,
+    torch's GEMM blocking) is only defined up to that order there.  Parity tests on fixed seeds require a margin above the
+    noise so that a gradient mismatch can never be this discontinuity."""
     B = batch["states"].shape[0]
     p_on = {k: _t(v).clone().requires_grad_(True) for k, v in online.items()}
     p_tg = {k: _t(v) for k, v in target.items()}
@@ -179,7 +188,8 @@ def learn(cfg, online, target, noise_online, noise_target, batch):
     nonterminals = _t(batch["nonterminals"]).to(torch.float32).reshape(B)
     weights = _t(batch["weights"]).to(torch.float32)
 
-    log_ps = forward(cfg, p_on, noise_online, states, log=True)                # agent.py:66
+    probe = {}
+    log_ps = forward(cfg, p_on, noise_online, states, log=True, probe=probe)   # agent.py:66
     log_ps_a = log_ps[torch.arange(B), actions]                                # agent.py:67
     with torch.no_grad():
         pns = forward(cfg, p_on, noise_online, next_states)                    # agent.py:71
@@ -192,7 +202,7 @@ def learn(cfg, online, target, noise_online, noise_target, batch):
     grads = {k: v.grad.numpy().copy() for k, v in p_on.items()}
     return dict(loss=loss.detach().numpy().copy(), m=m.numpy().copy(), a_star=a_star.numpy().copy(),
                 pns_a=pns_a.numpy().copy(), log_ps_a=log_ps_a.detach().numpy().copy(), grads=grads,
-                l=l.numpy().copy(), u=u.numpy().copy())
+                l=l.numpy().copy(), u=u.numpy().copy(), hidden_relu_margin=probe["hidden_relu_margin"])
 
 
 def clip_grads(grads, max_norm):

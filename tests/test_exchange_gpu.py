@@ -74,15 +74,20 @@ def test_replica_exchange_kernels_match_oracle_on_mean_gradient(hip, monkeypatch
     adam = O.AdamOracle(online, hy["lr"], hy["adam_eps"])
     draws = O.noise_draw_count(cfg)
     got_t, want_t = {}, {}
+    # (world 8's sixteen learn calls on the world-2 seeds contain one ill-conditioned batch — rank 6 of step 1: a hidden
+    # pre-activation of +2.8e-9 in the f32 oracle, -8.1e-10 in float64 — where relu'(x) and with it 4 % of that unit's
+    # gradients depend on the summation order, oracle.learner_oracle.learn; its seeds start at 1000, and the margin is asserted)
+    base = 0 if world == 2 else 1000
     for k in range(2):
         per_rank = []
         for r, ad in enumerate(ads):
-            rs = np.random.RandomState(100 + 10 * k + r)                 # per-replica noise and data
+            rs = np.random.RandomState(base + 100 + 10 * k + r)          # per-replica noise and data
             raw_on, raw_tg = rs.randn(draws).astype(np.float32), rs.randn(draws).astype(np.float32)
-            batch = scenarios.make_batch(cfgd, 200 + 10 * k + r)
+            batch = scenarios.make_batch(cfgd, base + 200 + 10 * k + r)
             ad.reset_noise_online(raw_on)
             ad.learn_only(batch, raw_tg)
             per_rank.append(O.learn(cfg, online, target, O.make_noise(cfg, raw_on), O.make_noise(cfg, raw_tg), batch))
+            assert per_rank[-1]["hidden_relu_margin"] > 3e-8, "ill-conditioned seed (step %d rank %d)" % (k, r)
         if exch is not None:
             exch.run()
         else:
