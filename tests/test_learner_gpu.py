@@ -200,6 +200,16 @@ def agent_shape_oracle(shape, online, args, inp=None):
     return out, ora_mem.transitions.tree
 
 
+def _assert_params_track(got, want, atol, flip_atol, flip_frac, msg):
+    """Post-Adam parameters: every element within `atol`, except that a fraction `flip_frac` of a tensor's elements may deviate up
+    to `flip_atol` (batch 256 only, see the test's docstring; flip_frac = 0 is a plain absolute tolerance)."""
+    d = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
+    bad = d > atol
+    assert float(d.max()) <= flip_atol and int(bad.sum()) <= int(flip_frac * d.size), \
+        "%s: %d / %d elements beyond %.1e (allowed %d), largest %.3e (allowed %.1e)" % (
+            msg, int(bad.sum()), d.size, atol, int(flip_frac * d.size), float(d.max()), flip_atol)
+
+
 @pytest.mark.parametrize("shape", sorted(AGENT_SHAPES))
 def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape):
     """The EXACT configuration bench.py times at BASELINE configs 2, 3 and 4, against the oracle (agent.py:61-100,
@@ -212,14 +222,17 @@ def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape)
     per-sample loss and tree indices at every step; the parameters and the norm of step k are read RAW (no flush) after
     call k + 1 has hosted that step's pass — reading them through the public names would run the pass as a launch of its
     own and the hosted path would never be exercised; the tree at the end.
-    Parameter tolerance: 3e-7 absolute at batch 32 (as the two-step tests); 1.5e-6 at batch 256 over six steps — there every
-    step flips a few of its 10^7 conv ReLU masks against the oracle's summation order, a 1e-4-relative wobble of the
-    smallest gradient elements that Adam's g / (sqrt(v) + eps) turns into up to 2 % of lr = 6.25e-5 (0.1 % of the elements
-    of one conv tensor exceeded 3e-7, largest 5.9e-7); a wrong or missing update is >= lr."""
+    Parameter tolerance: 3e-7 absolute at batch 32 (as the two-step tests).  Batch 256, six steps: 1.5e-6, and up to 0.5 % of a
+    tensor's elements may reach 6e-6 (a tenth of lr = 6.25e-5).  Why: the hidden layer there is a split-K GEMM whose
+    pre-activations carry ~5e-8 of summation-order noise, and the smallest |pre-activation| among a step's 262 144 is ~3e-8 on any
+    seed, so every few steps one (sample, unit) ReLU mask differs from the oracle's; that moves the unit's bias and weight
+    gradients by 1/256 of one sample's share, and where the gradient itself nearly cancels, Adam's g / (sqrt(v) + eps) turns
+    it into a few per cent of lr (seen: 1 of 512 elements of fc_h_a.bias_mu at 2.1e-6, 33 of 32 768 of a conv weight at 5.9e-7).
+    A missing or doubled pass moves every element by ~lr."""
     from rainbow_amd.agent import Agent
     from rainbow_amd.memory import ReplayMemory
     arch, hidden, B, A, n, cap, appends, _seed = AGENT_SHAPES[shape]
-    p_atol = 3e-7 if B <= 32 else 1.5e-6
+    p_atol, flip_atol, flip_frac = (3e-7, 3e-7, 0.0) if B <= 32 else (1.5e-6, 6e-6, 0.005)
     args = _args(architecture=arch, hidden_size=hidden, batch_size=B, multi_step=n)
     env = types.SimpleNamespace(action_space=lambda: A)
     torch.manual_seed(5)
@@ -254,8 +267,7 @@ def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape)
             got = raw_params()      # = the parameters after step - 1's update, which this call's sampler launch hosted
             prev = want[step - 1]
             for k in prev["params"]:
-                np.testing.assert_allclose(got[k], prev["params"][k], rtol=0, atol=p_atol,
-                                           err_msg="hosted pass of step %d: %s" % (step - 1, k))
+                _assert_params_track(got[k], prev["params"][k], p_atol, flip_atol, flip_frac, "hosted pass of step %d: %s" % (step - 1, k))
             np.testing.assert_allclose(float(agent._norm_buf.item()), prev["norm"], rtol=5e-5)
         torch.cuda.synchronize()
         assert np.array_equal(mem._out[B]["tree_idxs"].cpu().numpy(), want[step]["tree_idxs"]), "step %d" % step
@@ -266,7 +278,7 @@ def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape)
     assert hosted >= 4, hosted
     got = {k: v.cpu().numpy() for k, v in agent.state_dict().items() if "epsilon" not in k}      # (flushes the last pass)
     for k in got:
-        np.testing.assert_allclose(got[k], want[-1]["params"][k], rtol=0, atol=p_atol, err_msg="final %s" % k)
+        _assert_params_track(got[k], want[-1]["params"][k], p_atol, flip_atol, flip_frac, "final %s" % k)
     np.testing.assert_allclose(float(agent._norm.item()), want[-1]["norm"], rtol=5e-5)
     np.testing.assert_allclose(mem._dump()["tree"], want_tree, rtol=2e-5)
     assert int(agent.optimiser.state_dict()["state"][0]["step"]) == AGENT_STEPS
@@ -564,9 +576,14 @@ def test_batched_evaluation_of_validation_memory(hip):
     assert qs.shape == (cap,) and np.all(np.isfinite(qs))
 
 
-@pytest.mark.parametrize("one_call", ["1", "0"], ids=["train_step", "three-calls"])
-def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch, one_call):
-    """RAINBOW_AMD_DEFER_UPDATE (default on): Agent.learn leaves clip + Adam pending and the next learn's sampler launch
+@pytest.mark.parametrize("one_call,split", [("1", False), ("0", False), ("1", True)],
+                         ids=["train_step", "three-calls", "train_step-split-pass"])
+def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch, one_call, split):
+    """Third case, RB_OPTS adam_split=1: the pending pass's (mu, sigma) pair workgroups run as k_adam_split on the library's
+    second stream behind the flag the hosting sampler launch sets, and the hidden layer's forward waits in-kernel for their
+    arrival total — two streams, no host event, the same bits (the act / target-sync / state_dict calls in between take the
+    un-split paths).
+    RAINBOW_AMD_DEFER_UPDATE (default on): Agent.learn leaves clip + Adam pending and the next learn's sampler launch
     hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE).  Against an agent with the switch off (same device-resident
     step number): 8 steps with acting, a target sync and a state_dict() in between — per-step losses, actions, parameters,
     target parameters, Adam moments, the norm and the sum-tree bit-identical; the deferred agent really deferred."""
@@ -581,7 +598,7 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
         monkeypatch.setenv("RAINBOW_AMD_DEFER_UPDATE", defer)
         # RB_LEARNER_IMPLICIT_SIGMA rides on the deferral (the hosted pass forms the hidden layer's sigma gradient itself and
         # updates (mu, sigma) pairs together); the library switches it on from 1 M-element layers: force it on this small net
-        monkeypatch.setenv("RB_OPTS", "implicit_small=1")
+        monkeypatch.setenv("RB_OPTS", "implicit_small=1" + (",adam_split=1" if split else ""))
         # the deferring agent through rb_learner_train_step or through the step's entry points one by one
         # (rb_learner_attach_pending / rb_learner_clip_adam_deferred: the path the replica exchange uses as well)
         monkeypatch.setenv("RAINBOW_AMD_ONE_CALL", one_call if defer == "1" else "1")
@@ -638,6 +655,13 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
     assert torch.equal(a1.grads, a2.grads) and torch.equal(a1._norm, a2._norm)
     assert int(a1._step_dev.item()) == int(a2._step_dev.item()) == 8
     assert np.array_equal(m1._grab("tree"), m2._grab("tree"))
+    if split:      # the pair workgroups really ran on the second stream (steps 1 and 2: the other pending passes were run by act /
+                   # update_target_net / state_dict / _norm as launches of their own)
+        words = torch.zeros(288, dtype=torch.int32, device="cuda")
+        L.check(a1._lib, a1._lib.rb_learner_debug_read(a1._h, 5, words.data_ptr(), a1._stream()))
+        torch.cuda.synchronize()
+        w = words.cpu().numpy()
+        assert int(w[0]) == 2 and int(w[32::32].sum()) > 0, w[:40]
 
 
 def test_checkpoint_restore_resumes_bit_exactly(hip, tmp_path):
