@@ -72,6 +72,16 @@ def init_parameters_flat(layout, n_params, noisy_std):
 
 _ACT_PENDING = -7          # preset of the pinned action word while an act launch is in flight
 
+# torch.cuda.current_stream(device).cuda_stream builds a Stream object per call (~4 us: a tenth of one act()); the raw handle
+# of the same current stream is one C call (what torch's own compiled-kernel launchers use)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def current_stream_handle(device):
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
+
 
 class _FlatAdam(torch.optim.Adam):
     """torch.optim.Adam over the single flat parameter tensor (agent.py:46).  The state is ordinary Adam state
@@ -225,6 +235,7 @@ class Agent:
         self._act_pin = torch.zeros(2 * self.batch_size, dtype=torch.int32).pin_memory()     # written by the device
         self._q_pin = torch.zeros(2 * self.batch_size, dtype=torch.float32).pin_memory()
         self._act_np, self._q_np = self._act_pin.numpy(), self._q_pin.numpy()
+        self._pin_ptrs = None
         self._world = rdist.world_size()
         self._dist = rdist.active()
         self._exchange = None
@@ -286,7 +297,7 @@ class Agent:
             pass
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return current_stream_handle(self.device)
 
     def _view(self, flat, name):
         for n, off, shape in self._layout:
@@ -332,13 +343,19 @@ class Agent:
     def _forward_single(self, state):
         """One state through the act path; the action / value land in PINNED host memory the kernel writes directly
         (no device-to-host copy): they are final after the stream synchronize below."""
-        self._flush_noise()
-        st = state.to(device=self.device, dtype=torch.float32).contiguous()
+        if self._noise_pending:
+            self._flush_noise()
+        st = state
+        if st.dtype != torch.float32 or st.device != self.device or not st.is_contiguous():     # (env.py hands over exactly this)
+            st = state.to(device=self.device, dtype=torch.float32).contiguous()
         act = self._act_np
+        pins = self._pin_ptrs
+        if pins is None or pins[2] is not self._act_pin:
+            pins = self._pin_ptrs = (self._act_pin.data_ptr(), self._q_pin.data_ptr(), self._act_pin)
+        fn, stream = self._lib.rb_learner_act, current_stream_handle(self.device)
         for attempt in range(2):
             act[0] = _ACT_PENDING
-            rc = self._lib.rb_learner_act(self._h, st.data_ptr(), 1 if self.training else 0, self._act_pin.data_ptr(),
-                                          self._q_pin.data_ptr(), self._stream())
+            rc = fn(self._h, st.data_ptr(), 1 if self.training else 0, pins[0], pins[1], stream)
             if rc != 0:
                 L.check(self._lib, rc)
             # completion = the pinned action word changes (the head writes q, fences, then the action): polling it returns

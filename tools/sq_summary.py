@@ -31,7 +31,10 @@ def main():
                "active_inst_frac": round(m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3),
                "lds_conflict_frac_of_lds_active": round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, m.get("SQ_LDS_IDX_ACTIVE", 0.0)), 3),
                "mfma_busy_cycles": round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)),
-               "sq_busy_cycles": round(busy)}
+               "sq_busy_cycles": round(busy),
+               # MFMA-busy as a fraction of the launch: SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs' busy cycles, SQ_BUSY_CYCLES
+               # the 32 shader engines' (a 12.5 us launch = 30 k cycles reads 0.84 M): busy / (32 x SQ_BUSY) = mean over the SIMDs
+               "mfma_busy_frac": round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1.0, 32.0 * busy), 3)}
         out["%s [grid %d]" % (name, grid)] = row
     print(json.dumps(out, indent=1))
 
