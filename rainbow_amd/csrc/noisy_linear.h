@@ -882,6 +882,10 @@ struct NlPriorityUpdate {
   const float* loss;
   int n;
   double omega;
+  // the early draw (replay_internal.h rb_replay_spec_launch; enabled == 0): this launch is the first one behind the head kernel,
+  // so its START proves the per-sample losses final — workgroup 0 stores go_epoch for the replay's stream to see (NULL: nothing)
+  unsigned* go_flag;
+  unsigned go_epoch;
 };
 #if defined(RB_STAMP)
 extern __device__ long long g_span[64];
@@ -911,6 +915,13 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
   (void)kid; (void)wgb;
   RB_WGT(kid, wgb, 0);
   RB_WGT_HW(kid, wgb);
+  if (up.go_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+#if defined(RB_HOST_INTERP)
+    *up.go_flag = up.go_epoch;
+#else
+    __hip_atomic_store(up.go_flag, up.go_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  }
   if (up.enabled) {
     if (TALL && threadIdx.x >= 256 && b == 0) return;    // (the write-back body is written for 256 threads)
     if (b == 0) {

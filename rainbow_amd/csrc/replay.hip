@@ -44,12 +44,38 @@ struct rb_replay {
   float* scaling_dev;
   int32_t max_batch;
   const float* neg_beta_dev;   // optional device-resident -beta (graph replay: no by-value argument may change)
-  int32_t* fail_host;          // pinned, device-mapped, two words: [0] sampler launches that found no valid batch (see k_sample),
-                               // [1] priority write-backs dropped because their indices came from such a draw (rb_update_body)
+  int32_t* fail_host;          // pinned, device-mapped, four words: [0] sampler launches that found no valid batch (see k_sample),
+                               // [1] priority write-backs dropped because their indices came from such a draw (rb_update_body),
+                               // [2] expired cross-stream waits of the early draw (rb_wait_epoch; must stay 0)
   // host mirror of the deterministic part of the header
   int64_t host_index;
   int32_t host_full;
+  // the early draw (replay_internal.h rb_replay_spec_launch)
+  int32_t* win2;               // the second window table
+  int win_sel;                 // table of the last draw (0 = win, 1 = win2)
+  hipStream_t spec_stream;
+  SpecResult* spec_res;        // device
+  unsigned spec_epoch;
+  int spec_inflight;
+  struct { int32_t batch, max_attempts, win_set; double beta; int64_t* tree_idx; int64_t* actions; float* returns; float* nonterm; float* weights; } spec_args;
+  unsigned long long mutations;   // entry points that changed the replay (or drew from it) so far
 };
+static int32_t* win_of(const rb_replay* r, int set) { return set ? r->win2 : r->win; }
+// every entry point that reads or writes the replay outside a draw: wait for an early draw in flight and discard it (its
+// write-back part is final and stays, its tentative draw is simply never accepted)
+static int spec_join(rb_replay* r) {
+  if (!r->spec_inflight) return RB_OK;
+#if !defined(RB_HOST_INTERP)
+  RB_HIP_TRY(hipStreamSynchronize(r->spec_stream));
+#endif
+  r->spec_inflight = 0;
+  return RB_OK;
+}
+#define RB_SPEC_JOIN(r)                 \
+  do {                                  \
+    const int rcj_ = spec_join(r);      \
+    if (rcj_ != RB_OK) return rcj_;     \
+  } while (0)
 
 static ReplayView view_of(const rb_replay* r) {
   ReplayView v;
@@ -460,7 +486,9 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
                                                const double* unit_uniforms, int32_t max_attempts, uint64_t seed, const float* scaling,
                                                int64_t* tree_idx_out, int32_t* win, int64_t* actions_out, float* returns_out,
                                                float* nonterminals_out, float* weights_out, int32_t* fail_count, int32_t lds_top,
-                                               int* s_flag, float* s_red, float* s_top, bool top_staged);
+                                               int* s_flag, float* s_red, float* s_top, bool top_staged, SpecResult* spec = nullptr,
+                                               unsigned spec_epoch = 0u);
+__device__ __forceinline__ void rb_wait_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host);
 template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
@@ -468,7 +496,8 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
                                                   int64_t* actions_out, float* returns_out, float* nonterminals_out,
                                                   float* weights_out, const NoiseJob* job_dev, float* job_noise, float* job_noise2,
                                                   unsigned long long* job_ctr, int32_t* fail_count, int32_t lds_top,
-                                                  int32_t noise_blocks, const ClipAdamArgs* adam_dev) {
+                                                  int32_t noise_blocks, const ClipAdamArgs* adam_dev, SpecResult* spec,
+                                                  unsigned spec_epoch, int32_t spec_mode) {
   if ((int)blockIdx.x > noise_blocks) {
     // co-tenant workgroups behind the noise ones: the previous learn call's optimiser pass (adam_body.h) — independent of
     // this batch's sampling, and 30 us of pure streaming that now runs beside the sampler's serial chain, not before it
@@ -489,8 +518,25 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
+  // spec_mode (the early draw, replay_internal.h): 1 = THIS is the tentative draw; 2 = an early draw is in flight on another stream
+  // and is accepted: wait for it, commit its header effects, done; 3 = in flight but not acceptable (other arguments): wait, then
+  // draw as usual (it wrote the same output buffers)
+  if (spec_mode >= 2) {
+    rb_wait_epoch(&spec->done, spec_epoch, fail_count ? fail_count + 2 : nullptr);
+    if (spec_mode == 2) {
+      if (threadIdx.x == 0) {
+        const int32_t st = spec->status;
+        v.hdr->last_attempts = spec->attempts;
+        v.hdr->last_status = st;
+        v.hdr->rng_counter = spec->rng_next;
+        if (st != 0 && fail_count) rb_atomic_inc_system(fail_count);
+      }
+      return;
+    }
+  }
   rb_sample_main<MAXT>(v, batch, neg_beta_arg, neg_beta_ptr, unit_uniforms, max_attempts, seed, scaling, tree_idx_out, win, actions_out,
-                       returns_out, nonterminals_out, weights_out, fail_count, lds_top, s_flag, s_red, s_top, false);
+                       returns_out, nonterminals_out, weights_out, fail_count, lds_top, s_flag, s_red, s_top, false,
+                       spec_mode == 1 ? spec : nullptr, spec_epoch);
 }
 
 // The sampler proper (one workgroup, thread i = sample i): shared by k_sample (block 0) and k_update_sample.  top_staged: the
@@ -500,7 +546,8 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
                                                const double* unit_uniforms, int32_t max_attempts, uint64_t seed, const float* scaling,
                                                int64_t* tree_idx_out, int32_t* win, int64_t* actions_out, float* returns_out,
                                                float* nonterminals_out, float* weights_out, int32_t* fail_count, int32_t lds_top,
-                                               int* s_flag, float* s_red, float* s_top, bool top_staged) {
+                                               int* s_flag, float* s_red, float* s_top, bool top_staged, SpecResult* spec,
+                                               unsigned spec_epoch) {
   RB_STAMP_AT(0);
   const int i = (int)threadIdx.x;
   const bool active = i < batch;
@@ -587,6 +634,29 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
   // every importance weight is 0, so the step's gradient is exactly zero, and the failure is counted in host-visible
   // memory (rb_replay_failed_samples) so the caller can raise without a device synchronisation.
   if (active) weights_out[i] = ok ? __fdiv_rn(w, w_max) : 0.0f;         // memory.py:154
+  if (spec) {
+    // a TENTATIVE draw (rb_replay_spec_launch): the header is not touched — what the draw would have done to it goes to the side
+    // record, committed by the draw that accepts it (k_sample, spec_mode 2).  The record's epoch is stored LAST, behind an
+    // agent-scope release of everything this workgroup wrote: the accepting workgroup polls it from another stream.
+    if (threadIdx.x == 0) {
+      spec->attempts = attempts_used;
+      spec->status = ok ? 0 : 1;
+      spec->rng_next = rng_base + (uint64_t)attempts_used;
+    }
+#if defined(RB_HOST_INTERP)
+    __syncthreads();
+    if (threadIdx.x == 0) spec->done = spec_epoch;
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&spec->done, spec_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+    return;
+  }
   if (threadIdx.x == 0) {
     v.hdr->last_attempts = attempts_used;
     v.hdr->last_status = ok ? 0 : 1;
@@ -596,6 +666,25 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
     if (!ok && fail_count) rb_atomic_inc_system(fail_count);
   }
   RB_STAMP_AT(5);
+}
+
+// wait for *flag >= epoch (one lane polls, relaxed; then ONE agent-scope acquire; all threads call).  The bound is seconds: the
+// producers are launches submitted EARLIER (a head kernel, an early draw), so an expiry means the device is wedged anyway.
+__device__ __forceinline__ void rb_wait_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host) {
+#if defined(RB_HOST_INTERP)
+  if (threadIdx.x == 0 && (int)(*flag - epoch) < 0 && err_host) *err_host = 1;      // launches run in submission order there
+  __syncthreads();
+#else
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { if (err_host) rb_atomic_inc_system(err_host); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+#endif
 }
 
 // Frame-stack gather (memory.py:136-138 minus the /255): block = (sample, stack slot),
@@ -626,8 +715,10 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 // ---------------------------------------------------------------------- update --
 // (body: replay_internal.h)
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
-                                                  int32_t apply_pow, double omega) {
+                                                  int32_t apply_pow, double omega, const unsigned* go_flag, unsigned go_epoch,
+                                                  int32_t* err_host) {
   __shared__ float lds[UpdateLds<2048, 1024>::WORDS];
+  if (go_flag) rb_wait_epoch(go_flag, go_epoch, err_host);      // (the early write-back: its losses come from another stream)
   rb_update_auto<2048, 1024>(v, tree_idx, values, n, apply_pow, omega, lds);
 }
 
@@ -643,13 +734,15 @@ __global__ __launch_bounds__(256) void k_update_sample(ReplayView v, const int64
                                                         const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts,
                                                         uint64_t seed, const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                         int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                        float* weights_out, int32_t* fail_count) {
+                                                        float* weights_out, int32_t* fail_count, const unsigned* go_flag,
+                                                        unsigned go_epoch, SpecResult* spec, unsigned spec_epoch) {
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
   __shared__ float lds_upd[UpdateLds<512, 256>::WORDS];
   __shared__ int s_sorted;
   const int i = (int)threadIdx.x;
+  if (go_flag) rb_wait_epoch(go_flag, go_epoch, fail_count ? fail_count + 2 : nullptr);   // (the early pair: the losses come from another stream)
   const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
   UpdateOperand op;
   op.node = -1; op.val = 0.0f; op.status = 0; op.sorted = 0;
@@ -676,7 +769,7 @@ __global__ __launch_bounds__(256) void k_update_sample(ReplayView v, const int64
   __threadfence_block();               // the tree this workgroup wrote, read back by the same workgroup (as in k_rebuild_top)
   __syncthreads();
   rb_sample_main<256>(v, batch, neg_beta_arg, neg_beta_ptr, unit_uniforms, max_attempts, seed, scaling, tree_idx_out, win, actions_out,
-                      returns_out, nonterminals_out, weights_out, fail_count, 1, s_flag, s_red, s_top, sorted);
+                      returns_out, nonterminals_out, weights_out, fail_count, 1, s_flag, s_red, s_top, sorted, spec, spec_epoch);
 }
 
 // -------------------------------------------------------------- validation view --
@@ -759,6 +852,63 @@ void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nby
   }
 }
 
+// One wave, no LDS, a handful of registers: holds the replay's stream back until *flag >= epoch.  The early pair itself must not
+// do the waiting: submitted a whole step ahead of the device, a 256-thread / 50 KB workgroup polling on a CU takes that CU away
+// from every launch of the step that needs all 256 (the batch-256 conv kernels are one LDS-filling workgroup per CU: each of them
+// ran a second round for ONE workgroup — 498 -> 650 us per step, measured); a lone wave fits beside anything.
+__global__ __launch_bounds__(64) void k_spec_gate(const unsigned* flag, unsigned epoch, int32_t* err_host) {
+  rb_wait_epoch(flag, epoch, err_host);
+}
+
+int rb_replay_spec_inflight(rb_replay_t* r) { return r ? r->spec_inflight : 0; }
+const int32_t* rb_replay_current_windows(rb_replay_t* r) { return win_of(r, r->win_sel); }
+unsigned long long rb_replay_mutations(rb_replay_t* r) { return r->mutations; }
+
+// (replay_internal.h) the write-back of learn call k + the tentative draw of call k + 1 on the replay's own stream
+int rb_replay_spec_launch(rb_replay_t* r, const rb_spec_request& q) {
+  RB_REQUIRE(r && q.upd_idx && q.upd_loss && q.tree_idx && q.actions && q.returns && q.nonterminals && q.weights, "rb_replay_spec_launch: NULL argument");
+  RB_REQUIRE(q.batch >= 1 && q.batch <= 256 && q.upd_n >= 1 && q.upd_n <= 1024, "rb_replay_spec_launch: batch must be in [1,256], upd_n in [1,1024]");
+  RB_REQUIRE(r->capacity > (int64_t)r->history + r->n, "rb_replay_spec_launch: capacity must exceed history + multi_step");
+  RB_SPEC_JOIN(r);
+#if defined(RB_HOST_INTERP)
+  hipStream_t s2 = nullptr;
+#else
+  if (!r->spec_stream) RB_HIP_TRY(hipStreamCreateWithFlags(&r->spec_stream, hipStreamNonBlocking));
+  hipStream_t s2 = r->spec_stream;
+#endif
+  const ReplayView v = view_of(r);
+  const int win_set = r->win_sel ^ 1;            // the table the step in flight still reads is left alone
+  const float neg_beta = (float)(-q.priority_weight);
+  const unsigned epoch = ++r->spec_epoch;
+  ++r->mutations;
+  if (q.go_flag) {
+    RB_LAUNCH(k_spec_gate, dim3(1), dim3(64), s2, q.go_flag, q.go_epoch, r->fail_host + 2);
+    RB_LAUNCH_CHECK();
+  }
+  if (q.upd_n <= 256) {
+    // one launch (latency is no concern on this stream): sorted batches of up to 64 leaves take the one-wave write-back, the rest
+    // the hashed body inside the same kernel
+    RB_LAUNCH(k_update_sample, dim3(1), dim3(256), s2, v, q.upd_idx, q.upd_loss, q.upd_n, 1, r->omega, q.batch, neg_beta, r->neg_beta_dev,
+              (const double*)nullptr, q.max_attempts, r->seed, r->scaling_dev, q.tree_idx, win_of(r, win_set), q.actions, q.returns,
+              q.nonterminals, q.weights, r->fail_host, (const unsigned*)nullptr, 0u, r->spec_res, epoch);
+    RB_LAUNCH_CHECK();
+  } else {
+    int uthreads = (int)(rb_div_up(q.upd_n, 64) * 64);
+    if (uthreads < 256) uthreads = 256;
+    RB_LAUNCH(k_update, dim3(1), dim3(uthreads), s2, v, q.upd_idx, q.upd_loss, q.upd_n, 1, r->omega, (const unsigned*)nullptr, 0u, (int32_t*)nullptr);
+    RB_LAUNCH_CHECK();
+    RB_LAUNCH((k_sample<256, 8>), dim3(1), dim3(256), s2, v, q.batch, neg_beta, r->neg_beta_dev, (const double*)nullptr, q.max_attempts, r->seed,
+              r->scaling_dev, q.tree_idx, win_of(r, win_set), q.actions, q.returns, q.nonterminals, q.weights, (const NoiseJob*)nullptr,
+              (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, r->fail_host, 1, 0, (const ClipAdamArgs*)nullptr, r->spec_res, epoch, 1);
+    RB_LAUNCH_CHECK();
+  }
+  r->spec_args.batch = q.batch; r->spec_args.max_attempts = q.max_attempts; r->spec_args.win_set = win_set;
+  r->spec_args.beta = q.priority_weight; r->spec_args.tree_idx = q.tree_idx; r->spec_args.actions = q.actions;
+  r->spec_args.returns = q.returns; r->spec_args.nonterm = q.nonterminals; r->spec_args.weights = q.weights;
+  r->spec_inflight = 1;
+  return RB_OK;
+}
+
 int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega) {
   if (!r || !view || !omega) return RB_ERR_INVALID;
   *view = view_of(r);
@@ -790,6 +940,8 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   r->host_index = 0; r->host_full = 0;
   r->tree = nullptr; r->frames = nullptr; r->timestep = nullptr; r->action = nullptr; r->reward = nullptr;
   r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr; r->fail_host = nullptr;
+  r->win2 = nullptr; r->win_sel = 0; r->spec_stream = nullptr; r->spec_res = nullptr; r->spec_epoch = 0; r->spec_inflight = 0;
+  r->mutations = 0;
 #define RB_ALLOC(ptr, bytes)                                                                      \
   do {                                                                                            \
     hipError_t e_ = rb_dev_malloc((void**)&(ptr), (size_t)(bytes));                                   \
@@ -807,16 +959,18 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_ALLOC(r->nonterminal, capacity);
   RB_ALLOC(r->hdr, sizeof(rb_replay_header_t));
   RB_ALLOC(r->win, (int64_t)r->max_batch * 64 * sizeof(int32_t));
+  RB_ALLOC(r->win2, (int64_t)r->max_batch * 64 * sizeof(int32_t));
+  RB_ALLOC(r->spec_res, sizeof(SpecResult));
   RB_ALLOC(r->scaling_dev, 64 * sizeof(float));
 #undef RB_ALLOC
   {
-    hipError_t e_ = hipHostMalloc((void**)&r->fail_host, 2 * sizeof(int32_t), hipHostMallocMapped);
+    hipError_t e_ = hipHostMalloc((void**)&r->fail_host, 4 * sizeof(int32_t), hipHostMallocMapped);
     if (e_ != hipSuccess) {
       rb_set_error("rb_replay_create: hipHostMalloc failed: %s", hipGetErrorString(e_));
       rb_replay_destroy(r);
       return RB_ERR_OOM;
     }
-    r->fail_host[0] = 0; r->fail_host[1] = 0;
+    r->fail_host[0] = 0; r->fail_host[1] = 0; r->fail_host[2] = 0; r->fail_host[3] = 0;
   }
   // blank_trans everywhere (memory.py:8,19), zero tree (memory.py:18)
   RB_HIP_TRY(hipMemset(r->tree, 0, r->tree_len * sizeof(float)));
@@ -826,6 +980,7 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_HIP_TRY(hipMemset(r->reward, 0, capacity * sizeof(float)));
   RB_HIP_TRY(hipMemset(r->nonterminal, 0, capacity));
   RB_HIP_TRY(hipMemcpy(r->scaling_dev, r->scaling, 64 * sizeof(float), hipMemcpyHostToDevice));
+  RB_HIP_TRY(hipMemset(r->spec_res, 0, sizeof(SpecResult)));
   RB_LAUNCH(k_replay_init, dim3(1), dim3(64), nullptr, r->hdr);
   RB_LAUNCH_CHECK();
   RB_HIP_TRY(hipDeviceSynchronize());
@@ -836,7 +991,13 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
 
 int rb_replay_destroy(rb_replay_t* r) {
   if (!r) return RB_OK;
+  (void)spec_join(r);
+#if !defined(RB_HOST_INTERP)
+  if (r->spec_stream) (void)hipStreamDestroy(r->spec_stream);
+#endif
   live_del(r);
+  if (r->win2) rb_dev_free(r->win2);
+  if (r->spec_res) rb_dev_free(r->spec_res);
   if (r->tree) rb_dev_free(r->tree);
   if (r->frames) rb_dev_free(r->frames);
   if (r->timestep) rb_dev_free(r->timestep);
@@ -853,6 +1014,7 @@ int rb_replay_destroy(rb_replay_t* r) {
 
 int rb_replay_buffers(rb_replay_t* r, rb_replay_buffers_t* o) {
   RB_REQUIRE(r && o, "rb_replay_buffers: NULL argument");
+  RB_SPEC_JOIN(r);
   o->sum_tree_dev = r->tree; o->tree_len = r->tree_len; o->tree_start = r->tree_start;
   o->frames_dev = r->frames; o->timestep_dev = r->timestep; o->action_dev = r->action;
   o->reward_dev = r->reward; o->nonterminal_dev = r->nonterminal; o->header_dev = r->hdr;
@@ -862,6 +1024,7 @@ int rb_replay_buffers(rb_replay_t* r, rb_replay_buffers_t* o) {
 
 int rb_replay_header(rb_replay_t* r, rb_replay_header_t* o, rb_stream_t stream) {
   RB_REQUIRE(r && o, "rb_replay_header: NULL argument");
+  RB_SPEC_JOIN(r);
   RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   RB_HIP_TRY(hipMemcpy(o, r->hdr, sizeof(*o), hipMemcpyDeviceToHost));
   r->host_index = o->index;  // resynchronise the mirror (e.g. after a state restore)
@@ -872,6 +1035,8 @@ int rb_replay_header(rb_replay_t* r, rb_replay_header_t* o, rb_stream_t stream) 
 int rb_replay_append(rb_replay_t* r, const float* state_dev, int32_t timestep, int32_t action, float reward,
                      int32_t nonterminal, rb_stream_t stream) {
   RB_REQUIRE(r && state_dev, "rb_replay_append: NULL argument");
+  RB_SPEC_JOIN(r);
+  ++r->mutations;
   const float* last = state_dev + (int64_t)(r->history - 1) * RB_FRAME_BYTES;  // state[-1], memory.py:106
   RB_LAUNCH(k_append_one, dim3(1), dim3(256), stream, view_of(r), last, timestep, action, reward, nonterminal);
   RB_LAUNCH_CHECK();
@@ -885,6 +1050,8 @@ int rb_replay_append_batch(rb_replay_t* r, const uint8_t* frames_dev, const int3
                            int64_t n, rb_stream_t stream) {
   RB_REQUIRE(r && frames_dev && timesteps_dev && actions_dev && rewards_dev && nonterminals_dev,
              "rb_replay_append_batch: NULL argument");
+  RB_SPEC_JOIN(r);
+  ++r->mutations;
   RB_REQUIRE(n >= 0 && n <= r->capacity, "rb_replay_append_batch: n must be in [0, capacity]");
   if (n == 0) return RB_OK;
   const ReplayView v = view_of(r);
@@ -961,6 +1128,7 @@ int rb_replay_set_beta_source(rb_replay_t* r, const float* neg_beta_dev) {
 int rb_replay_find(rb_replay_t* r, const double* values_dev, int32_t n, float* probs_dev, int64_t* data_idx_dev,
                    int64_t* tree_idx_dev, rb_stream_t stream) {
   RB_REQUIRE(r && values_dev && probs_dev && data_idx_dev && tree_idx_dev, "rb_replay_find: NULL argument");
+  RB_SPEC_JOIN(r);
   if (n <= 0) return RB_OK;
   RB_LAUNCH(k_find, dim3((unsigned)rb_div_up(n, 256)), dim3(256), stream, view_of(r), values_dev, n, probs_dev,
             data_idx_dev, tree_idx_dev);
@@ -996,6 +1164,27 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   RB_REQUIRE(r->capacity > (int64_t)r->history + r->n,
              "rb_replay_sample: capacity must exceed history + multi_step (no window can clear the write head otherwise: "
              "the reference's rejection loop, memory.py:128-132, would never end)");
+  if (*(volatile int32_t*)(r->fail_host + 2) != 0) {
+    rb_set_error("rb_replay_sample: a cross-stream wait of the early draw expired (%d): the device did not make progress", r->fail_host[2]);
+    return RB_ERR_STATE;
+  }
+  // an early draw in flight (rb_replay_spec_launch): this launch's sampler workgroup waits for it and either ACCEPTS it — same
+  // batch, beta, attempt bound and output buffers, device RNG, nothing else has touched the replay since (every other entry
+  // point cancels it) — or draws again; either way the stream-2 work is complete before anything of this stream goes on
+  int spec_mode = 0;
+  int win_set = 0;
+  if (r->spec_inflight) {
+    const bool same = unit_uniforms_dev == nullptr && r->spec_args.batch == batch && r->spec_args.beta == priority_weight &&
+                      r->spec_args.max_attempts == max_attempts && r->spec_args.tree_idx == tree_idx_dev &&
+                      r->spec_args.actions == actions_dev && r->spec_args.returns == returns_dev &&
+                      r->spec_args.nonterm == nonterminals_dev && r->spec_args.weights == weights_dev;
+    spec_mode = same ? 2 : 3;
+    if (same) win_set = r->spec_args.win_set;
+    r->spec_inflight = 0;
+  }
+  r->win_sel = win_set;
+  ++r->mutations;
+  int32_t* const win_cur = win_of(r, win_set);
   const ReplayView v = view_of(r);
   int threads = (int)(rb_div_up(batch, 64) * 64);
   if (threads < 256) threads = 256;   // enough lanes to stage the 16 KB tree top into LDS in one sweep
@@ -1034,15 +1223,15 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   const int lds_top = 1;
   if (threads <= 256 && host_mode != 1) {
     RB_LAUNCH_T("sample:k_sample", (k_sample<256, 8>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
+                r->scaling_dev, tree_idx_dev, win_cur, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev, r->spec_res, r->spec_epoch, spec_mode);
   } else {
     RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: the 1024-thread sampler (batch > 256) supports history + multi_step <= 24");
     RB_LAUNCH_T("sample:k_sample", (k_sample<1024, RB_HOST_AU_WIDE>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, r->win, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev);
+                r->scaling_dev, tree_idx_dev, win_cur, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev, r->spec_res, r->spec_epoch, spec_mode);
   }
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
-    RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win,
+    RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, win_cur,
               states_dev, next_states_dev);
     RB_LAUNCH_CHECK();
   }
@@ -1070,9 +1259,12 @@ static int rb_update_impl(rb_replay_t* r, const int64_t* tree_idx_dev, const flo
                           int32_t apply_pow, rb_stream_t stream) {
   RB_REQUIRE(r && tree_idx_dev && values_dev, "rb_replay_update: NULL argument");
   RB_REQUIRE(n >= 1 && n <= 1024, "rb_replay_update: n must be in [1,1024]");
+  RB_SPEC_JOIN(r);
+  ++r->mutations;
   int threads = (int)(rb_div_up(n, 64) * 64);
   if (threads < 256) threads = 256;     // the dense rebuild of the tree top wants lanes, not just one per leaf
-  RB_LAUNCH(k_update, dim3(1), dim3(threads), stream, view_of(r), tree_idx_dev, values_dev, n, apply_pow, r->omega);
+  RB_LAUNCH(k_update, dim3(1), dim3(threads), stream, view_of(r), tree_idx_dev, values_dev, n, apply_pow, r->omega, (const unsigned*)nullptr, 0u,
+            (int32_t*)nullptr);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }
@@ -1105,11 +1297,14 @@ int rb_replay_update_sample(rb_replay_t* r, const int64_t* upd_tree_idx_dev, con
   RB_REQUIRE(batch >= 1, "rb_replay_update_sample: batch must be in [1,%d]", r->max_batch);
   RB_REQUIRE(max_attempts >= 1, "rb_replay_update_sample: max_attempts must be >= 1");
   RB_REQUIRE(r->capacity > (int64_t)r->history + r->n, "rb_replay_update_sample: capacity must exceed history + multi_step");
+  RB_SPEC_JOIN(r);
+  ++r->mutations;
+  r->win_sel = 0;
   const ReplayView v = view_of(r);
   const float neg_beta = (float)(-priority_weight);
   RB_LAUNCH_T("sample:k_update_sample", k_update_sample, dim3(1), dim3(256), stream, v, upd_tree_idx_dev, upd_losses_dev, upd_n, 1, r->omega,
               batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed, r->scaling_dev, tree_idx_dev, r->win, actions_dev,
-              returns_dev, nonterminals_dev, weights_dev, r->fail_host);
+              returns_dev, nonterminals_dev, weights_dev, r->fail_host, (const unsigned*)nullptr, 0u, (SpecResult*)nullptr, 0u);
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
     RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win, states_dev, next_states_dev);
@@ -1120,6 +1315,7 @@ int rb_replay_update_sample(rb_replay_t* r, const int64_t* upd_tree_idx_dev, con
 
 int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_stream_t stream) {
   RB_REQUIRE(r && out_dev, "rb_replay_state_at: NULL argument");
+  RB_SPEC_JOIN(r);
   RB_REQUIRE(data_index >= 0 && data_index < r->capacity, "rb_replay_state_at: index out of range");
   RB_LAUNCH(k_state_at, dim3(1), dim3(256), stream, view_of(r), data_index, out_dev);
   RB_LAUNCH_CHECK();
@@ -1128,6 +1324,7 @@ int rb_replay_state_at(rb_replay_t* r, int64_t data_index, float* out_dev, rb_st
 
 int rb_replay_states_at(rb_replay_t* r, const int64_t* data_index_dev, int32_t n, float* out_dev, rb_stream_t stream) {
   RB_REQUIRE(r && data_index_dev && out_dev, "rb_replay_states_at: NULL argument");
+  RB_SPEC_JOIN(r);
   RB_REQUIRE(n >= 0, "rb_replay_states_at: n must be >= 0");
   if (n == 0) return RB_OK;
   RB_LAUNCH(k_states_at, dim3((unsigned)n), dim3(256), stream, view_of(r), data_index_dev, out_dev);

@@ -350,3 +350,30 @@ __device__ __forceinline__ void rb_update_auto(ReplayView v, const int64_t* tree
 
 // host side (replay.hip): kernel view + priority exponent of a handle
 int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega);
+
+// ---- the early draw (replay.hip; called by learner.hip train_step, not part of the C ABI).
+// ReplayMemory.update_priorities of learn call k and ReplayMemory.sample of call k + 1 (agent.py:100 / :63, memory.py:124-159) depend
+// on nothing of call k after its head kernel (the per-sample loss), while call k's backward is another ~90 us of launches that
+// never touch the replay.  rb_replay_spec_launch issues that pair on a stream the replay owns, as soon as the head is done:
+// the write-back is final (it IS call k's), the draw TENTATIVE — it writes the caller's sample buffers and the replay's OTHER
+// window table, but its header effects (Philox counter, status, attempts, failure count) go to a side record.  The next draw on
+// the handle with the same arguments ACCEPTS it (k_sample block 0 waits for the record's epoch, commits the header effects and
+// returns); any other entry point that touches the replay waits for the stream and discards it; a draw with other arguments
+// waits and draws again.  Results are those of the two calls made one after the other.
+struct SpecResult {
+  unsigned long long rng_next;
+  int32_t attempts, status;
+  unsigned done;             // epoch of the last tentative draw that completed (release-stored last)
+  unsigned pad;
+};
+struct rb_spec_request {
+  const int64_t* upd_idx; const float* upd_loss; int32_t upd_n;     // the write-back (loss^w: rb_replay_update_priorities)
+  int32_t batch; double priority_weight; int32_t max_attempts;      // the draw (rb_replay_sample with device RNG)
+  int64_t* tree_idx; int64_t* actions; float* returns; float* nonterminals; float* weights;
+  const unsigned* go_flag; unsigned go_epoch;                       // both kernels wait for *go_flag >= go_epoch first (NULL: no wait)
+};
+int rb_replay_spec_launch(rb_replay_t* r, const rb_spec_request& q);
+int rb_replay_spec_inflight(rb_replay_t* r);
+// the window table the LAST draw on the handle filled (rb_replay_buffers_t.window_dev is table 0; an accepted early draw used the other)
+const int32_t* rb_replay_current_windows(rb_replay_t* r);
+unsigned long long rb_replay_mutations(rb_replay_t* r);

@@ -653,3 +653,60 @@ def test_replica_exchange_kernels_fold_more_than_two_blocks(emu, world):
     for ad in ads:
         emu.rb_learner_set_exchange(ad.h, 1, None, None)
         ad.close()
+
+
+def test_early_draw_on_the_replays_stream_is_bit_identical(emu, monkeypatch):
+    """RB_OPTS spec_draw=1 (replay_internal.h rb_replay_spec_launch): from the third back-to-back rb_learner_train_step on, the
+    priority write-back of call k (agent.py:100) and the draw of call k + 1 (agent.py:63) run behind call k's head kernel on the
+    replay's own stream; call k + 1's sampler launch ACCEPTS the draw.  Twin without the option, ten calls with device RNG:
+    per-sample loss, parameters, Adam moments, norm, noise, the sum-tree and the replay header (Philox counter, attempts, status)
+    bit-identical after every call — through accepted draws (calls 3, 4, 7), a REJECTED one (beta changes before call 5: the
+    tentative draw waits in the sampler launch, is discarded and redrawn), a CANCELLED one (an append before call 8 joins the
+    stream) and the streak building up again.  With an early draw accepted, the twin's batch of call k + 1 is what the
+    speculating handle's buffers already held after call k."""
+    import ctypes as C
+    from rainbow_amd import _lib as L
+    name = "dataeff"
+    c = scenarios.LEARN_CONFIGS[name]
+    monkeypatch.setenv("RB_OPTS", "spec_draw=1")
+    h1 = _ts_build(emu, name)
+    monkeypatch.setenv("RB_OPTS", "spec_draw=0")
+    h2 = _ts_build(emu, name)
+    rs = np.random.RandomState(77)
+    extra = [(scenarios.synth_state(rs, c["history"], 0), int(rs.randint(0, c["actions"])), 0.0, False) for _ in range(3)]
+    idx_after = {}
+    accepted = 0
+    for step in range(1, 11):
+        beta = 0.4 if step < 5 else 0.55
+        if step == 8:                          # something else touches the replay between two calls: the early draw is cancelled
+            for (mem, rp, ad, o, job) in (h1, h2):
+                for tr in extra:
+                    rp.append(*tr)
+        snaps, hdrs = [], []
+        for (mem, rp, ad, o, job) in (h1, h2):
+            ts = _ts_args(name, mem, rp, ad, o, job, beta, step)
+            L.check(emu, emu.rb_learner_train_step(ad.h, C.byref(ts), None))
+            assert emu.rb_learner_priority_written(ad.h) == 1
+            snaps.append(_ts_snapshot(mem, rp, ad, o))
+            h = rp.raw_header()
+            hdrs.append((h.index, h.full, h.max, h.total, h.last_attempts, h.last_status, h.rng_counter))
+        a, b = snaps
+        for k in ("loss", "params", "m", "v", "noise", "tree", "norm", "grads"):
+            assert np.array_equal(a[k], b[k]), (step, k)
+        assert hdrs[0][:4] == hdrs[1][:4], step
+        idx_after[step] = a["idx"]
+        if np.array_equal(idx_after.get(step - 1), b["idx"]) and step >= 3:
+            accepted += 1                       # the speculating handle held call `step`'s batch one call early
+            assert hdrs[0][4:6] == hdrs[1][4:6]
+        elif not np.array_equal(a["idx"], b["idx"]):
+            pass                                # (an early draw for the NEXT call is in the buffers: compared one call later)
+    assert accepted >= 3, accepted
+    # the Philox counter: the twin's is final; the speculating handle's last tentative draw is not committed until accepted
+    for (mem, rp, ad, o, job) in (h1, h2):
+        L.check(emu, emu.rb_replay_sample(rp.h, c["batch"], 0.55, None, 64, mem.ptr(o["tree_idx"]), None, None, mem.ptr(o["actions"]),
+                                          mem.ptr(o["returns"]), mem.ptr(o["nonterm"]), mem.ptr(o["weights"]), None))
+    assert np.array_equal(h1[0].download(h1[3]["tree_idx"]), h2[0].download(h2[3]["tree_idx"]))
+    ha, hb = h1[1].raw_header(), h2[1].raw_header()
+    assert (ha.rng_counter, ha.last_attempts, ha.last_status) == (hb.rng_counter, hb.last_attempts, hb.last_status)
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ad.close(); rp.close()
