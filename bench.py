@@ -438,14 +438,16 @@ def main():
     per_iters = 500
     B = cfg["batch_size"]
     fake_loss = torch.rand(B, device=dev) + 0.1
+    # (donate=True: this loop never modifies its loss tensor between the call and the next draw, so the write-back reads it in place;
+    # without it the library copies caller-owned device operands at the call — +1.7 us per batch, tools/per_bench.py)
     for _ in range(20):
         o = mem.sample_device(B)
-        mem.update_priorities(o["tree_idxs"], fake_loss)
+        mem.update_priorities(o["tree_idxs"], fake_loss, donate=True)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for _ in range(per_iters):
         o = mem.sample_device(B)
-        mem.update_priorities(o["tree_idxs"], fake_loss)
+        mem.update_priorities(o["tree_idxs"], fake_loss, donate=True)
     mem.flush()                      # update_priorities is lazy (it rides in the next sampler launch): the last one runs inside the timed region
     torch.cuda.synchronize(dev)
     per_rate = per_iters * B / (time.perf_counter() - t1)

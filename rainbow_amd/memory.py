@@ -278,11 +278,11 @@ class ReplayMemory:
         return (tree_idxs, states, o["actions"].clone(), o["returns"].clone(), next_states,
                 o["nonterminals"].clone().unsqueeze(1), o["weights"].clone())
 
-    def _stage_operands(self, idxs, priorities):
+    def _stage_operands(self, idxs, priorities, stage_i, stage_p):
         """The operands of a deferred write-back in memory THIS object owns: `.to()` / `.contiguous()` hand a matching device
         tensor back as it is, and the reference's semantics are immediate (memory.py:157-159) — a caller may reuse its loss
-        or index tensor right after the call.  Two slots per length, used in turn (the launch that applies a write-back may
-        still be reading slot k when the next call fills slot k + 1); an asynchronous device-to-device copy of <= 3 KB."""
+        or index tensor right after the call.  Two slots per length, used in turn; an asynchronous device-to-device copy of
+        <= 3 KB per operand that needs one (each costs the PER-only loop ~1.7 us per batch: `donate=True` skips them)."""
         n = int(idxs.numel())
         ring = self._stage.get(n)
         if ring is None:
@@ -290,14 +290,26 @@ class ReplayMemory:
                                       torch.empty(n, dtype=torch.float32, device=self.device)] for _ in range(2)] + [0]
         slot = ring[ring[2]]
         ring[2] ^= 1
-        slot[0].copy_(idxs.reshape(-1), non_blocking=True)
-        slot[1].copy_(priorities.reshape(-1), non_blocking=True)
-        return slot[0], slot[1]
+        if stage_i:
+            slot[0].copy_(idxs.reshape(-1), non_blocking=True)
+            idxs = slot[0]
+        if stage_p:
+            slot[1].copy_(priorities.reshape(-1), non_blocking=True)
+            priorities = slot[1]
+        return idxs, priorities
 
-    def update_priorities(self, idxs, priorities, _immediate=False):
+    def _is_own_index_buffer(self, t):
+        for o in self._out.values():
+            if o["tree_idxs"] is t:
+                return True
+        return False
+
+    def update_priorities(self, idxs, priorities, _immediate=False, donate=False):
         """memory.py:157-159.  Accepts numpy arrays (reference call site agent.py:100) or device tensors.  By default the
-        write-back is recorded and rides in the next sample_device() launch (RAINBOW_AMD_LAZY_PRIORITIES); its operands are
-        copied at the call, so the caller's tensors are free again when this returns, as in the reference."""
+        write-back is recorded and rides in the next sample_device() launch (RAINBOW_AMD_LAZY_PRIORITIES); caller-owned device
+        operands are copied at the call, so the caller's tensors are free again when this returns, as in the reference.
+        donate=True (an extension): the caller will not modify its device operands before the next sample_device() / flush() —
+        they are read in place when the write-back runs (no staging copy)."""
         d = self.device
         if not torch.is_tensor(idxs):
             idxs = torch.as_tensor(np.asarray(idxs, dtype=np.int64))
@@ -311,8 +323,12 @@ class ReplayMemory:
             own_p = priorities.device != d or priorities.dtype != torch.float32 or not priorities.is_contiguous()
             i_d = idxs.to(device=d, dtype=torch.int64).contiguous()
             p_d = priorities.to(device=d, dtype=torch.float32).contiguous()
-            if not (own_i and own_p):       # at least one operand is still the caller's own device tensor
-                i_d, p_d = self._stage_operands(i_d, p_d)
+            # (the index buffer sample_device() hands out is this object's: the launch that applies the write-back reads it
+            # before its sampler part refills it)
+            stage_i = not own_i and not donate and not self._is_own_index_buffer(idxs)
+            stage_p = not own_p and not donate
+            if stage_i or stage_p:          # an operand is still the caller's own device tensor
+                i_d, p_d = self._stage_operands(i_d, p_d, stage_i, stage_p)
             self._upd = self._pending = (i_d, p_d)
             return
         self._upd = (idxs.to(device=d, dtype=torch.int64).contiguous(),

@@ -17,7 +17,7 @@ fi
 if [ -f rainbow_amd/librainbow_hip_stamp.so ]; then
   RAINBOW_AMD_LIB=$PWD/rainbow_amd/librainbow_hip_stamp.so timeout 120 python tools/stamp/gemm_timeline.py 2>&1 | grep "==\|   " > gpurun_out/${TAG}_gemm_timeline.txt
 fi
-for v in "RAINBOW_AMD_LAZY_PRIORITIES=0" "RAINBOW_AMD_LAZY_PRIORITIES=1"; do echo "[$v]"; env $v timeout 120 python tools/per_bench.py 2>/dev/null | tail -1; done > gpurun_out/${TAG}_per_bench.txt
+for v in "RAINBOW_AMD_LAZY_PRIORITIES=0" "RAINBOW_AMD_LAZY_PRIORITIES=1 PER_DONATE=0" "RAINBOW_AMD_LAZY_PRIORITIES=1 PER_DONATE=1"; do echo "[$v]"; env $v timeout 120 python tools/per_bench.py 2>/dev/null | tail -1; done > gpurun_out/${TAG}_per_bench.txt
 for v in "RB_OPTS=fc_gemm=0" "RB_OPTS=fc_gemm=-1" "RB_OPTS=fc_gemm=0" "RB_OPTS=fc_gemm=-1"; do
   env $v timeout 90 python bench.py --config breakout-canonical-b256 --steps 1000 --warmup 200 --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read() or '{\"ms_per_step\":0,\"value\":0}'); print('[$v]: %.2f us/step  %.0f steps/s' % (d['ms_per_step']*1e3, d['value']))"
 done > gpurun_out/${TAG}_fc_gemm_ab.txt

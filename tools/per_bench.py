@@ -14,15 +14,16 @@ mem = ReplayMemory(args, cfg["capacity"], seed=7)
 bench.fill_replay(mem, cfg["capacity"], cfg["actions"], seed=0)
 B = cfg["batch_size"]
 loss = torch.rand(B, device=dev) + 0.1
+DONATE = os.environ.get("PER_DONATE", "1") == "1"      # PER_DONATE=0: the library stages the caller-owned loss tensor at every call
 def loop(n, gather=True, update=True):
     for _ in range(50):
         o = mem.sample_device(B, gather=gather)
-        if update: mem.update_priorities(o["tree_idxs"], loss)
+        if update: mem.update_priorities(o["tree_idxs"], loss, donate=DONATE)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(n):
         o = mem.sample_device(B, gather=gather)
-        if update: mem.update_priorities(o["tree_idxs"], loss)
+        if update: mem.update_priorities(o["tree_idxs"], loss, donate=DONATE)
     mem.flush()
     t1 = time.perf_counter()
     torch.cuda.synchronize(dev)
@@ -33,4 +34,5 @@ for name, g, u in (("sample+gather+update", True, True), ("sample+update", False
     w, h = loop(1000, g, u)
     out[name] = dict(wall_us=round(w, 2), host_enqueue_us=round(h, 2))
 out["samples_per_s"] = round(B / out["sample+gather+update"]["wall_us"] * 1e6)
+out["donate"] = DONATE
 print(json.dumps(out))

@@ -32,7 +32,12 @@ def tag_of(name, grid, biggest):
     if "k_nl_fwd" in name:
         return "fc_h_fwd" if grid == biggest["k_nl_fwd"] and not biggest.get("gemm") else "fc_z_fwd"
     if "k_nl_bwd" in name:
-        return "fc_h_bwd" if grid == biggest["k_nl_bwd"] and not biggest.get("gemm") else "fc_z_bwd"
+        # the output layer's backward is the TALL instantiation at batch <= 32 (k_nl_bwd<true>); with the hidden layer on the tiled
+        # GEMMs (batch >= 128) k_nl_bwd<false> is the output layer's.  (Not by grid size: the data-efficient net's output layer
+        # has the larger grid, and the hidden layer's launch loses one workgroup when the early draw takes the write-back away.)
+        if "k_nl_bwd<true>" in name:
+            return "fc_z_bwd"
+        return "fc_z_bwd" if biggest.get("gemm") else "fc_h_bwd"
     if "k_conv_dw_all" in name:
         return "conv_dw_all"
     if "k_sample" in name:
@@ -63,8 +68,9 @@ def main():
         tag = tag_of(key[0], key[1], biggest)
         if tag is None or len(fetch[key]) < 5:
             continue
-        if tag in res and res[tag]["grid_size"] > key[1]:
-            continue      # e.g. "sample": the learn step's launch (it hosts the optimiser pass) over the PER-only phase's
+        if tag in res and (res[tag]["launches"] > len(fetch[key]) if tag.startswith("fc_") else res[tag]["grid_size"] > key[1]):
+            continue      # e.g. "sample": the learn step's launch (it hosts the optimiser pass) over the PER-only phase's;
+                          # fc_*: the steady-state variant of the launch (most launches)
         f = sum(fetch[key]) / len(fetch[key])
         w = sum(write.get(key, [0])) / max(1, len(write.get(key, [0])))
         res[tag] = {"kernel": key[0].split("(")[0][:80], "grid_size": key[1], "launches": len(fetch[key]), "FETCH_SIZE_KiB": f,
