@@ -1242,6 +1242,8 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   // image-fastest decode (an image group's workgroups of every layer on XCD group mod 8, where the input-gradient chain left
   // its dY): block ranges and the group count must be multiples of 8
   a.img_fast = (l->opt_img_fast && groups % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
+  // (a pipelined body — two operand sets in LDS, the next image's loads in flight under this image's MFMAs — was built in round 5,
+  // bit-identical, and measured SLOWER at batch 256: 75.9 against 64.5 us for this launch, profiles/round5_experiments.txt; removed)
   if (L.nconv == 3) {
     RB_LAUNCH_T("conv_dw_all", (k_conv_dw_all<GeomC1, 7, GeomC2, 9, 512, GeomC3, 7, 576, 3>), dim3(total), dim3(RB_CONV_THREADS), stream, a);
   } else {

@@ -710,3 +710,4 @@ def test_early_draw_on_the_replays_stream_is_bit_identical(emu, monkeypatch):
     assert (ha.rng_counter, ha.last_attempts, ha.last_status) == (hb.rng_counter, hb.last_attempts, hb.last_status)
     for (mem, rp, ad, o, job) in (h1, h2):
         ad.close(); rp.close()
+
