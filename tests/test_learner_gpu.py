@@ -788,3 +788,88 @@ def test_update_target_net_copies_noise_buffers_too(hip):
     torch.cuda.synchronize()
     assert torch.equal(agent.target_noise, agent.noise) and float(agent.noise.abs().sum()) > 0
     assert torch.equal(agent.target_params, agent.params.detach())
+
+
+def test_early_draw_random_interleaving_is_bit_identical(hip, monkeypatch):
+    """RB_OPTS spec_draw (default on) against a twin with spec_draw=0 through 240 randomly interleaved operations on the classes —
+    runs of back-to-back learn() (where the early draw is launched and accepted), beta changes (a tentative draw rejected inside
+    the sampler launch), appends / append_batch / update_priorities / sample / header reads (the replay's stream joined, the draw
+    cancelled), act / evaluate_q / update_target_net / state_dict (which do not touch the replay: the streak goes on): after
+    every operation that returns something the two agents agree, and at the end parameters, moments, noise, the sum-tree, the
+    frames' bookkeeping columns and the replay header (Philox counter included) are bit-identical."""
+    from rainbow_amd.agent import Agent
+    from rainbow_amd.memory import ReplayMemory
+    args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
+    env = types.SimpleNamespace(action_space=lambda: 4)
+
+    def fresh(spec):
+        monkeypatch.setenv("RB_OPTS", "implicit_small=1,spec_draw=%d" % spec)
+        torch.manual_seed(91)
+        np.random.seed(91)
+        agent = Agent(args, env)
+        mem = ReplayMemory(args, 2048, seed=7)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        rs = np.random.RandomState(5)
+        for _ in range(2):
+            mem.append_batch(torch.randint(0, 256, (1500, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
+                             rs.randint(0, 4, 1500), rs.choice([-1.0, 0.0, 1.0], size=1500), rs.random_sample(1500) < 0.01)
+        return agent, mem
+
+    twins = [fresh(1), fresh(0)]
+    rs = np.random.RandomState(123)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    ops = ["learn"] * 10 + ["act", "evalq", "append", "append_batch", "beta", "target", "update", "sample", "header", "state_dict"]
+    learns = 0
+    for step in range(240):
+        op = ops[rs.randint(len(ops))]
+        st = torch.rand(4, 84, 84, device="cuda", generator=g)
+        fr = torch.randint(0, 256, (5, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+        a_, r_, t_ = int(rs.randint(4)), float(rs.choice([-1.0, 0.0, 1.0])), bool(rs.random_sample() < 0.05)
+        loss_ = torch.rand(16, device="cuda", generator=g) + 0.05
+        # (leaf indices of its own: after learn() the speculating handle's sample buffers already hold the NEXT call's batch)
+        idx_ = torch.from_numpy(np.sort(rs.randint(0, 2048, 16)) + 2047).cuda()
+        beta_ = float(min(1.0, 0.4 + 0.002 * step))
+        outs = []
+        for agent, mem in twins:
+            if op == "learn":
+                agent.reset_noise()
+                agent.learn(mem)
+                outs.append(agent._loss.clone())
+            elif op == "act":
+                outs.append(torch.tensor([agent.act(st)]))
+            elif op == "evalq":
+                outs.append(torch.tensor([agent.evaluate_q(st)]))
+            elif op == "append":
+                mem.append(st, a_, r_, t_)
+            elif op == "append_batch":
+                mem.append_batch(fr, [a_] * 5, [r_] * 5, [t_, False, False, False, False])
+            elif op == "beta":
+                mem.priority_weight = beta_
+            elif op == "target":
+                agent.update_target_net()
+            elif op == "update":
+                mem.update_priorities(idx_, loss_)
+            elif op == "sample":
+                o = mem.sample_device(16)
+                outs.append(o["tree_idxs"].clone())
+            elif op == "header":
+                h = mem._header()
+                outs.append(torch.tensor([h.index, h.full, h.last_attempts, h.last_status, h.rng_counter], dtype=torch.float64))
+            elif op == "state_dict":
+                outs.append(agent.state_dict()["fc_z_a.weight_mu"].flatten()[:32].clone())
+        learns += op == "learn"
+        if outs:
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0].cpu(), outs[1].cpu()), (step, op)
+    assert learns > 80
+    (a1, m1), (a2, m2) = twins
+    assert torch.equal(a1.params.detach(), a2.params.detach()) and torch.equal(a1.target_params, a2.target_params)
+    s1, s2 = a1.optimiser.state[a1.params], a2.optimiser.state[a2.params]
+    assert torch.equal(s1["exp_avg"], s2["exp_avg"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
+    assert torch.equal(a1.noise, a2.noise) and torch.equal(a1.target_noise, a2.target_noise)
+    d1, d2 = m1._dump(), m2._dump()
+    for k in ("tree", "timestep", "action", "reward", "nonterminal"):
+        assert np.array_equal(d1[k], d2[k]), k
+    h1, h2 = m1._header(), m2._header()
+    assert (h1.index, h1.full, h1.max, h1.total, h1.rng_counter) == (h2.index, h2.full, h2.max, h2.total, h2.rng_counter)
+    assert m1.failed_samples() == m2.failed_samples() == 0
