@@ -272,6 +272,12 @@ int rb_learner_noise_job(rb_learner_t* l, int32_t which, rb_noise_job_t* out);
  * noisy=0 is online_net.eval() (mu only, model.py:46).                              */
 int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_dev,
                    float* q_dev, rb_stream_t stream);
+/* rb_learner_act for a caller that needs the result on the HOST at once (agent.py:53-55 returns a Python int; main.py:153 feeds it to
+ * the emulator): action_pinned / q_pinned are PINNED host words mapped on the device (hipHostMalloc / torch pin_memory); the call
+ * presets the action word, launches, polls the word in a compiled loop (falling back to a stream synchronise after ~10 ms) and
+ * returns the action and its value through action_out / q_out (either may be NULL).  One call instead of launch + a Python poll loop. */
+int rb_learner_act_wait(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_pinned, float* q_pinned,
+                        int32_t* action_out, float* q_out, rb_stream_t stream);
 /* The same for n states at once (vectorised actors; the reference acts on one state per call,
  * main.py:153 — this is that call batched): states f32[n][history][7056],
  * 1 <= n <= 4096 (beyond the learn step's 3*batch images the forward buffers are regrown once, synchronising — batched

@@ -98,6 +98,7 @@ SIGNATURES = {
     "rb_learner_noise_job": (c_int, [c_void_p, c_int32, C.POINTER(NoiseJob)]),
     "rb_learner_noise_draws": (c_int64, [C.POINTER(LearnerConfig)]),
     "rb_learner_act": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rb_learner_act_wait": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, C.POINTER(c_int32), C.POINTER(c_float), c_void_p]),
     "rb_learner_act_batch": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rb_learner_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),

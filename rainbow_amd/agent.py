@@ -352,28 +352,13 @@ class Agent:
         pins = self._pin_ptrs
         if pins is None or pins[2] is not self._act_pin:
             pins = self._pin_ptrs = (self._act_pin.data_ptr(), self._q_pin.data_ptr(), self._act_pin)
-        fn, stream = self._lib.rb_learner_act, current_stream_handle(self.device)
-        for attempt in range(2):
-            act[0] = _ACT_PENDING
-            rc = fn(self._h, st.data_ptr(), 1 if self.training else 0, pins[0], pins[1], stream)
-            if rc != 0:
-                L.check(self._lib, rc)
-            # completion = the pinned action word changes (the head writes q, fences, then the action): polling it returns
-            # ~5 us before a stream synchronize would (46 -> 41 us per act, tools/stamp/act_host.py); bounded, then the synchronize
-            for _ in range(20000):
-                if act[0] != _ACT_PENDING:
-                    break
-            else:
-                torch.cuda.current_stream(self.device).synchronize()
-            if act[0] >= 0:
-                return
-            torch.cuda.current_stream(self.device).synchronize()
-            if act[0] >= 0:
-                return
-            # an in-launch wait of THAT launch expired (its workgroups were not co-resident: another process on the GPU, CU
-            # masking).  The failure is tagged with the launch number, so the next launch starts clean: try once more.
-        raise RuntimeError("rb_learner_act: the one-launch act path reported an expired in-launch wait twice (action %d); "
-                           "RB_OPTS=act_fused=0 selects the per-layer launches" % int(act[0]))
+        # launch + wait in ONE C call: completion = the pinned action word changes (the head writes q, fences, then the action);
+        # the library polls it in a compiled loop (a Python loop over a numpy scalar sees the store a microsecond or two late),
+        # falls back to a stream synchronise, and retries once when the one-launch path reports an expired in-launch wait
+        rc = self._lib.rb_learner_act_wait(self._h, st.data_ptr(), 1 if self.training else 0, pins[0], pins[1], None, None,
+                                           current_stream_handle(self.device))
+        if rc != 0:
+            L.check(self._lib, rc)
 
     def act(self, state):
         """agent.py:53-55: greedy action on the expected value of the (noisy) online distribution."""

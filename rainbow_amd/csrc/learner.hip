@@ -1699,6 +1699,47 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
   return RB_OK;
 }
 
+// rb_learner_act + waiting for its result on the host, in one call (include/rainbow_hip.h): the action word is preset, the launch
+// goes out, and the pinned word is polled HERE — a compiled loop sees the head's store within tens of nanoseconds, a Python loop
+// over a numpy scalar within a microsecond or two, and the caller saves the interpreter's share of a 43 us act().
+int rb_learner_act_wait(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_pinned, float* q_pinned,
+                        int32_t* action_out, float* q_out, rb_stream_t stream) {
+  RB_REQUIRE(l && state_dev && action_pinned && q_pinned, "rb_learner_act_wait: NULL argument");
+  constexpr int32_t PENDING = -7;
+  int attempts = 0;
+  for (;;) {
+    *(volatile int32_t*)action_pinned = PENDING;
+    const int rc = rb_learner_act(l, state_dev, noisy, action_pinned, q_pinned, stream);
+    if (rc != RB_OK) return rc;
+#if !defined(RB_HOST_INTERP)
+    bool seen = false;
+    for (long spin = 0; spin < 4000000L; ++spin) {           // ~10 ms of polling, then the stream is synchronised instead
+      if (*(volatile int32_t*)action_pinned != PENDING) { seen = true; break; }
+    }
+    if (!seen) RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+#endif
+    int32_t a = *(volatile int32_t*)action_pinned;
+#if !defined(RB_HOST_INTERP)
+    if (a < 0) {                                             // an error code (or a torn view): the final word after a synchronise
+      RB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      a = *(volatile int32_t*)action_pinned;
+    }
+#endif
+    if (a >= 0) {
+      if (action_out) *action_out = a;
+      if (q_out) *q_out = *(volatile float*)q_pinned;        // (the head stores q, fences, then the action)
+      return RB_OK;
+    }
+    // the one-launch path reported an expired in-launch wait of THAT launch (its workgroups were not co-resident); the failure is
+    // tagged with the launch number, so the next launch starts clean: once more, then give up
+    if (++attempts >= 2) {
+      rb_set_error("rb_learner_act_wait: the one-launch act path reported an expired in-launch wait twice (action %d); "
+                   "RB_OPTS=act_fused=0 selects the per-layer launches", (int)a);
+      return RB_ERR_STATE;
+    }
+  }
+}
+
 // The forward buffers are sized for the learn step's 3B images; batched evaluation (test.py:38-39 over a 500-state
 // validation memory) may ask for more rows: grow them (synchronising; happens once per size).
 static int ensure_rows(rb_learner* l, int rows) {
