@@ -469,9 +469,7 @@ int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream);
 
 /* White-box access for parity tests: copies an internal activation to out_dev.
  * what: 0 log_ps_a [B][atoms], 1 m (projected target) [B][atoms], 2 argmax a* i32[B],
- *       3 pns_a [B][atoms], 4 logits [3B][atoms*(actions+1)],
- *       5 (RB_OPTS adam_split=1) u32[288]: [0] split optimiser passes that ran (k_adam_split launches), [32 + 32 s] pair workgroups
- *         arrived on shard s (0 <= s < 8).                                                                                     */
+ *       3 pns_a [B][atoms], 4 logits [3B][atoms*(actions+1)].                          */
 int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream);
 
 #ifdef __cplusplus

@@ -238,9 +238,3 @@ __device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int
 // The pending pass as a launch of its own through the HOSTED body (replay.hip k_adam_pending; arguments in device memory): what
 // runs a pass with (mu, sigma) pairing outside a sampler launch.  Returns a hipError_t as int.
 int rb_launch_adam_pending(const ClipAdamArgs* args_dev, int blocks, void* stream);
-// The (mu, sigma) pair workgroups of a pending pass as a launch of their own on ANOTHER stream (replay.hip k_adam_split; the
-// caller orders that stream behind the backward): every workgroup updates its pairs and arrives on the sharded counters `done`
-// (rb_fan_signal), which the consumer of the updated parameters — the hidden layer's forward of the next step — waits for
-// in-kernel (rb_fan_wait_total).  `ran` receives `epoch` (introspection: rb_learner_debug_read 5).
-int rb_launch_adam_split(const ClipAdamArgs* args_dev, int pair_blk0, int pair_blocks, unsigned epoch, unsigned* ran, unsigned* done,
-                         void* stream);

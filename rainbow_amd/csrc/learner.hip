@@ -219,22 +219,13 @@ struct rb_learner {
   ClipAdamArgs* adam_args_dev;   // the pending pass's arguments in device memory (rewritten only when they change)
   ClipAdamArgs adam_args_host;   // ... and what that memory holds
   int adam_args_valid, adam_pending, adam_blocks;
-  // Split pass (RB_OPTS adam_split=1; OFF by default: measured 177 us per step against 161.5, profiles/round5_split_experiments.txt).
-  // The pending pass's (mu, sigma) pair workgroups — 94 % of its bytes — run as k_adam_split on a second stream beside the
-  // sampler AND the conv forward launches of the next step (nothing before the hidden layer's forward reads the hidden layer's
-  // weights); the hosting sampler launch keeps the plain workgroups.  Edge A (backward -> second stream): an event recorded
-  // behind the backward, no timing, no system-scope fence.  Edge B (second stream -> hidden layer's forward): in-kernel, the
-  // forward's online-net workgroups wait for the pair workgroups' arrival total before their first weight load.
-  // What it measured: the sampler launch 35.6 -> 20.6 us as intended, but the event record leaves a 5.4 us gap on the step's
-  // stream and the first conv layer, running beside 4.7 TB/s of streaming, takes 30.8 us instead of 12.0.  The two other
-  // forms of edge A were worse: pair workgroups polling a flag in-kernel fill the CUs' register files ahead of the launch that
-  // sets it (a 256-thread workgroup of the 128-register sampler kernel then fits nowhere: a bounded-wait expiry per step), and
-  // hipStreamWaitValue32 is itself a polling KERNEL on this runtime (__amd_rocclr_streamOpsWait, 152 us per step, every
-  // kernel beside it slower: 287-395 us per step).
   // The early draw (RB_OPTS spec_draw; replay_internal.h rb_replay_spec_launch): from the third back-to-back rb_learner_train_step on
   // the same replay, the priority write-back leaves the hidden layer's backward launch and runs — together with the NEXT call's
   // draw — on the replay's own stream as soon as the head kernel is done; the next call's sampler launch accepts the draw and
   // carries only the noise and the pending optimiser pass.
+  // (A SPLIT optimiser pass — the (mu, sigma) pair workgroups on a second stream beside the sampler and the conv forward, the hidden
+  // layer's forward waiting in-kernel for their arrival — was built in round 5, bit-identical, and measured 177 us per step against
+  // 161.5: profiles/round5_split_experiments.txt; removed, the code is commit 645f60a.)
   int opt_spec_draw;
   unsigned* go_flag;          // device word: epoch of the last head kernel known complete (stored by the launch behind it)
   unsigned go_epoch;
@@ -242,14 +233,6 @@ struct rb_learner {
   rb_spec_request spec_req;
   struct { rb_replay_t* replay; int32_t batch, max_attempts; double beta; int64_t* tree_idx; int64_t* actions; float* returns; float* nonterm;
            float* weights; unsigned long long mut_after; int valid, streak; } ts_last;
-  int opt_adam_split;
-  hipStream_t stream2;
-  unsigned* split_words;      // device: [0] epoch of the last k_adam_split that ran, [RB_SPLIT_DONE ...] sharded arrivals
-  hipEvent_t split_event;
-  int split_event_recorded;
-  unsigned* split_err_host;   // pinned: 2 = a forward workgroup's bounded wait for the arrivals expired
-  unsigned split_epoch, split_total;
-  int split_armed;            // the next hidden-layer forward must wait for split_total arrivals
   // RB_LEARNER_IMPLICIT_SIGMA: the hidden layer's sigma-weight gradient is not stored by the backward; the hosted optimiser
   // pass forms it from g_mu and the noise the backward used (adam_body.h rb_adam_hosted_pairs).  sigma_implicit = the flat
   // gradient lacks that range right now; every other consumer of the gradient materialises it first (materialize_sigma)
@@ -264,10 +247,6 @@ struct rb_learner {
 #ifndef RB_SPEC_DRAW_DEFAULT
 #define RB_SPEC_DRAW_DEFAULT 1    // RB_OPTS spec_draw: see rb_learner::opt_spec_draw
 #endif
-#ifndef RB_ADAM_SPLIT_DEFAULT
-#define RB_ADAM_SPLIT_DEFAULT 0   // RB_OPTS adam_split: see rb_learner::opt_adam_split
-#endif
-#define RB_SPLIT_DONE 32      // word offset of the sharded arrival counters inside split_words
 static int flush_update(rb_learner* l, hipStream_t stream);
 #define RB_FLUSH_UPDATE(l, stream)                                  \
   do {                                                              \
@@ -1054,7 +1033,6 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     a.grp[0] = NlRowGroup{0, L.H, 0, 0, 0};
     a.grp[1] = NlRowGroup{L.H, L.H, 0, L.F, ht16};
     a.out = l->h; a.out_blocked = l->h_b; a.ld_out = 2 * L.H; a.rows_total = NI; a.relu = 1;
-    a.wait_ctr = nullptr; a.wait_total = 0; a.wait_err = nullptr;
     // batch 256: 64-row m-chunks halve the passes over the weights (at batch 32 one 64-row chunk for the online net's rows
     // reads every tile once instead of twice and is 7 us per step SLOWER: a workgroup's MFMAs are serial on its CU)
     const bool wide = m_max >= 128;
@@ -1076,13 +1054,7 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
       ga.S = S; ga.part = l->gemm_part; ga.ctr = l->gemm_ctr;
       RB_LAUNCH_T("fc_h_fwd:k_fc_gemm_fwd", k_fc_gemm_fwd, dim3((unsigned)(tiles * S)), dim3(RB_TG_THREADS), stream, ga);
     } else if (wide) { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<4>, hg, hb, stream, a); }
-    else {
-      if (l->split_armed) {      // the online net's hidden-layer weights are being updated on the second stream (train_step_impl)
-        a.wait_ctr = l->split_words + RB_SPLIT_DONE; a.wait_total = l->split_total; a.wait_err = l->split_err_host;
-        l->split_armed = 0;
-      }
-      RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a);
-    }
+    else { RB_LAUNCH_T("fc_h_fwd:k_nl_fwd3", k_nl_fwd3<2>, hg, hb, stream, a); }
     RB_LAUNCH_CHECK();
     // output layer: value rows read h[:, :H], advantage rows read h[:, H:]; bias fused
     NlFwd2Args z;
@@ -1094,7 +1066,6 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
     z.grp[0] = NlRowGroup{0, L.Z, 0, 0, 0};
     z.grp[1] = NlRowGroup{L.Z, L.NZ - L.Z, L.H, L.H, vt16};
     z.out = l->logits; z.out_blocked = nullptr; z.ld_out = L.NZ; z.rows_total = NI; z.relu = 0;
-    z.wait_ctr = nullptr; z.wait_total = 0; z.wait_err = nullptr;
     const dim3 zgrid((unsigned)(vt16 + at16), 1, 2 * mch32), zblock(64 * RB_NL_FWD_WAVES);
     if (wide) { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<4>, zgrid, zblock, stream, z); }
     else { RB_LAUNCH_T("fc_z_fwd:k_nl_fwd3", k_nl_fwd3<2>, zgrid, zblock, stream, z); }
@@ -1369,14 +1340,6 @@ int rb_learner_destroy(rb_learner_t* l) {
   if (l->job_dev) rb_dev_free(l->job_dev);
   if (l->status_copy) rb_dev_free(l->status_copy);
   if (l->adam_args_dev) rb_dev_free(l->adam_args_dev);
-#if !defined(RB_HOST_INTERP)
-  if (l->stream2) { (void)hipStreamSynchronize(l->stream2); (void)hipStreamDestroy(l->stream2); }
-  if (l->split_err_host) (void)hipHostFree(l->split_err_host);
-  if (l->split_event) (void)hipEventDestroy(l->split_event);
-#else
-  if (l->split_err_host) free(l->split_err_host);
-#endif
-  if (l->split_words) rb_dev_free(l->split_words);
   if (l->go_flag) rb_dev_free(l->go_flag);
   delete l;
   return RB_OK;
@@ -1496,23 +1459,6 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
     hipError_t e = rb_dev_malloc((void**)&l->go_flag, 64);
     if (e != hipSuccess) { rb_set_error("rb_learner_create: hipMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
     RB_HIP_TRY(hipMemset(l->go_flag, 0, 64));
-  }
-  l->opt_adam_split = rb_opt("adam_split", RB_ADAM_SPLIT_DEFAULT);
-  if (l->opt_adam_split) {
-    hipError_t e = rb_dev_malloc((void**)&l->split_words, (RB_SPLIT_DONE + RB_FAN_SHARDS * RB_FAN_STRIDE) * 4);
-    if (e != hipSuccess) { rb_set_error("rb_learner_create: hipMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
-    RB_HIP_TRY(hipMemset(l->split_words, 0, (RB_SPLIT_DONE + RB_FAN_SHARDS * RB_FAN_STRIDE) * 4));
-#if defined(RB_HOST_INTERP)
-    l->split_err_host = (unsigned*)calloc(1, sizeof(unsigned));
-#else
-    RB_HIP_TRY(hipHostMalloc((void**)&l->split_err_host, sizeof(unsigned), hipHostMallocMapped));
-    *l->split_err_host = 0u;
-    RB_HIP_TRY(hipStreamCreateWithFlags(&l->stream2, hipStreamNonBlocking));
-    if (hipEventCreateWithFlags(&l->split_event, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
-      (void)hipGetLastError();
-      RB_HIP_TRY(hipEventCreateWithFlags(&l->split_event, hipEventDisableTiming));
-    }
-#endif
   }
 #if defined(RB_HOST_INTERP)
   l->n_cu = 8;
@@ -2198,29 +2144,11 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
   rb_noise_job_t hosted_job;
   const rb_noise_job_t* job = a->noise_job;
   bool hosted = false;
-  int split_blocks = 0;
-  if (l->split_err_host && *(volatile unsigned*)l->split_err_host != 0u) {
-    rb_set_error("rb_learner_train_step: the hidden layer's forward did not see the split optimiser pass arrive within its "
-                 "bounded in-kernel wait (code %u); RB_OPTS=adam_split=0 keeps the whole pass in the sampler launch", *l->split_err_host);
-    return RB_ERR_STATE;
-  }
   if (l->adam_pending) {
     if (job != nullptr && a->batch <= 256) {
       memcpy(&hosted_job, job, sizeof(hosted_job));
       NoiseJob* nj = reinterpret_cast<NoiseJob*>(&hosted_job);
       nj->adam_dev = l->adam_args_dev; nj->adam_blocks = l->adam_blocks;
-      // split pass: the (mu, sigma) pair workgroups leave the sampler launch for the second stream when the hidden layer's
-      // forward of THIS step is the streamed kernel that can wait for them (k_nl_fwd3<2>: fewer than 128 rows per net, no
-      // tiled GEMM), the sampler launch can host at all (windows <= 24 slots) and no replica exchange sits in the step
-      const ClipAdamArgs& pa = l->adam_args_host;
-      ReplayView rv;
-      double om = 0.0;
-      if (l->opt_adam_split && comm == nullptr && pa.pair_len4 > 0 && pa.pair_blk0 > 0 && l->adam_blocks > pa.pair_blk0 &&
-          l->split_event_recorded && l->fast_fc && 2 * a->batch < 128 && l->opt_fc_gemm != 1 &&
-          rb_replay_internal_view(a->replay, &rv, &om) == RB_OK && rv.history + rv.n <= 24) {
-        split_blocks = l->adam_blocks - pa.pair_blk0;
-        nj->adam_blocks = pa.pair_blk0;
-      }
       job = &hosted_job;
       hosted = true;
     } else {
@@ -2250,27 +2178,6 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
                                         nullptr, a->actions_dev, a->returns_dev, a->nonterminals_dev, a->weights_dev,
                                         job, stream);
   if (rc != RB_OK) { l->spec_now = 0; return rc; }
-  if (split_blocks > 0) {
-    // (submitted after everything it depends on: whatever serialises launches in submission order — a counter-collecting
-    // profiler, HIP_LAUNCH_BLOCKING — still terminates)
-    ++l->split_epoch;
-#if defined(RB_HOST_INTERP)
-    void* s2 = stream;
-#else
-    void* s2 = l->stream2;
-    // the second stream joins the step's stream behind the backward whose gradient the pass consumes (recorded by clip_adam_impl
-    // when it left the pass pending): no workgroup of k_adam_split is admitted before, none ever waits in-kernel
-    RB_HIP_TRY(hipStreamWaitEvent(l->stream2, l->split_event, 0));
-#endif
-    rc = rb_launch_adam_split(l->adam_args_dev, l->adam_args_host.pair_blk0, split_blocks, l->split_epoch, l->split_words,
-                              l->split_words + RB_SPLIT_DONE, s2);
-    if (rc != RB_OK) {           // the plain workgroups have run, the pair range has not: finish it on the step's own stream
-      l->adam_pending = 0;
-      return rc;
-    }
-    l->split_total += (unsigned)split_blocks;
-    l->split_armed = 1;
-  }
   if (hosted) l->adam_pending = 0;
   // (the window table of THIS draw: an accepted early draw filled the replay's other table)
   rc = rb_learner_learn_windows(l, a->frames_dev, rb_replay_current_windows(a->replay), a->window_len, a->actions_dev, a->returns_dev,
@@ -2282,14 +2189,6 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
     t.actions = a->actions_dev; t.returns = a->returns_dev; t.nonterm = a->nonterminals_dev; t.weights = a->weights_dev;
     t.mut_after = rb_replay_mutations(a->replay); t.valid = rc == RB_OK ? 1 : 0;
   }
-#if !defined(RB_HOST_INTERP)
-  if (l->split_armed) {          // (the forward took a path that cannot wait in-kernel, or failed before it: join on the host)
-    (void)hipStreamSynchronize(l->stream2);
-    l->split_armed = 0;
-  }
-#else
-  l->split_armed = 0;
-#endif
   if (rc != RB_OK) return rc;
   if (comm) {      // replicas: the factor all-gather + the finishing launch between backward and clip (agent.py:96-97)
     rc = rb_learner_exchange_rccl(l, comm, stream);
@@ -2413,13 +2312,6 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
       }
       l->adam_pending = 1;
       l->adam_blocks = (int)grid;
-      l->split_event_recorded = 0;
-      if (l->opt_adam_split && a.pair_len4 > 0) {     // edge A of the split pass (train_step_impl): the gradient is final here
-#if !defined(RB_HOST_INTERP)
-        RB_HIP_TRY(hipEventRecord(l->split_event, stream));
-#endif
-        l->split_event_recorded = 1;
-      }
       return RB_OK;
     }
     RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3(grid), dim3(256), stream, a, f);
@@ -2705,9 +2597,6 @@ int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_strea
     case 2: src = l->a_star; bytes = (size_t)L.B * 4; break;
     case 3: src = l->pns_a; bytes = (size_t)L.B * L.Z * 4; break;
     case 4: src = l->logits; bytes = (size_t)3 * L.B * L.NZ * 4; break;
-    case 5:   // the split pass's device words: [0] = epoch of the last k_adam_split that ran, [32 + 32 s] = arrivals of shard s
-      if (!l->split_words) { rb_set_error("rb_learner_debug_read: the handle was created without RB_OPTS adam_split"); return RB_ERR_STATE; }
-      src = l->split_words; bytes = (size_t)(RB_SPLIT_DONE + RB_FAN_SHARDS * RB_FAN_STRIDE) * 4; break;
     default: rb_set_error("rb_learner_debug_read: unknown selector %d", what); return RB_ERR_INVALID;
   }
   RB_HIP_TRY(hipMemcpyAsync(out_dev, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -74,11 +74,6 @@ struct NlFwd2Args {
   float* out_blocked;       // optional k-blocked copy over ld_out columns
   int ld_out, rows_total;
   int relu;
-  // split optimiser pass (learner.hip train_step_impl): net 0's weights are being updated by k_adam_split on another stream;
-  // its workgroups wait for the arrival total before their first weight load (NULL: no wait).  Net 1 (the target net) never waits.
-  const unsigned* wait_ctr;
-  unsigned wait_total;
-  unsigned* wait_err;
 };
 
 // grid = (16-row tiles, 1, 2 * m-chunks of 16 MT rows), block = 512
@@ -168,17 +163,8 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
       for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4_buf(bx, xo[mt], so);
     }
   };
-  if (a.wait_ctr) {                                      // block-uniform (all workgroups of the launch agree on the branch)
-    // the activations and eps_in do not depend on the pass: request them first, wait, then the weights
 #pragma unroll
-    for (int d = 0; d < RING; ++d) load_x(d, blk_of(d));
-    if (net == 0) rb_fan_wait_total(a.wait_ctr, a.wait_total, a.wait_err);
-#pragma unroll
-    for (int d = 0; d < RING; ++d) load_w(d, blk_of(d));
-  } else {
-#pragma unroll
-    for (int d = 0; d < RING; ++d) { load_w(d, blk_of(d)); load_x(d, blk_of(d)); }
-  }
+  for (int d = 0; d < RING; ++d) { load_w(d, blk_of(d)); load_x(d, blk_of(d)); }
   __syncthreads();                                       // eps_in visible
   auto compute = [&](int d, int b) {
     const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[b * 32 + 4 * lk]);

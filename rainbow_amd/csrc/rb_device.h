@@ -177,33 +177,6 @@ __device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned t
 #endif
 }
 
-// The wait side for arrivals that are NOT spread evenly over the shards (a grid that is no multiple of 8): the SUM of the
-// shards against a monotonic total, followed by ONE agent-scope acquire, so that the caller's plain loads see what the
-// arrivers stored write-through.  All threads of the workgroup call.
-__device__ __forceinline__ void rb_fan_wait_total(const unsigned* counters, unsigned target_total, unsigned* err) {
-#if defined(RB_HOST_INTERP)
-  __syncthreads();
-  (void)counters; (void)target_total; (void)err;
-#else
-  if (threadIdx.x < 64) {
-    const int lane = (int)threadIdx.x;
-    unsigned spins = 0;
-    for (;;) {
-      unsigned v = 0;
-      if (lane < RB_FAN_SHARDS) v = __hip_atomic_load(counters + lane * RB_FAN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      if ((int)(__shfl(v, 0, 64) - target_total) >= 0) break;
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 16)) { if (lane == 0 && err) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-    if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-#endif
-}
-
 // A 4-byte load through a pointer the CALLER knows to be global memory: where a pointer is a runtime choice among several
 // kernel arguments (the three frame sources of the first conv layer) the compiler may fall back to a generic pointer and a FLAT
 // load, which also probes the LDS and scratch apertures; the address-space cast pins it to global_load.

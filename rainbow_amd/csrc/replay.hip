@@ -1143,16 +1143,6 @@ __global__ __launch_bounds__(256) void k_adam_pending(const ClipAdamArgs* ad) {
   rb_adam_hosted_block<4>(ad, (int)blockIdx.x, (int)gridDim.x, s_adam);
 }
 
-// the (mu, sigma) pair workgroups of the pending pass as a launch of their own (adam_body.h rb_launch_adam_split: a second
-// stream, ordered behind the backward by an event): workgroup b = pair workgroup b of the hosted pass, same body, same arithmetic
-__global__ __launch_bounds__(256) void k_adam_split(const ClipAdamArgs* ad, int pair_blk0, unsigned epoch, unsigned* ran, unsigned* done) {
-  __shared__ float s_adam[18];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && ran) *ran = epoch;
-  ClipAdamArgs a = *ad;
-  rb_adam_hosted_pairs(a, pair_blk0 + (int)blockIdx.x, (int)blockIdx.x, s_adam);
-  rb_fan_signal(done, (int)blockIdx.x);
-}
-
 static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, const double* unit_uniforms_dev,
                        int32_t max_attempts, int64_t* tree_idx_dev, uint8_t* states_dev, uint8_t* next_states_dev,
                        int64_t* actions_dev, float* returns_dev, float* nonterminals_dev, float* weights_dev,
@@ -1357,12 +1347,6 @@ int rb_u8_to_unit_f32(const uint8_t* src_dev, float* dst_dev, int64_t n, rb_stre
 }  // extern "C"
 
 // (C++ linkage: called by learner.hip flush_update, not part of the C ABI)
-int rb_launch_adam_split(const ClipAdamArgs* args_dev, int pair_blk0, int pair_blocks, unsigned epoch, unsigned* ran, unsigned* done,
-                         void* stream) {
-  RB_LAUNCH(k_adam_split, dim3((unsigned)pair_blocks), dim3(256), (hipStream_t)stream, args_dev, pair_blk0, epoch, ran, done);
-  RB_LAUNCH_CHECK();
-  return RB_OK;
-}
 int rb_launch_adam_pending(const ClipAdamArgs* args_dev, int blocks, void* stream) {
   RB_LAUNCH_T("clip_adam:k_adam_pending", k_adam_pending, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, args_dev);
   RB_LAUNCH_CHECK();

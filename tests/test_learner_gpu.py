@@ -578,16 +578,12 @@ def test_batched_evaluation_of_validation_memory(hip):
     assert qs.shape == (cap,) and np.all(np.isfinite(qs))
 
 
-@pytest.mark.parametrize("one_call,split,spec", [("1", False, False), ("0", False, False), ("1", True, False), ("1", False, True)],
-                         ids=["train_step", "three-calls", "train_step-split-pass", "train_step-early-draw"])
-def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch, one_call, split, spec):
-    """Fourth case, RB_OPTS spec_draw=1: from the third back-to-back learn() on, the priority write-back and the NEXT call's draw run
+@pytest.mark.parametrize("one_call,spec", [("1", False), ("0", False), ("1", True)],
+                         ids=["train_step", "three-calls", "train_step-early-draw"])
+def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monkeypatch, one_call, spec):
+    """Third case, RB_OPTS spec_draw=1: from the third back-to-back learn() on, the priority write-back and the NEXT call's draw run
     on the replay's own stream behind the head kernel, and the next sampler launch accepts the draw (act / target-sync / state_dict
     in between do not touch the replay: the streak goes on) — two streams, in-kernel flags, the same bits.
-    Third case, RB_OPTS adam_split=1: the pending pass's (mu, sigma) pair workgroups run as k_adam_split on the library's
-    second stream behind the flag the hosting sampler launch sets, and the hidden layer's forward waits in-kernel for their
-    arrival total — two streams, no host event, the same bits (the act / target-sync / state_dict calls in between take the
-    un-split paths).
     RAINBOW_AMD_DEFER_UPDATE (default on): Agent.learn leaves clip + Adam pending and the next learn's sampler launch
     hosts it (include/rainbow_hip.h RB_LEARNER_DEFER_UPDATE).  Against an agent with the switch off (same device-resident
     step number): 8 steps with acting, a target sync and a state_dict() in between — per-step losses, actions, parameters,
@@ -603,7 +599,7 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
         monkeypatch.setenv("RAINBOW_AMD_DEFER_UPDATE", defer)
         # RB_LEARNER_IMPLICIT_SIGMA rides on the deferral (the hosted pass forms the hidden layer's sigma gradient itself and
         # updates (mu, sigma) pairs together); the library switches it on from 1 M-element layers: force it on this small net
-        monkeypatch.setenv("RB_OPTS", "implicit_small=1" + (",adam_split=1" if split else "") + (",spec_draw=1" if spec and defer == "1" else ""))
+        monkeypatch.setenv("RB_OPTS", "implicit_small=1,spec_draw=%d" % (1 if spec and defer == "1" else 0))
         # the deferring agent through rb_learner_train_step or through the step's entry points one by one
         # (rb_learner_attach_pending / rb_learner_clip_adam_deferred: the path the replica exchange uses as well)
         monkeypatch.setenv("RAINBOW_AMD_ONE_CALL", one_call if defer == "1" else "1")
@@ -660,13 +656,7 @@ def test_deferred_update_agent_is_bit_identical_to_the_undeferred_one(hip, monke
     assert torch.equal(a1.grads, a2.grads) and torch.equal(a1._norm, a2._norm)
     assert int(a1._step_dev.item()) == int(a2._step_dev.item()) == 8
     assert np.array_equal(m1._grab("tree"), m2._grab("tree"))
-    if split:      # the pair workgroups really ran on the second stream (steps 1 and 2: the other pending passes were run by act /
-                   # update_target_net / state_dict / _norm as launches of their own)
-        words = torch.zeros(288, dtype=torch.int32, device="cuda")
-        L.check(a1._lib, a1._lib.rb_learner_debug_read(a1._h, 5, words.data_ptr(), a1._stream()))
-        torch.cuda.synchronize()
-        w = words.cpu().numpy()
-        assert int(w[0]) == 2 and int(w[32::32].sum()) > 0, w[:40]
+
 
 
 def test_checkpoint_restore_resumes_bit_exactly(hip, tmp_path):
