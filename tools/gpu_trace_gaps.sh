@@ -7,7 +7,7 @@ CFG=$1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT=$PWD
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/gaps -o gaps -- python $ROOT/bench.py --config $CFG --steps 60 --warmup 20 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/gaps.log 2>&1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/gaps -o gaps -- python $ROOT/bench.py --config $CFG --steps 60 --warmup 20 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/gaps.log 2>&1
 cd $ROOT
 python - <<'PY'
 import csv, glob, collections
