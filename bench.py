@@ -439,18 +439,23 @@ def main():
     B = cfg["batch_size"]
     fake_loss = torch.rand(B, device=dev) + 0.1
     # (donate=True: this loop never modifies its loss tensor between the call and the next draw, so the write-back reads it in place;
-    # without it the library copies caller-owned device operands at the call — +1.7 us per batch, tools/per_bench.py)
-    for _ in range(20):
-        o = mem.sample_device(B)
-        mem.update_priorities(o["tree_idxs"], fake_loss, donate=True)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for _ in range(per_iters):
-        o = mem.sample_device(B)
-        mem.update_priorities(o["tree_idxs"], fake_loss, donate=True)
-    mem.flush()                      # update_priorities is lazy (it rides in the next sampler launch): the last one runs inside the timed region
-    torch.cuda.synchronize(dev)
-    per_rate = per_iters * B / (time.perf_counter() - t1)
+    # the DEFAULT copies caller-owned device operands at the call, like the reference's immediate update — both are timed and
+    # reported, `per_samples_per_s` is the default, tools/per_bench.py)
+    def per_loop(donate):
+        for _ in range(20):
+            o = mem.sample_device(B)
+            mem.update_priorities(o["tree_idxs"], fake_loss, donate=donate)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(per_iters):
+            o = mem.sample_device(B)
+            mem.update_priorities(o["tree_idxs"], fake_loss, donate=donate)
+        mem.flush()                  # update_priorities is lazy (it rides in the next sampler launch): the last one runs inside the timed region
+        torch.cuda.synchronize(dev)
+        return per_iters * B / (time.perf_counter() - t1)
+    per_rate = per_loop(False)
+    per_rate_donate = per_loop(True)
+    assert mem.expired_waits() == 0, "a cross-stream wait of the early draw expired during the run"
 
     if rank == 0:
         ms_per_step = elapsed / opt.steps * 1e3
@@ -464,6 +469,7 @@ def main():
                        "global_batch": B * world, "atoms": 51, "actions": cfg["actions"], "multi_step": cfg["multi_step"],
                        "replay_capacity_per_gpu": cfg["capacity"], "parallelism": par},
             "per_samples_per_s": per_rate * world,
+            "early_draw": "spec_draw=1" in os.environ.get("RB_OPTS", ""),     # (opt-in: only an append-free loop like this one arms it)
             "ms_per_step_unbracketed": plain_ms,
             "library_source_hash": L.source_hash(lib),
         }
@@ -475,7 +481,8 @@ def main():
         per_bytes = (4 + cfg["multi_step"] + 2 * 4) * 7056          # history 4 in every BASELINE config
         out["roofline_per"] = {"bound": "hbm", "achieved": per_rate * per_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": per_rate * per_bytes / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_sample": per_bytes,
-                               "batch": B, "us_per_batch": 1e6 * B / per_rate,
+                               "batch": B, "us_per_batch": 1e6 * B / per_rate, "donate": False,
+                               "samples_per_s_with_donate": per_rate_donate * world,
                                "binding": "latency: one batch in flight = 2 dependent launches (update of batch k + draw of batch k + 1 "
                                           "as one single-workgroup chain, then the frame gather); up to 64 leaves per write-back, "
                                           "else 3 launches; bytes are 0.1% of what HBM moves in that time"}

@@ -172,13 +172,20 @@ int rb_replay_failed_samples(rb_replay_t* r, int64_t* count_host);
 /* Zero that counter (after the caller has reported the failure and, e.g., appended more transitions).  A learn step that
  * consumed a failed batch left no trace: its priority write-back (rb_replay_update_priorities and the learner's fused
  * sink: by the mark in the index buffer, rb_replay_dropped_updates), the optimiser update and the optimiser's step number
- * (by last_status of the draw the learn call consumes) are all skipped on the device.  Also zeroes the dropped-update count. */
+ * (by last_status of the draw the learn call consumes) are all skipped on the device.  Also zeroes the dropped-update count
+ * and the expired-wait count (rb_replay_expired_waits: the early draw is allowed again). */
 int rb_replay_reset_failed_samples(rb_replay_t* r);
 /* A draw that gave up marks its own index buffer (every tree index = -1).  ReplayMemory.update_priorities (memory.py:157-159)
  * — rb_replay_update_priorities, rb_replay_update_sample and the learner's fused sink — drops exactly the write-back whose
  * indices carry that mark and counts it here (pinned host word, read WITHOUT synchronising: completed launches so far).  The
  * write-back of an earlier, valid batch is applied whatever happened to later draws.                                        */
 int rb_replay_dropped_updates(rb_replay_t* r, int64_t* count_host);
+/* The early draw (RB_OPTS spec_draw=1, off by default: rb_learner_train_step may issue ReplayMemory.update_priorities of call k and
+ * ReplayMemory.sample of call k + 1 — agent.py:100 / :63, memory.py:124-159 — on a stream the replay owns) waits across streams with
+ * a bound of ~2 ms and fails safe: an expired wait makes the waiting launch do the work itself (the draw) or drop it (the
+ * write-back: also counted by rb_replay_dropped_updates), is counted here (pinned host word, read WITHOUT synchronising) and
+ * switches the early draw off on this handle until rb_replay_reset_failed_samples.  0 on a healthy device.                      */
+int rb_replay_expired_waits(rb_replay_t* r, int64_t* count_host);
 /* SegmentTree.index / .full (memory.py:14,16) from the library's host mirror, without touching the device: exact as long
  * as every append went through this handle (a header restored with rb_copy_to_device is picked up as well).        */
 int rb_replay_position(rb_replay_t* r, int64_t* index_host, int32_t* full_host);
@@ -445,9 +452,12 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream);
  * A one-rank communicator with a two-block exchange buffer (the single-GPU plumbing run, RAINBOW_AMD_FORCE_DIST=1) gathers
  * into block 0 and copies it to block 1.  Replaces the [caller: all-gather] step above; insert point agent.py:96-97.        */
 typedef struct rb_comm rb_comm_t;
+/* 1 when librccl can be loaded by this process (dlopen + symbol lookup only: creates nothing), else 0.  What every rank asks
+ * before the group decides whether to build library-owned communicators; only rank 0 then calls rb_comm_unique_id.          */
+int rb_comm_available(void);
 int rb_comm_unique_id(void* id128);
 int rb_comm_create(rb_comm_t** out, const void* id128, int32_t world, int32_t rank);
-int rb_comm_destroy(rb_comm_t* comm);
+int rb_comm_destroy(rb_comm_t* comm);   /* waits for the stream of the communicator's last all-gather first */
 int rb_learner_exchange_rccl(rb_learner_t* l, rb_comm_t* comm, rb_stream_t stream);
 /* rb_learner_train_step with the exchange in its place (sampler + noise, learn, exchange_rccl, clip + Adam): the replica
  * step as ONE C call.  Needs rb_learner_set_exchange to be armed for comm's world size.                                  */

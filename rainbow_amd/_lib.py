@@ -78,6 +78,7 @@ SIGNATURES = {
     "rb_replay_failed_samples": (c_int, [c_void_p, C.POINTER(c_int64)]),
     "rb_replay_reset_failed_samples": (c_int, [c_void_p]),
     "rb_replay_dropped_updates": (c_int, [c_void_p, C.POINTER(c_int64)]),
+    "rb_replay_expired_waits": (c_int, [c_void_p, C.POINTER(c_int64)]),
     "rb_replay_position": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_int32)]),
     "rb_replay_sample_fused_noise": (c_int, [c_void_p, c_int32, c_double, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(NoiseJob), c_void_p]),
@@ -123,6 +124,7 @@ SIGNATURES = {
     "rb_learner_set_exchange": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "rb_learner_wait_factors": (c_int, [c_void_p, c_void_p]),
     "rb_learner_finish_grads": (c_int, [c_void_p, c_void_p]),
+    "rb_comm_available": (c_int, []),
     "rb_comm_unique_id": (c_int, [c_void_p]),
     "rb_comm_create": (c_int, [C.POINTER(c_void_p), c_void_p, c_int32, c_int32]),
     "rb_comm_destroy": (c_int, [c_void_p]),

@@ -219,14 +219,17 @@ struct rb_learner {
   ClipAdamArgs* adam_args_dev;   // the pending pass's arguments in device memory (rewritten only when they change)
   ClipAdamArgs adam_args_host;   // ... and what that memory holds
   int adam_args_valid, adam_pending, adam_blocks;
-  // The early draw (RB_OPTS spec_draw; replay_internal.h rb_replay_spec_launch): from the third back-to-back rb_learner_train_step on
-  // the same replay, the priority write-back leaves the hidden layer's backward launch and runs — together with the NEXT call's
-  // draw — on the replay's own stream as soon as the head kernel is done; the next call's sampler launch accepts the draw and
-  // carries only the noise and the pending optimiser pass.
+  // The early draw (RB_OPTS spec_draw=1, OFF by default; replay_internal.h rb_replay_spec_launch): from the second back-to-back
+  // rb_learner_train_step on the same replay with nothing in between, the priority write-back leaves the hidden layer's backward
+  // launch and runs — together with the NEXT call's draw — on the replay's own stream as soon as the head kernel is done; the next
+  // call's sampler launch accepts the draw and carries only the noise and the pending optimiser pass.  Only an append-free,
+  // constant-beta loop ever arms it (a PER benchmark; never main.py's loop), every wait is bounded at ~2 ms and fails safe, and the
+  // first expiry disables it on the handle.  opt_spec_stall (RB_OPTS spec_stall=1, test hook): the launch behind the head kernel does
+  // not store the go flag — the gate in front of the pair expires.
   // (A SPLIT optimiser pass — the (mu, sigma) pair workgroups on a second stream beside the sampler and the conv forward, the hidden
   // layer's forward waiting in-kernel for their arrival — was built in round 5, bit-identical, and measured 177 us per step against
   // 161.5: profiles/round5_split_experiments.txt; removed, the code is commit 645f60a.)
-  int opt_spec_draw;
+  int opt_spec_draw, opt_spec_stall;
   unsigned* go_flag;          // device word: epoch of the last head kernel known complete (stored by the launch behind it)
   unsigned go_epoch;
   int spec_now;               // this train_step: the write-back and the next draw go to the replay's stream
@@ -245,7 +248,7 @@ struct rb_learner {
 };
 
 #ifndef RB_SPEC_DRAW_DEFAULT
-#define RB_SPEC_DRAW_DEFAULT 1    // RB_OPTS spec_draw: see rb_learner::opt_spec_draw
+#define RB_SPEC_DRAW_DEFAULT 0    // RB_OPTS spec_draw: see rb_learner::opt_spec_draw (opt-in: only append-free loops ever arm it)
 #endif
 static int flush_update(rb_learner* l, hipStream_t stream);
 #define RB_FLUSH_UPDATE(l, stream)                                  \
@@ -1455,6 +1458,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   RB_HIP_TRY(hipMemset(l->act_ctr, 0, (6 * RB_FAN_SHARDS * RB_FAN_STRIDE + 32) * 4));
   l->opt_act_fused = rb_opt("act_fused", 1);
   l->opt_spec_draw = rb_opt("spec_draw", RB_SPEC_DRAW_DEFAULT);
+  l->opt_spec_stall = rb_opt("spec_stall", 0);
   if (l->opt_spec_draw) {
     hipError_t e = rb_dev_malloc((void**)&l->go_flag, 64);
     if (e != hipSuccess) { rb_set_error("rb_learner_create: hipMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
@@ -1581,13 +1585,8 @@ static int act_forward_single(rb_learner* l, const float* state_dev, const NetPt
   z.x = l->h; z.w = nl_z(on); z.K = L.H; z.n_rows = L.NZ; z.split_row = L.Z; z.x_off1 = L.H; z.ein_off1 = L.H;
   z.out = l->logits; z.relu = 0; z.mu_only = noisy ? 0 : 1;
   bool can_fuse = l->opt_act_fused != 0;
-#if !defined(RB_HOST_INTERP)
-  {
-    // (a captured launch would replay a stale launch number: under stream capture the per-layer launches below run instead)
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) can_fuse = false;
-  }
-#endif
+  // (a captured launch would replay a stale launch number: under stream capture the per-layer launches below run instead)
+  if (can_fuse && rb_stream_capturing(stream)) can_fuse = false;
   if (can_fuse) {
     // ONE persistent launch (act_path.h k_act_fused): G workgroups, one per CU, all resident — the in-launch waits need that
     f.Z = L.Z; f.A = L.A; f.logits = l->logits; f.support = l->support; f.action_out = head_action_out; f.q_out = head_q_out;
@@ -1907,7 +1906,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : hp.dw_y, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
     NlPriorityUpdate up;
     memset(&up, 0, sizeof(up));
-    const bool spec = l->spec_now && l->sink && B <= 256 && !exch;     // the write-back leaves this launch for the replay's stream
+    // the write-back leaves this launch for the replay's stream (decided HERE, once: an expiry seen later only affects the next call)
+    const bool spec = l->spec_now && l->sink && B <= 256 && !exch && rb_replay_spec_allowed(l->sink);
     if (l->sink && B <= 256 && !spec) {
       up.enabled = 1; up.tree_idx = l->sink_idx; up.loss = loss_dev; up.n = B;
       if (rb_replay_internal_view(l->sink, &up.view, &up.omega) != RB_OK) {
@@ -1918,7 +1918,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     {
       NlPriorityUpdate none;
       memset(&none, 0, sizeof(none));
-      if (spec) { none.go_flag = l->go_flag; none.go_epoch = ++l->go_epoch; }
+      if (spec) { none.go_flag = l->opt_spec_stall ? nullptr : l->go_flag; none.go_epoch = ++l->go_epoch; }
       const dim3 zgrid_((unsigned)(zg.dw_x * zg.dw_y + zg.dx_x * zg.dx_y * zg.dx_z));
       if (z_tall) { RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd<true>, zgrid_, dim3(64 * RB_NL_DXT_WAVES), stream, zw, zx, zg, none); }
       else { RB_LAUNCH_T("fc_z_bwd:k_nl_bwd", k_nl_bwd<false>, zgrid_, dim3(256), stream, zw, zx, zg, none); }
@@ -2156,16 +2156,21 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
       if (rc != RB_OK) return rc;
     }
   }
-  // the early draw: from the third consecutive call with the same replay, batch, beta and buffers — and nothing else having touched
-  // the replay in between — this call's write-back and the next call's draw leave for the replay's stream behind the head kernel
+  // the early draw (RB_OPTS spec_draw=1; off by default): from the SECOND consecutive call with the same replay, batch, beta and
+  // buffers — and nothing else having touched the replay in between — this call's write-back and the next call's draw leave for the
+  // replay's stream behind the head kernel.  main.py's loop never meets the condition (it appends and anneals beta between learn
+  // calls, main.py:157,161): this is for append-free loops only (a PER benchmark, bench.py).  Never under stream capture: the pair
+  // would be launched now, outside the graph, waiting for a flag the captured kernels only store on replay.
   {
     auto& t = l->ts_last;
-    const bool same = t.valid && t.replay == a->replay && t.batch == a->batch && t.max_attempts == a->max_attempts && t.beta == a->priority_weight &&
+    const bool capturing = l->opt_spec_draw && rb_stream_capturing(stream);
+    const bool same = !capturing && t.valid && t.replay == a->replay && t.batch == a->batch && t.max_attempts == a->max_attempts &&
+                      t.beta == a->priority_weight &&
                       t.tree_idx == a->tree_idx_dev && t.actions == a->actions_dev && t.returns == a->returns_dev &&
                       t.nonterm == a->nonterminals_dev && t.weights == a->weights_dev && t.mut_after == rb_replay_mutations(a->replay);
     t.streak = same ? t.streak + 1 : 0;
     l->spec_now = (l->opt_spec_draw && t.streak >= 1 && comm == nullptr && a->noise_job != nullptr && a->batch <= 256 && l->fast_fc &&
-                   l->sink == a->replay && l->sink_idx == a->tree_idx_dev) ? 1 : 0;
+                   l->sink == a->replay && l->sink_idx == a->tree_idx_dev && rb_replay_spec_allowed(a->replay)) ? 1 : 0;
     if (l->spec_now) {
       rb_spec_request& q = l->spec_req;
       memset(&q, 0, sizeof(q));
@@ -2173,6 +2178,7 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
       q.tree_idx = a->tree_idx_dev; q.actions = a->actions_dev; q.returns = a->returns_dev; q.nonterminals = a->nonterminals_dev;
       q.weights = a->weights_dev;
     }
+    if (l->opt_spec_draw && !capturing) rb_replay_spec_arm_accept(a->replay);     // only THIS caller reads the table of the accepted draw
   }
   int rc = rb_replay_sample_fused_noise(a->replay, a->batch, a->priority_weight, nullptr, a->max_attempts, a->tree_idx_dev, nullptr,
                                         nullptr, a->actions_dev, a->returns_dev, a->nonterminals_dev, a->weights_dev,
@@ -2405,7 +2411,17 @@ static RbNccl* rb_nccl() {
 struct rb_comm {
   void* comm;
   int world, rank;
+  hipStream_t last_stream = nullptr;   // stream of the last all-gather (rb_comm_destroy waits for it)
+  int used = 0;
 };
+
+int rb_comm_available(void) {
+#if defined(RB_HOST_INTERP)
+  return 0;
+#else
+  return rb_nccl() ? 1 : 0;        // dlopen + dlsym only: no bootstrap id, no listener thread
+#endif
+}
 
 int rb_comm_unique_id(void* id128) {
   RB_REQUIRE(id128 != nullptr, "rb_comm_unique_id: NULL argument");
@@ -2446,6 +2462,8 @@ int rb_comm_destroy(rb_comm_t* comm) {
   if (!comm) return RB_OK;
 #if !defined(RB_HOST_INTERP)
   RbNccl* n = rb_nccl();
+  // the all-gather of the last exchange may still be in flight on the stream it was issued on
+  if (comm->used) (void)hipStreamSynchronize(comm->last_stream);
   if (n && comm->comm) n->CommDestroy(comm->comm);
 #endif
   delete comm;
@@ -2466,6 +2484,7 @@ int rb_learner_exchange_rccl(rb_learner_t* l, rb_comm_t* comm, rb_stream_t strea
   hipStream_t stream = (hipStream_t)stream_;
   float* all = const_cast<float*>(l->fact_all);
   RB_NCCL_TRY(n, n->AllGather(l->fact_local, all, (size_t)l->fact_stride, /* ncclFloat32 */ 7, comm->comm, stream));
+  comm->last_stream = stream; comm->used = 1;
   if (comm->world == 1 && l->world == 2)      // single-GPU plumbing run: the lone block stands for both replicas
     RB_HIP_TRY(hipMemcpyAsync(all + l->fact_stride, all, (size_t)l->fact_stride * 4, hipMemcpyDeviceToDevice, stream));
   return rb_learner_finish_grads(l, stream_);

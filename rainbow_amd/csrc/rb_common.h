@@ -43,6 +43,18 @@ void rb_dev_free(void* p);
 
 static inline int64_t rb_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Is `stream` being captured into a hipGraph right now?  (A query error counts as "yes": the callers take the conservative path.)
+// Whatever a captured launch bakes in is replayed verbatim: nothing in it may depend on work outside the graph or on a launch number.
+static inline bool rb_stream_capturing(void* stream) {
+#if defined(RB_HOST_INTERP)
+  (void)stream;
+  return false;
+#else
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+#endif
+}
+
 // ---- RB_OPTS="key=value,key=value": the library's ONE tuning / test-hook variable (common.hip; DESIGN.md §8 lists the keys).
 // Returns `dflt` when the key is absent.  Read when a handle is created, never per launch.
 int rb_opt(const char* key, int dflt);

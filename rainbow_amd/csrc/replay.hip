@@ -59,6 +59,10 @@ struct rb_replay {
   int spec_inflight;
   struct { int32_t batch, max_attempts, win_set; double beta; int64_t* tree_idx; int64_t* actions; float* returns; float* nonterm; float* weights; } spec_args;
   unsigned long long mutations;   // entry points that changed the replay (or drew from it) so far
+  int spec_accept_armed;          // the NEXT draw on the handle may accept a tentative draw (set by rb_learner_train_step only, one shot:
+                                  // the public sample entry points always redraw into table 0 = rb_replay_buffers_t.window_dev)
+  int spec_disabled;              // an expired cross-stream wait was seen (fail_host[2]): no early draw on this handle until
+                                  // rb_replay_reset_failed_samples
 };
 static int32_t* win_of(const rb_replay* r, int set) { return set ? r->win2 : r->win; }
 // every entry point that reads or writes the replay outside a draw: wait for an early draw in flight and discard it (its
@@ -488,7 +492,7 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
                                                float* nonterminals_out, float* weights_out, int32_t* fail_count, int32_t lds_top,
                                                int* s_flag, float* s_red, float* s_top, bool top_staged, SpecResult* spec = nullptr,
                                                unsigned spec_epoch = 0u);
-__device__ __forceinline__ void rb_wait_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host);
+__device__ __forceinline__ int rb_poll_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host);
 template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
@@ -519,20 +523,26 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
   // spec_mode (the early draw, replay_internal.h): 1 = THIS is the tentative draw; 2 = an early draw is in flight on another stream
-  // and is accepted: wait for it, commit its header effects, done; 3 = in flight but not acceptable (other arguments): wait, then
-  // draw as usual (it wrote the same output buffers)
+  // and is accepted: wait for it, commit its header effects, done; 3 = in flight but not acceptable (other arguments, or a public
+  // entry point): wait, then draw as usual.  FAIL SAFE: when the wait expires, or the pair on the other stream reports that it
+  // gave up (SPEC_ABORTED: its gate expired), mode 2 draws here as well — the header was never touched by the tentative draw, so
+  // this is exactly the draw a launch without an early draw would have made.
   if (spec_mode >= 2) {
-    rb_wait_epoch(&spec->done, spec_epoch, fail_count ? fail_count + 2 : nullptr);
-    if (spec_mode == 2) {
-      if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {           // ONE lane waits, decides and commits (the decision goes to the others through LDS)
+      int accept = rb_poll_epoch(&spec->done, spec_epoch, fail_count ? fail_count + 2 : nullptr);
+      if (spec_mode != 2 || spec->status == RB_SPEC_ABORTED) accept = 0;
+      if (accept) {
         const int32_t st = spec->status;
         v.hdr->last_attempts = spec->attempts;
         v.hdr->last_status = st;
         v.hdr->rng_counter = spec->rng_next;
         if (st != 0 && fail_count) rb_atomic_inc_system(fail_count);
       }
-      return;
+      s_flag[15] = accept;
     }
+    __syncthreads();
+    if (s_flag[15]) return;                               // block-uniform
+    __syncthreads();                                      // (s_flag is reused by the sampler proper)
   }
   rb_sample_main<MAXT>(v, batch, neg_beta_arg, neg_beta_ptr, unit_uniforms, max_attempts, seed, scaling, tree_idx_out, win, actions_out,
                        returns_out, nonterminals_out, weights_out, fail_count, lds_top, s_flag, s_red, s_top, false,
@@ -668,23 +678,33 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
   RB_STAMP_AT(5);
 }
 
-// wait for *flag >= epoch (one lane polls, relaxed; then ONE agent-scope acquire; all threads call).  The bound is seconds: the
-// producers are launches submitted EARLIER (a head kernel, an early draw), so an expiry means the device is wedged anyway.
-__device__ __forceinline__ void rb_wait_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host) {
+// wait for *flag >= epoch (one lane polls, relaxed; then ONE agent-scope acquire; all threads call).  Returns 1 when the flag
+// arrived, 0 when the bound (RB_WAIT_EPOCH_POLLS polls, ~2 ms) expired — counted in *err_host.  The producers are launches submitted
+// EARLIER (a head kernel, an early draw), so an expiry means something serialises the two queues against each other (a profiler's
+// counter pass does) or the device is wedged; every caller FAILS SAFE: it does the work in its own launch instead (k_sample) or
+// drops it and says so (k_spec_gate -> k_update_sample), never proceeds on data that may not be final.
+#define RB_WAIT_EPOCH_POLLS (1u << 13)
+// (the polling lane's part: returns 1 when the flag arrived; ends with the agent-scope acquire either way)
+__device__ __forceinline__ int rb_poll_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host) {
 #if defined(RB_HOST_INTERP)
-  if (threadIdx.x == 0 && (int)(*flag - epoch) < 0 && err_host) *err_host = 1;      // launches run in submission order there
-  __syncthreads();
+  const int ok = (int)(*flag - epoch) >= 0;             // launches run in submission order there
+  if (!ok && err_host) *err_host = *err_host + 1;
+  return ok;
 #else
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 22)) { if (err_host) rb_atomic_inc_system(err_host); break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  unsigned spins = 0;
+  int ok = 1;
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > RB_WAIT_EPOCH_POLLS) { ok = 0; if (err_host) rb_atomic_inc_system(err_host); break; }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
 #endif
+}
+__device__ __forceinline__ int rb_wait_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host, int* s_ok) {
+  if (threadIdx.x == 0) *s_ok = rb_poll_epoch(flag, epoch, err_host);
+  __syncthreads();
+  return *s_ok;
 }
 
 // Frame-stack gather (memory.py:136-138 minus the /255): block = (sample, stack slot),
@@ -715,10 +735,8 @@ __global__ __launch_bounds__(256) void k_gather_stacks(ReplayView v, int32_t bat
 // ---------------------------------------------------------------------- update --
 // (body: replay_internal.h)
 __global__ __launch_bounds__(1024) void k_update(ReplayView v, const int64_t* tree_idx, const float* values, int32_t n,
-                                                  int32_t apply_pow, double omega, const unsigned* go_flag, unsigned go_epoch,
-                                                  int32_t* err_host) {
+                                                  int32_t apply_pow, double omega) {
   __shared__ float lds[UpdateLds<2048, 1024>::WORDS];
-  if (go_flag) rb_wait_epoch(go_flag, go_epoch, err_host);      // (the early write-back: its losses come from another stream)
   rb_update_auto<2048, 1024>(v, tree_idx, values, n, apply_pow, omega, lds);
 }
 
@@ -734,15 +752,42 @@ __global__ __launch_bounds__(256) void k_update_sample(ReplayView v, const int64
                                                         const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts,
                                                         uint64_t seed, const float* scaling, int64_t* tree_idx_out, int32_t* win,
                                                         int64_t* actions_out, float* returns_out, float* nonterminals_out,
-                                                        float* weights_out, int32_t* fail_count, const unsigned* go_flag,
-                                                        unsigned go_epoch, SpecResult* spec, unsigned spec_epoch) {
+                                                        float* weights_out, int32_t* fail_count, SpecResult* spec, unsigned spec_epoch) {
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
   __shared__ float lds_upd[UpdateLds<512, 256>::WORDS];
   __shared__ int s_sorted;
   const int i = (int)threadIdx.x;
-  if (go_flag) rb_wait_epoch(go_flag, go_epoch, fail_count ? fail_count + 2 : nullptr);   // (the early pair: the losses come from another stream)
+  if (spec) {
+    // the early pair (rb_replay_spec_launch): the gate in front of this launch (same stream) waited for the head kernel of the learn
+    // call whose losses are written back here.  If the gate EXPIRED the losses may not be final: give up — no write-back (counted as a
+    // dropped one), no draw; the record says so and the accepting sampler launch draws itself (k_sample, spec_mode 2)
+    if (i == 0) {
+#if defined(RB_HOST_INTERP)
+      s_flag[0] = spec->abort_epoch == spec_epoch ? 1 : 0;
+#else
+      s_flag[0] = __hip_atomic_load(&spec->abort_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == spec_epoch ? 1 : 0;
+#endif
+    }
+    __syncthreads();
+    const int aborted = s_flag[0];
+    __syncthreads();
+    if (aborted) {                                        // block-uniform
+      if (i == 0) {
+        spec->attempts = 0; spec->status = RB_SPEC_ABORTED;
+        if (v.dropped) rb_atomic_inc_system(v.dropped);
+#if defined(RB_HOST_INTERP)
+        spec->done = spec_epoch;
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&spec->done, spec_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      }
+      return;
+    }
+  }
   const int n_cached = (int)(v.tree_len < RB_TOP_NODES ? v.tree_len : RB_TOP_NODES);
   UpdateOperand op;
   op.node = -1; op.val = 0.0f; op.status = 0; op.sorted = 0;
@@ -856,8 +901,17 @@ void rb_replay_note_device_write(void* dst_dev, const void* src_host, size_t nby
 // do the waiting: submitted a whole step ahead of the device, a 256-thread / 50 KB workgroup polling on a CU takes that CU away
 // from every launch of the step that needs all 256 (the batch-256 conv kernels are one LDS-filling workgroup per CU: each of them
 // ran a second round for ONE workgroup — 498 -> 650 us per step, measured); a lone wave fits beside anything.
-__global__ __launch_bounds__(64) void k_spec_gate(const unsigned* flag, unsigned epoch, int32_t* err_host) {
-  rb_wait_epoch(flag, epoch, err_host);
+__global__ __launch_bounds__(64) void k_spec_gate(const unsigned* flag, unsigned epoch, int32_t* err_host, SpecResult* spec, unsigned spec_epoch) {
+  __shared__ int s_ok;
+  if (!rb_wait_epoch(flag, epoch, err_host, &s_ok) && threadIdx.x == 0) {
+    // the head kernel's launch was not seen to complete within the bound: the pair behind this gate must NOT read its losses.  It is
+    // told to give up (k_update_sample: no write-back — counted as dropped — and no draw; the accepting launch draws itself)
+#if defined(RB_HOST_INTERP)
+    spec->abort_epoch = spec_epoch;
+#else
+    __hip_atomic_store(&spec->abort_epoch, spec_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  }
 }
 
 int rb_replay_spec_inflight(rb_replay_t* r) { return r ? r->spec_inflight : 0; }
@@ -865,9 +919,16 @@ const int32_t* rb_replay_current_windows(rb_replay_t* r) { return win_of(r, r->w
 unsigned long long rb_replay_mutations(rb_replay_t* r) { return r->mutations; }
 
 // (replay_internal.h) the write-back of learn call k + the tentative draw of call k + 1 on the replay's own stream
+int rb_replay_spec_allowed(rb_replay_t* r) {
+  if (!r) return 0;
+  if (*(volatile int32_t*)(r->fail_host + 2) != 0) r->spec_disabled = 1;   // an expired wait: the handle stays without early draws
+  return r->spec_disabled ? 0 : 1;
+}
+void rb_replay_spec_arm_accept(rb_replay_t* r) { r->spec_accept_armed = 1; }
+
 int rb_replay_spec_launch(rb_replay_t* r, const rb_spec_request& q) {
   RB_REQUIRE(r && q.upd_idx && q.upd_loss && q.tree_idx && q.actions && q.returns && q.nonterminals && q.weights, "rb_replay_spec_launch: NULL argument");
-  RB_REQUIRE(q.batch >= 1 && q.batch <= 256 && q.upd_n >= 1 && q.upd_n <= 1024, "rb_replay_spec_launch: batch must be in [1,256], upd_n in [1,1024]");
+  RB_REQUIRE(q.batch >= 1 && q.batch <= 256 && q.upd_n >= 1 && q.upd_n <= 256, "rb_replay_spec_launch: batch and upd_n must be in [1,256]");
   RB_REQUIRE(r->capacity > (int64_t)r->history + r->n, "rb_replay_spec_launch: capacity must exceed history + multi_step");
   RB_SPEC_JOIN(r);
 #if defined(RB_HOST_INTERP)
@@ -882,26 +943,15 @@ int rb_replay_spec_launch(rb_replay_t* r, const rb_spec_request& q) {
   const unsigned epoch = ++r->spec_epoch;
   ++r->mutations;
   if (q.go_flag) {
-    RB_LAUNCH(k_spec_gate, dim3(1), dim3(64), s2, q.go_flag, q.go_epoch, r->fail_host + 2);
+    RB_LAUNCH(k_spec_gate, dim3(1), dim3(64), s2, q.go_flag, q.go_epoch, r->fail_host + 2, r->spec_res, epoch);
     RB_LAUNCH_CHECK();
   }
-  if (q.upd_n <= 256) {
-    // one launch (latency is no concern on this stream): sorted batches of up to 64 leaves take the one-wave write-back, the rest
-    // the hashed body inside the same kernel
-    RB_LAUNCH(k_update_sample, dim3(1), dim3(256), s2, v, q.upd_idx, q.upd_loss, q.upd_n, 1, r->omega, q.batch, neg_beta, r->neg_beta_dev,
-              (const double*)nullptr, q.max_attempts, r->seed, r->scaling_dev, q.tree_idx, win_of(r, win_set), q.actions, q.returns,
-              q.nonterminals, q.weights, r->fail_host, (const unsigned*)nullptr, 0u, r->spec_res, epoch);
-    RB_LAUNCH_CHECK();
-  } else {
-    int uthreads = (int)(rb_div_up(q.upd_n, 64) * 64);
-    if (uthreads < 256) uthreads = 256;
-    RB_LAUNCH(k_update, dim3(1), dim3(uthreads), s2, v, q.upd_idx, q.upd_loss, q.upd_n, 1, r->omega, (const unsigned*)nullptr, 0u, (int32_t*)nullptr);
-    RB_LAUNCH_CHECK();
-    RB_LAUNCH((k_sample<256, 8>), dim3(1), dim3(256), s2, v, q.batch, neg_beta, r->neg_beta_dev, (const double*)nullptr, q.max_attempts, r->seed,
-              r->scaling_dev, q.tree_idx, win_of(r, win_set), q.actions, q.returns, q.nonterminals, q.weights, (const NoiseJob*)nullptr,
-              (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, r->fail_host, 1, 0, (const ClipAdamArgs*)nullptr, r->spec_res, epoch, 1);
-    RB_LAUNCH_CHECK();
-  }
+  // one launch (latency is no concern on this stream): sorted batches of up to 64 leaves take the one-wave write-back, the rest
+  // the hashed body inside the same kernel
+  RB_LAUNCH(k_update_sample, dim3(1), dim3(256), s2, v, q.upd_idx, q.upd_loss, q.upd_n, 1, r->omega, q.batch, neg_beta, r->neg_beta_dev,
+            (const double*)nullptr, q.max_attempts, r->seed, r->scaling_dev, q.tree_idx, win_of(r, win_set), q.actions, q.returns,
+            q.nonterminals, q.weights, r->fail_host, r->spec_res, epoch);
+  RB_LAUNCH_CHECK();
   r->spec_args.batch = q.batch; r->spec_args.max_attempts = q.max_attempts; r->spec_args.win_set = win_set;
   r->spec_args.beta = q.priority_weight; r->spec_args.tree_idx = q.tree_idx; r->spec_args.actions = q.actions;
   r->spec_args.returns = q.returns; r->spec_args.nonterm = q.nonterminals; r->spec_args.weights = q.weights;
@@ -940,7 +990,7 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   r->host_index = 0; r->host_full = 0;
   r->tree = nullptr; r->frames = nullptr; r->timestep = nullptr; r->action = nullptr; r->reward = nullptr;
   r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr; r->fail_host = nullptr;
-  r->win2 = nullptr; r->win_sel = 0; r->spec_stream = nullptr; r->spec_res = nullptr; r->spec_epoch = 0; r->spec_inflight = 0;
+  r->win2 = nullptr; r->win_sel = 0; r->spec_stream = nullptr; r->spec_res = nullptr; r->spec_epoch = 0; r->spec_inflight = 0; r->spec_accept_armed = 0; r->spec_disabled = 0;
   r->mutations = 0;
 #define RB_ALLOC(ptr, bytes)                                                                      \
   do {                                                                                            \
@@ -1105,10 +1155,19 @@ int rb_replay_dropped_updates(rb_replay_t* r, int64_t* count) {
   return RB_OK;
 }
 
+int rb_replay_expired_waits(rb_replay_t* r, int64_t* count) {
+  RB_REQUIRE(r && count, "rb_replay_expired_waits: NULL argument");
+  *count = (int64_t)*(volatile int32_t*)(r->fail_host + 2);   // pinned host word: no synchronisation
+  return RB_OK;
+}
+
 int rb_replay_reset_failed_samples(rb_replay_t* r) {
   RB_REQUIRE(r != nullptr, "rb_replay_reset_failed_samples: NULL handle");
+  RB_SPEC_JOIN(r);                             // (an early pair in flight may still count)
   *(volatile int32_t*)r->fail_host = 0;        // (a failed launch still in flight re-increments it when it completes)
   *(volatile int32_t*)(r->fail_host + 1) = 0;
+  *(volatile int32_t*)(r->fail_host + 2) = 0;
+  r->spec_disabled = 0;
   return RB_OK;
 }
 
@@ -1154,17 +1213,19 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   RB_REQUIRE(r->capacity > (int64_t)r->history + r->n,
              "rb_replay_sample: capacity must exceed history + multi_step (no window can clear the write head otherwise: "
              "the reference's rejection loop, memory.py:128-132, would never end)");
-  if (*(volatile int32_t*)(r->fail_host + 2) != 0) {
-    rb_set_error("rb_replay_sample: a cross-stream wait of the early draw expired (%d): the device did not make progress", r->fail_host[2]);
-    return RB_ERR_STATE;
-  }
-  // an early draw in flight (rb_replay_spec_launch): this launch's sampler workgroup waits for it and either ACCEPTS it — same
-  // batch, beta, attempt bound and output buffers, device RNG, nothing else has touched the replay since (every other entry
-  // point cancels it) — or draws again; either way the stream-2 work is complete before anything of this stream goes on
+  // an early draw in flight (rb_replay_spec_launch): this launch's sampler workgroup waits for it and either ACCEPTS it — only when
+  // the caller is rb_learner_train_step (spec_accept_armed: it reads the table of THIS draw; the public entry points hand out
+  // table 0, rb_replay_buffers_t.window_dev, so for them the draw is always made again, into table 0), same batch, beta, attempt
+  // bound and output buffers, device RNG, nothing else has touched the replay since (every other entry point cancels it) — or draws
+  // again; either way the stream-2 work is complete before anything of this stream goes on.
+  const int accept_armed = r->spec_accept_armed;
+  r->spec_accept_armed = 0;
   int spec_mode = 0;
   int win_set = 0;
   if (r->spec_inflight) {
-    const bool same = unit_uniforms_dev == nullptr && r->spec_args.batch == batch && r->spec_args.beta == priority_weight &&
+    // (a captured launch never accepts: mode 3 bakes "wait for the record of epoch E, then draw" into the graph, and on every
+    // replay that record is long complete)
+    const bool same = accept_armed && !rb_stream_capturing(stream) && unit_uniforms_dev == nullptr && r->spec_args.batch == batch && r->spec_args.beta == priority_weight &&
                       r->spec_args.max_attempts == max_attempts && r->spec_args.tree_idx == tree_idx_dev &&
                       r->spec_args.actions == actions_dev && r->spec_args.returns == returns_dev &&
                       r->spec_args.nonterm == nonterminals_dev && r->spec_args.weights == weights_dev;
@@ -1253,8 +1314,7 @@ static int rb_update_impl(rb_replay_t* r, const int64_t* tree_idx_dev, const flo
   ++r->mutations;
   int threads = (int)(rb_div_up(n, 64) * 64);
   if (threads < 256) threads = 256;     // the dense rebuild of the tree top wants lanes, not just one per leaf
-  RB_LAUNCH(k_update, dim3(1), dim3(threads), stream, view_of(r), tree_idx_dev, values_dev, n, apply_pow, r->omega, (const unsigned*)nullptr, 0u,
-            (int32_t*)nullptr);
+  RB_LAUNCH(k_update, dim3(1), dim3(threads), stream, view_of(r), tree_idx_dev, values_dev, n, apply_pow, r->omega);
   RB_LAUNCH_CHECK();
   return RB_OK;
 }
@@ -1294,7 +1354,7 @@ int rb_replay_update_sample(rb_replay_t* r, const int64_t* upd_tree_idx_dev, con
   const float neg_beta = (float)(-priority_weight);
   RB_LAUNCH_T("sample:k_update_sample", k_update_sample, dim3(1), dim3(256), stream, v, upd_tree_idx_dev, upd_losses_dev, upd_n, 1, r->omega,
               batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed, r->scaling_dev, tree_idx_dev, r->win, actions_dev,
-              returns_dev, nonterminals_dev, weights_dev, r->fail_host, (const unsigned*)nullptr, 0u, (SpecResult*)nullptr, 0u);
+              returns_dev, nonterminals_dev, weights_dev, r->fail_host, (SpecResult*)nullptr, 0u);
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {
     RB_LAUNCH(k_gather_stacks, dim3((unsigned)(batch * 2 * r->history)), dim3(256), stream, v, batch, r->win, states_dev, next_states_dev);

@@ -360,11 +360,12 @@ int rb_replay_internal_view(rb_replay_t* r, ReplayView* view, double* omega);
 // the handle with the same arguments ACCEPTS it (k_sample block 0 waits for the record's epoch, commits the header effects and
 // returns); any other entry point that touches the replay waits for the stream and discards it; a draw with other arguments
 // waits and draws again.  Results are those of the two calls made one after the other.
+#define RB_SPEC_ABORTED 2     // SpecResult.status: the pair gave up (its gate expired) — nothing was written back, nothing was drawn
 struct SpecResult {
   unsigned long long rng_next;
-  int32_t attempts, status;
+  int32_t attempts, status;  // status: 0 = a legal batch, 1 = the draw hit its attempt bound, RB_SPEC_ABORTED
   unsigned done;             // epoch of the last tentative draw that completed (release-stored last)
-  unsigned pad;
+  unsigned abort_epoch;      // epoch of the last pair whose gate (k_spec_gate) expired
 };
 struct rb_spec_request {
   const int64_t* upd_idx; const float* upd_loss; int32_t upd_n;     // the write-back (loss^w: rb_replay_update_priorities)
@@ -373,6 +374,12 @@ struct rb_spec_request {
   const unsigned* go_flag; unsigned go_epoch;                       // both kernels wait for *go_flag >= go_epoch first (NULL: no wait)
 };
 int rb_replay_spec_launch(rb_replay_t* r, const rb_spec_request& q);
+// 0 once a cross-stream wait of an early pair has expired on this handle (until rb_replay_reset_failed_samples): the learner then
+// keeps the write-back and the draw in its own launches
+int rb_replay_spec_allowed(rb_replay_t* r);
+// one shot: the NEXT draw on the handle may accept the tentative draw in flight (rb_learner_train_step only — it is the one caller
+// that reads rb_replay_current_windows(); every public sample entry point redraws into table 0)
+void rb_replay_spec_arm_accept(rb_replay_t* r);
 int rb_replay_spec_inflight(rb_replay_t* r);
 // the window table the LAST draw on the handle filled (rb_replay_buffers_t.window_dev is table 0; an accepted early draw used the other)
 const int32_t* rb_replay_current_windows(rb_replay_t* r);

@@ -87,13 +87,17 @@ def _create_library_comm(lib, dev):
     loaded: the caller then keeps the collective in torch.distributed)."""
     ident = torch.zeros(128, dtype=torch.uint8, device=dev)
     ok = torch.ones(1, dtype=torch.int32, device=dev)
-    # EVERY rank probes librccl (rb_comm_unique_id resolves it with dlopen) and the flags are reduced before any rank enters
-    # ncclCommInitRank: a rank that cannot load the library must not leave the others blocked inside the collective init
+    # EVERY rank probes librccl (rb_comm_available: dlopen + symbol lookup, nothing created) and the flags are reduced before any
+    # rank enters ncclCommInitRank: a rank that cannot load the library must not leave the others blocked inside the collective
+    # init.  Only rank 0 creates the bootstrap id (ncclGetUniqueId starts a listener thread per id).
     buf = (C.c_ubyte * 128)()
-    if lib.rb_comm_unique_id(buf) != 0:
+    if not lib.rb_comm_available():
         ok.zero_()
     elif dist.get_rank() == 0:
-        ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        if lib.rb_comm_unique_id(buf) != 0:
+            ok.zero_()
+        else:
+            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
         return None       # on all ranks: the collective stays in torch.distributed

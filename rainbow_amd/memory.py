@@ -209,8 +209,16 @@ class ReplayMemory:
         L.check(self._lib, self._lib.rb_replay_dropped_updates(self._handle, C.byref(n)))
         return int(n.value)
 
+    def expired_waits(self):
+        """Cross-stream waits of the early draw (RB_OPTS spec_draw=1, off by default) that hit their ~2 ms bound so far (pinned
+        host word: no synchronisation).  Each one failed safe (the waiting launch drew itself / dropped the write-back) and
+        switched the early draw off on this replay until reset_failed_samples().  0 on a healthy device."""
+        n = C.c_int64(0)
+        L.check(self._lib, self._lib.rb_replay_expired_waits(self._handle, C.byref(n)))
+        return int(n.value)
+
     def reset_failed_samples(self):
-        """Zero that counter (the failure has been reported to the caller)."""
+        """Zero those counters (the failure has been reported to the caller); allows the early draw again."""
         L.check(self._lib, self._lib.rb_replay_reset_failed_samples(self._handle))
 
     def frame_source(self):

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import scenarios
+import ts_scenarios
 from cabi_adapter import CAbiLearnAdapter, NumpyMem
 from helpers import assert_learn_trace_matches, load_golden
 from hipemu import loader
@@ -330,49 +331,10 @@ def test_projection_known_answers(emu, monkeypatch):
 
 
 def _ts_build(emu, name):
-    """A filled replay, a learner with a priority sink into it and the buffers of one rb_learner_train_step call."""
-    import ctypes as C
-    from cabi_adapter import CAbiReplayAdapter
-    from rainbow_amd import _lib as L
-    c = scenarios.LEARN_CONFIGS[name]
-    B, h, n = c["batch"], c["history"], c["multi_step"]
-    mem = NumpyMem()
-    rp = CAbiReplayAdapter(emu, mem, 512, h, n, c["discount"], 0.5)
-    rs = np.random.RandomState(5)
-    for _ in range(600):
-        rp.append(scenarios.synth_state(rs, h, 0), int(rs.randint(0, c["actions"])), float(rs.choice([-1.0, 0.0, 1.0])),
-                  bool(rs.random_sample() < 0.05))
-    ad = CAbiLearnAdapter(emu, mem, name)
-    cfg = O.Config(**c)
-    ad.load(O.init_params(cfg, 1), O.init_params(cfg, 2))
-    ad.reset_noise_online(rs.randn(O.noise_draw_count(cfg)).astype(np.float32))
-    out = dict(tree_idx=mem.empty((B,), np.int64), actions=mem.empty((B,), np.int64), returns=mem.empty((B,), np.float32),
-               nonterm=mem.empty((B,), np.float32), weights=mem.empty((B,), np.float32), loss=mem.empty((B,), np.float32),
-               norm=mem.empty((1,), np.float32))
-    L.check(emu, emu.rb_learner_set_priority_sink(ad.h, rp.h, mem.ptr(out["tree_idx"])))
-    job = L.NoiseJob()
-    L.check(emu, emu.rb_learner_noise_job(ad.h, 1, C.byref(job)))
-    return mem, rp, ad, out, job
+    return ts_scenarios.ts_build(emu, NumpyMem, name)
 
 
-def _ts_snapshot(mem, rp, ad, out):
-    return dict(idx=mem.download(out["tree_idx"]).copy(), loss=mem.download(out["loss"]).copy(),
-                w=mem.download(out["weights"]).copy(), params=mem.download(ad.p_on).copy(),
-                m=mem.download(ad.adam_m).copy(), v=mem.download(ad.adam_v).copy(), noise=mem.download(ad.z_tg).copy(),
-                tree=rp.tree().copy(), norm=mem.download(out["norm"]).copy(), grads=mem.download(ad.grads).copy())
-
-
-def _ts_args(name, mem, rp, ad, o, job, beta, step, max_norm=None):
-    import ctypes as C
-    from rainbow_amd import _lib as L
-    hy = scenarios.LEARN_HYPER
-    return L.TrainStep(replay=rp.h, batch=scenarios.LEARN_CONFIGS[name]["batch"], max_attempts=64, window_len=rp.bufs.window_len,
-                       priority_weight=beta, tree_idx_dev=mem.ptr(o["tree_idx"]), actions_dev=mem.ptr(o["actions"]),
-                       returns_dev=mem.ptr(o["returns"]), nonterminals_dev=mem.ptr(o["nonterm"]), weights_dev=mem.ptr(o["weights"]),
-                       noise_job=C.addressof(job), frames_dev=rp.bufs.frames_dev, windows_dev=rp.bufs.window_dev,
-                       loss_dev=mem.ptr(o["loss"]), exp_avg_dev=mem.ptr(ad.adam_m), exp_avg_sq_dev=mem.ptr(ad.adam_v),
-                       norm_dev=mem.ptr(o["norm"]), lr=hy["lr"], beta1=0.9, beta2=0.999, eps=hy["adam_eps"], step=step,
-                       max_norm=hy["norm_clip"] if max_norm is None else max_norm)
+_ts_snapshot, _ts_args = ts_scenarios.ts_snapshot, ts_scenarios.ts_args
 
 
 def test_train_step_entry_point_equals_its_three_calls(emu):
@@ -704,3 +666,12 @@ def test_early_draw_on_the_replays_stream_is_bit_identical(emu, monkeypatch):
     for (mem, rp, ad, o, job) in (h1, h2):
         ad.close(); rp.close()
 
+
+
+@pytest.mark.parametrize("preceding", [3, 4])
+def test_public_sample_after_an_early_draw_reads_table_zero(emu, monkeypatch, preceding):
+    ts_scenarios.public_sample_after_early_draw_check(emu, NumpyMem, monkeypatch, preceding)
+
+
+def test_expired_gate_of_the_early_draw_fails_safe(emu, monkeypatch):
+    ts_scenarios.early_draw_expiry_check(emu, NumpyMem, monkeypatch)

@@ -781,12 +781,15 @@ def test_update_target_net_copies_noise_buffers_too(hip):
 
 
 def test_early_draw_random_interleaving_is_bit_identical(hip, monkeypatch):
-    """RB_OPTS spec_draw (default on) against a twin with spec_draw=0 through 240 randomly interleaved operations on the classes —
+    """RB_OPTS spec_draw=1 (opt-in) against a twin with spec_draw=0 through 240 randomly interleaved operations on the classes —
     runs of back-to-back learn() (where the early draw is launched and accepted), beta changes (a tentative draw rejected inside
     the sampler launch), appends / append_batch / update_priorities / sample / header reads (the replay's stream joined, the draw
-    cancelled), act / evaluate_q / update_target_net / state_dict (which do not touch the replay: the streak goes on): after
+    cancelled), act / evaluate_q / update_target_net / state_dict (which do not touch the replay: the streak goes on), and
+    learn() with INJECTED target noise — the step's entry points one by one with the cached frame_source() window pointer
+    (table 0): that draw must never accept the tentative one, which sits in the other table — : after
     every operation that returns something the two agents agree, and at the end parameters, moments, noise, the sum-tree, the
     frames' bookkeeping columns and the replay header (Philox counter included) are bit-identical."""
+    from oracle import learner_oracle as O
     from rainbow_amd.agent import Agent
     from rainbow_amd.memory import ReplayMemory
     args = _args(architecture="data-efficient", hidden_size=64, batch_size=16)
@@ -808,8 +811,12 @@ def test_early_draw_random_interleaving_is_bit_identical(hip, monkeypatch):
     twins = [fresh(1), fresh(0)]
     rs = np.random.RandomState(123)
     g = torch.Generator(device="cuda").manual_seed(17)
-    ops = ["learn"] * 10 + ["act", "evalq", "append", "append_batch", "beta", "target", "update", "sample", "header", "state_dict"]
+    ops = ["learn"] * 10 + ["learn_injected"] * 2 + ["act", "evalq", "append", "append_batch", "beta", "target", "update", "sample", "header", "state_dict"]
+    draws = O.noise_draw_count(O.Config(architecture="data-efficient", hidden=64, batch=16, actions=4, multi_step=args.multi_step,
+                                        history=4, atoms=51, v_min=-10.0, v_max=10.0, discount=0.99))
     learns = 0
+    injected_after_learn = 0
+    prev = None
     for step in range(240):
         op = ops[rs.randint(len(ops))]
         st = torch.rand(4, 84, 84, device="cuda", generator=g)
@@ -819,11 +826,17 @@ def test_early_draw_random_interleaving_is_bit_identical(hip, monkeypatch):
         # (leaf indices of its own: after learn() the speculating handle's sample buffers already hold the NEXT call's batch)
         idx_ = torch.from_numpy(np.sort(rs.randint(0, 2048, 16)) + 2047).cuda()
         beta_ = float(min(1.0, 0.4 + 0.002 * step))
+        raw_ = rs.randn(draws).astype(np.float32)
+        injected_after_learn += op == "learn_injected" and prev == "learn"
+        prev = op
         outs = []
         for agent, mem in twins:
             if op == "learn":
                 agent.reset_noise()
                 agent.learn(mem)
+                outs.append(agent._loss.clone())
+            elif op == "learn_injected":
+                agent.learn(mem, _target_raw_normals=torch.from_numpy(raw_))
                 outs.append(agent._loss.clone())
             elif op == "act":
                 outs.append(torch.tensor([agent.act(st)]))
@@ -851,8 +864,9 @@ def test_early_draw_random_interleaving_is_bit_identical(hip, monkeypatch):
         if outs:
             torch.cuda.synchronize()
             assert torch.equal(outs[0].cpu(), outs[1].cpu()), (step, op)
-    assert learns > 80
+    assert learns > 80 and injected_after_learn >= 5
     (a1, m1), (a2, m2) = twins
+    assert m1.expired_waits() == 0 and m1.dropped_updates() == 0
     assert torch.equal(a1.params.detach(), a2.params.detach()) and torch.equal(a1.target_params, a2.target_params)
     s1, s2 = a1.optimiser.state[a1.params], a2.optimiser.state[a2.params]
     assert torch.equal(s1["exp_avg"], s2["exp_avg"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
@@ -863,3 +877,18 @@ def test_early_draw_random_interleaving_is_bit_identical(hip, monkeypatch):
     h1, h2 = m1._header(), m2._header()
     assert (h1.index, h1.full, h1.max, h1.total, h1.rng_counter) == (h2.index, h2.full, h2.max, h2.total, h2.rng_counter)
     assert m1.failed_samples() == m2.failed_samples() == 0
+
+
+def test_expired_gate_of_the_early_draw_fails_safe(hip, monkeypatch):
+    """(tests/ts_scenarios.py) on the device the gate really polls for ~2 ms before it gives up."""
+    import ts_scenarios
+    from cabi_adapter import TorchMem
+    ts_scenarios.early_draw_expiry_check(hip, TorchMem, monkeypatch)
+
+
+@pytest.mark.parametrize("preceding", [3, 4])
+def test_public_sample_after_an_early_draw_reads_table_zero(hip, monkeypatch, preceding):
+    """(tests/test_learner_emu.py, same name) on the device: two streams, the tentative draw really in flight."""
+    import ts_scenarios
+    from cabi_adapter import TorchMem
+    ts_scenarios.public_sample_after_early_draw_check(hip, TorchMem, monkeypatch, preceding)
