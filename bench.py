@@ -215,7 +215,7 @@ def respawn_under_torchrun(opt):
     torch.distributed.run on this node and hand the terminal over to it."""
     import socket
     n_dev = torch.cuda.device_count()
-    if n_dev < opt.gpus:
+    if n_dev < (1 if opt.backend == "gloo" else opt.gpus):
         sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (opt.gpus, n_dev))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -305,6 +305,10 @@ def main():
                          "event record is a system-scope barrier packet and shows as ~6 us of idle GPU on both sides of the "
                          "bracketed launch (tools/gpu_trace_gaps.sh)")
     ap.add_argument("--capacity", type=int, default=0, help="override replay capacity (debug)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="debug: gloo = REHEARSAL of the multi-rank control flow on ONE GPU (every rank on cuda:0, RCCL refuses a second "
+                         "rank per device): same respawn, barriers, MAX-reduced elapsed and value arithmetic; the replica exchange "
+                         "stages its blocks through the host.  Its number says nothing about scaling")
     ap.add_argument("--extra-tags", default="", help="comma-separated extra profiling tags to time (bytes unknown: time only)")
     opt = ap.parse_args()
 
@@ -319,15 +323,20 @@ def main():
     if rank == 0:
         __graft_entry__.build()
     force_dist = os.environ.get("RAINBOW_AMD_FORCE_DIST") == "1" and "RANK" in os.environ   # one-rank RCCL plumbing test
+    rehearsal = opt.backend == "gloo"
+    dev_index = 0 if rehearsal else local_rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if torch.cuda.device_count() <= local_rank:
-            sys.exit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if torch.cuda.device_count() <= dev_index:
+            sys.exit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, dev_index, torch.cuda.device_count()))
+        torch.cuda.set_device(dev_index)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         torch.distributed.barrier()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from rainbow_amd import _lib as L
@@ -404,7 +413,7 @@ def main():
     lib.rb_profile_select(None)
     lib.rb_profile_stride(1)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
     # the same number of steps WITHOUT the event pair around the dominant kernel (what the bracketing itself costs)
@@ -460,6 +469,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / opt.steps * 1e3
         par = "single device" if world == 1 else "replicas x%d, exchange=%s" % (world, rdist.mode())
+        if world > 1 and rehearsal:
+            par += " [REHEARSAL: %d ranks on ONE GPU over gloo — control flow only, not a scaling number]" % world
         out = {
             "metric": "gradient-steps/sec (batch=%d, atoms=51)" % B, "value": world * opt.steps / elapsed,
             "unit": "gradient-steps/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,

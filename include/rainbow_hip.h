@@ -479,7 +479,9 @@ int rb_learner_sync_target(rb_learner_t* l, rb_stream_t stream);
 
 /* White-box access for parity tests: copies an internal activation to out_dev.
  * what: 0 log_ps_a [B][atoms], 1 m (projected target) [B][atoms], 2 argmax a* i32[B],
- *       3 pns_a [B][atoms], 4 logits [3B][atoms*(actions+1)].                          */
+ *       3 pns_a [B][atoms], 4 logits [3B][atoms*(actions+1)],
+ *       5 hidden activations relu(fc_h_v | fc_h_a) of the differentiated forward [B][2*hidden] (model.py:72-73) — read WITHOUT
+ *         running a pending optimiser pass (it is no parameter): h > 0 are the ReLU decisions the backward used.          */
 int rb_learner_debug_read(rb_learner_t* l, int32_t what, void* out_dev, rb_stream_t stream);
 
 #ifdef __cplusplus

@@ -125,9 +125,12 @@ def noisy_linear(x, params, layer, noise):
     return x @ w.t() + b
 
 
-def forward(cfg, params, noise, x, log=False, probe=None):
+def forward(cfg, params, noise, x, log=False, probe=None, hidden_mask=None):
     """DQN.forward (model.py:69-80).  x float32 [B,h,84,84] in [0,1]; params: torch tensors.
-    probe (optional dict): receives 'hidden_relu_margin' = the smallest |pre-activation| of the two hidden layers (see learn)."""
+    probe (optional dict): receives 'hidden_relu_margin' = the smallest |pre-activation| of the two hidden layers (see learn)
+    and 'hidden_pre' = the two pre-activation matrices (numpy).
+    hidden_mask (optional, test hook): boolean [B, 2H] — the hidden layers' ReLU decisions (value stream | advantage stream) are
+    TAKEN from it instead of from the sign of this forward's own pre-activations (see learn)."""
     convs, feat = cfg.convs
     for i, (_c, _k, stride) in enumerate(convs):
         x = F.relu(F.conv2d(x, params["convs.%d.weight" % (2 * i)], params["convs.%d.bias" % (2 * i)], stride=stride))
@@ -135,8 +138,15 @@ def forward(cfg, params, noise, x, log=False, probe=None):
     pre_v, pre_a = noisy_linear(x, params, "fc_h_v", noise), noisy_linear(x, params, "fc_h_a", noise)
     if probe is not None:
         probe["hidden_relu_margin"] = float(torch.minimum(pre_v.detach().abs().min(), pre_a.detach().abs().min()))
-    v = noisy_linear(F.relu(pre_v), params, "fc_z_v", noise)                   # model.py:72
-    a = noisy_linear(F.relu(pre_a), params, "fc_z_a", noise)                   # model.py:73
+        probe["hidden_pre"] = np.concatenate([pre_v.detach().numpy(), pre_a.detach().numpy()], axis=1)
+    if hidden_mask is not None:
+        mk = _t(np.asarray(hidden_mask)).to(torch.float32)
+        H = pre_v.shape[1]
+        h_v, h_a = pre_v * mk[:, :H], pre_a * mk[:, H:]                        # relu with the given decisions (value and gradient)
+    else:
+        h_v, h_a = F.relu(pre_v), F.relu(pre_a)
+    v = noisy_linear(h_v, params, "fc_z_v", noise)                             # model.py:72
+    a = noisy_linear(h_a, params, "fc_z_a", noise)                             # model.py:73
     v = v.reshape(-1, 1, cfg.atoms)
     a = a.reshape(-1, cfg.actions, cfg.atoms)
     q = v + a - a.mean(1, keepdim=True)                                        # model.py:75
@@ -168,7 +178,7 @@ def project(cfg, pns_a, returns, nonterminals):
     return m, l, u, b
 
 
-def learn(cfg, online, target, noise_online, noise_target, batch):
+def learn(cfg, online, target, noise_online, noise_target, batch, hidden_mask=None):
     """Agent.learn up to and including backward (agent.py:63-96).
     online/target: {name: np.float32 array}; batch: dict(states u8[B,h,84,84], next_states u8,
     actions i64[B], returns f32[B], nonterminals f32[B] or [B,1], weights f32[B]).
@@ -177,7 +187,13 @@ def learn(cfg, online, target, noise_online, noise_target, batch):
     product, rounding noise ~1e-7) is closer to zero than that noise, its SIGN — and with it one sample's whole contribution
     to that unit's gradients, up to 1/B of their magnitude — depends on the summation order; the reference itself (model.py:72-73,
     torch's GEMM blocking) is only defined up to that order there.  Parity tests on fixed seeds require a margin above the
-    noise so that a gradient mismatch can never be this discontinuity."""
+    noise so that a gradient mismatch can never be this discontinuity.
+    hidden_mask (optional, test hook; boolean [B, 2H]): the ReLU decisions of the differentiated forward are taken from it (what
+    another implementation of the same forward decided) instead of from this forward's own signs.  The result then carries
+    `hidden_mask_flips` = how many of its own decisions differ and `hidden_mask_flip_abs` = the largest |pre-activation| among
+    those: a parity test at batch 256 (262 144 pre-activations per step, the smallest ~3e-8, a split-K GEMM's summation noise
+    ~5e-8) uses it to show that every difference it tolerates IS this discontinuity — decisions that differ only where the
+    pre-activation is inside the rounding noise — and nothing else."""
     B = batch["states"].shape[0]
     p_on = {k: _t(v).clone().requires_grad_(True) for k, v in online.items()}
     p_tg = {k: _t(v) for k, v in target.items()}
@@ -189,7 +205,7 @@ def learn(cfg, online, target, noise_online, noise_target, batch):
     weights = _t(batch["weights"]).to(torch.float32)
 
     probe = {}
-    log_ps = forward(cfg, p_on, noise_online, states, log=True, probe=probe)   # agent.py:66
+    log_ps = forward(cfg, p_on, noise_online, states, log=True, probe=probe, hidden_mask=hidden_mask)   # agent.py:66
     log_ps_a = log_ps[torch.arange(B), actions]                                # agent.py:67
     with torch.no_grad():
         pns = forward(cfg, p_on, noise_online, next_states)                    # agent.py:71
@@ -202,7 +218,14 @@ def learn(cfg, online, target, noise_online, noise_target, batch):
     grads = {k: v.grad.numpy().copy() for k, v in p_on.items()}
     return dict(loss=loss.detach().numpy().copy(), m=m.numpy().copy(), a_star=a_star.numpy().copy(),
                 pns_a=pns_a.numpy().copy(), log_ps_a=log_ps_a.detach().numpy().copy(), grads=grads,
-                l=l.numpy().copy(), u=u.numpy().copy(), hidden_relu_margin=probe["hidden_relu_margin"])
+                l=l.numpy().copy(), u=u.numpy().copy(), hidden_relu_margin=probe["hidden_relu_margin"],
+                **(_mask_flips(probe["hidden_pre"], hidden_mask) if hidden_mask is not None else {}))
+
+
+def _mask_flips(pre, mask):
+    own = pre > 0
+    diff = own != np.asarray(mask, dtype=bool)
+    return dict(hidden_mask_flips=int(diff.sum()), hidden_mask_flip_abs=float(np.abs(pre[diff]).max()) if diff.any() else 0.0)
 
 
 def clip_grads(grads, max_norm):

@@ -1588,9 +1588,27 @@ struct ConvDwAllArgs {
   int ipb;                 // images summed per workgroup
   int img_fast;            // decode with the image group as the FASTEST index (see k_conv_fwd_lds): needs block ranges and group
                            // counts that are multiples of 8
+  // ONE housekeeping workgroup behind the layers' (hk != 0; learner.hip: the slice reduction of this call is folded into the next
+  // call's sampler launch, so what its launch did besides summing happens here): copy hk_n floats (the learn call's online noise:
+  // the snapshot for the optimiser pass that forms the hidden layer's sigma gradient itself), clear *hk_clear
+  // (ClipAdamArgs::pair_clipped) and zero *hk_ctr (the folded reduction's arrival counter)
+  int hk;
+  const float* hk_src;
+  float* hk_dst;
+  int hk_n;
+  int32_t* hk_clear;
+  unsigned* hk_ctr;
 };
 template <class G0, int RC0, class G1, int RC1, int K1, class G2, int RC2, int K2, int NL>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a) {
+  if (a.hk && (int)blockIdx.x == a.nblocks[0] + a.nblocks[1] + (NL > 2 ? a.nblocks[2] : 0)) {     // block-uniform
+    for (int j = (int)threadIdx.x; j < a.hk_n; j += (int)blockDim.x) a.hk_dst[j] = a.hk_src[j];
+    if (threadIdx.x == 0) {
+      if (a.hk_clear) *a.hk_clear = 0;
+      if (a.hk_ctr) *a.hk_ctr = 0u;
+    }
+    return;
+  }
   typedef ConvDwLdsSize<G0, RC0, 4 * G0::KK> S0;
   typedef ConvDwLdsSize<G1, RC1, K1> S1;
   typedef ConvDwLdsSize<G2, RC2, K2> S2;

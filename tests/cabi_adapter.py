@@ -53,7 +53,7 @@ class TorchMem:
         return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
 
     def download(self, buf):
-        return buf.cpu().numpy()
+        return buf.detach().cpu().numpy()
 
     def ptr(self, buf):
         return buf.data_ptr() if buf is not None else None

@@ -133,3 +133,28 @@ def test_two_agents_on_one_device_stay_identical_and_match_the_oracle(tmp_path, 
         np.testing.assert_allclose(r[0]["s%d_norm" % step], total, rtol=2e-5)
     for n in names:
         np.testing.assert_allclose(r[0]["final/" + n], online[n], rtol=0, atol=3e-7, err_msg=n)
+
+
+def test_bench_multi_rank_control_flow_rehearsal_on_one_gpu():
+    """`bench.py --gpus N` has only ever run with ONE rank (no multi-GPU box in the pool), so its multi-rank
+    branch — the torchrun respawn, process-group init, the barriers around the timed region, the MAX-reduced elapsed time,
+    `value = world * steps / elapsed`, the Agent's exchange between backward and clip (agent.py:96-97) — is REHEARSED here:
+    `--backend gloo` puts both ranks on cuda:0 (RCCL refuses a second rank per device; the replica exchange stages its blocks
+    through the host).  Checks the one JSON line rank 0 prints: two ranks claimed, the value arithmetic, finite numbers, the
+    rehearsal marked as such.  It measures NOTHING about scaling."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("RB_OPTS", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "5",
+           "--capacity", "65536", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line (rank 0): %r" % lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and "REHEARSAL" in d["config"]["parallelism"] and "replicas x2" in d["config"]["parallelism"]
+    assert np.isfinite(d["value"]) and d["value"] > 0
+    np.testing.assert_allclose(d["value"], 2 * 20 / (d["ms_per_step"] * 1e-3 * 20), rtol=1e-9)     # whole-job aggregate over both ranks
+    assert "roofline" in d and "cpu_baseline" not in d

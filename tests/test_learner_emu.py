@@ -416,6 +416,10 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu, monke
         if implicit_sigma:      # the hidden layer's sigma gradient of THIS step is not in the flat gradient (its mu part is)
             sg = h1[2].layout["fc_h_v.weight_sigma"][0]
             assert not np.array_equal(a["grads"][sg:sg + 512], b["grads"][sg:sg + 512])
+        # the conv gradients of THIS step are not in the flat gradient either: the fixed-order sum of their slices is folded into
+        # the pending pass (RB_OPTS fold_reduce, reduce_body.h) — the twin's k_reduce_conv_dw_all has run
+        cw = h1[2].layout["convs.0.weight"][0]
+        assert not np.array_equal(a["grads"][cw:cw + 512], b["grads"][cw:cw + 512]), "the conv slice reduction was not folded"
         for k in ("idx", "loss", "w", "noise", "tree"):             # the step itself never waits for the pending pass' results
             assert np.array_equal(a[k], b[k]), (step, k)            # ... because it has run by then (same launch as the sampler)
         if prev_twin is not None:                                   # one update behind, exactly
