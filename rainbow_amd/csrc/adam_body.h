@@ -66,27 +66,33 @@ struct ClipAdamArgs {
 };
 // arrivals / polls on a counter whose address came out of device memory: pinned to the global address space (a generic pointer
 // would make these FLAT instructions)
-__device__ __forceinline__ void rb_fold_arrive(unsigned* ctr) {            // all threads of the workgroup call; payload stored write-through
+#define RB_FOLD_READY_WORD 1024      // the READY flag sits 4 KB behind the arrival counter: the waiters' polls and the arrivals' atomics
+                                     // then meet in different L2 channels (a thousand resident workgroups polling the counter itself
+                                     // held the arrivals back by ~25 us: profiles/round6_experiments.txt)
+__device__ __forceinline__ void rb_fold_arrive(unsigned* ctr, unsigned target) {   // all threads of the workgroup call; payload stored write-through
 #if defined(RB_HOST_INTERP)
   __syncthreads();
-  if (threadIdx.x == 0) *ctr = *ctr + 1u;
+  if (threadIdx.x == 0) { *ctr = *ctr + 1u; if (*ctr == target) ctr[RB_FOLD_READY_WORD] = 1u; }
 #else
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's stores have left the CU
   __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == target)                                             // the last arriver: every other producer's payload drained before ITS arrival
+      __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(ctr + RB_FOLD_READY_WORD), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #endif
 }
-__device__ __forceinline__ void rb_fold_wait(const unsigned* ctr, unsigned target, int32_t* err_host) {   // all threads call
+__device__ __forceinline__ void rb_fold_wait(const unsigned* ctr, int32_t* err_host) {   // all threads call
 #if defined(RB_HOST_INTERP)
-  if (threadIdx.x == 0 && (int)(*ctr - target) < 0) *err_host = 1;         // blocks run in index order: the producers are done
+  if (threadIdx.x == 0 && ctr[RB_FOLD_READY_WORD] == 0u) *err_host = 1;    // blocks run in index order: the producers are done
   __syncthreads();
 #else
   if (threadIdx.x == 0) {
     unsigned spins = 0;
-    while ((int)(__hip_atomic_load((const __attribute__((address_space(1))) unsigned*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 20)) {
+    while (__hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(ctr + RB_FOLD_READY_WORD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(40);                                        // ~1 us: a thousand workgroups may be waiting with this one
+      if (++spins > (1u << 18)) {
         __hip_atomic_store((__attribute__((address_space(1))) int32_t*)err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -125,7 +131,7 @@ __device__ __forceinline__ bool rb_adam_hosted_prologue(ClipAdamArgs& a, int eb,
     return false;
   }
   // the folded conv reduction (earlier workgroups of THIS launch) has delivered its gradients and partials
-  if (a.red_blocks > 0) rb_fold_wait(a.red_ctr, (unsigned)a.red_blocks, a.red_err);      // block-uniform
+  if (a.red_blocks > 0) rb_fold_wait(a.red_ctr, a.red_err);      // block-uniform
 
   float acc = 0.0f;
   {
@@ -239,7 +245,7 @@ __device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int
     my = rb_wave_sum(my);
     const int slot = eb * (int)(blockDim.x >> 6) + rb_wave();
     if (rb_lane() == 0 && ad->red.sq_part && slot < ad->red_slots) rb_st1_wt(ad->red.sq_part, 4u * (unsigned)slot, my);
-    rb_fold_arrive(ad->red_ctr);
+    rb_fold_arrive(ad->red_ctr, (unsigned)rblocks);
     return;
   }
   eb -= rblocks; nblk -= rblocks;

@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a
     for (int j = (int)threadIdx.x; j < a.hk_n; j += (int)blockDim.x) a.hk_dst[j] = a.hk_src[j];
     if (threadIdx.x == 0) {
       if (a.hk_clear) *a.hk_clear = 0;
-      if (a.hk_ctr) *a.hk_ctr = 0u;
+      if (a.hk_ctr) { a.hk_ctr[0] = 0u; a.hk_ctr[1024] = 0u; }           // (arrivals, READY flag: adam_body.h RB_FOLD_READY_WORD)
     }
     return;
   }

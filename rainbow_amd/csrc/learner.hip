@@ -1446,9 +1446,9 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_act_fused = rb_opt("act_fused", 1);
   l->opt_fold_reduce = rb_opt("fold_reduce", 1);
   if (l->opt_fold_reduce) {
-    hipError_t e = rb_dev_malloc((void**)&l->fold_ctr, 64);
+    hipError_t e = rb_dev_malloc((void**)&l->fold_ctr, 8192);     // word 0: arrivals, word RB_FOLD_READY_WORD: the READY flag
     if (e != hipSuccess) { rb_set_error("rb_learner_create: hipMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
-    RB_HIP_TRY(hipMemset(l->fold_ctr, 0, 64));
+    RB_HIP_TRY(hipMemset(l->fold_ctr, 0, 8192));
     e = hipHostMalloc((void**)&l->fold_err, 64, hipHostMallocMapped);
     if (e != hipSuccess) { rb_set_error("rb_learner_create: hipHostMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
     *l->fold_err = 0;
