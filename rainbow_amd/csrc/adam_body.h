@@ -6,10 +6,6 @@
 // workgroup instead of in front of it.  Same arithmetic, same summation order: the parameters are bit-identical.
 #pragma once
 #include "rb_common.h"
-#include "reduce_body.h"
-#ifndef RB_ADAM_NT
-#define RB_ADAM_NT 0
-#endif
 
 // clip_grad_norm_ + Adam in ONE pass over the flat buffers (agent.py:97-98).  Every block re-sums the partial list in the
 // same fixed order (so all blocks agree on the clip coefficient) while its first parameter/gradient/moment loads are
@@ -52,55 +48,7 @@ struct ClipAdamArgs {
   int32_t* pair_clipped;       // written by the pair pass: 1 = the clip bit and the SCALED gradients (sigma's included) were stored
                                // back, exactly as the reference leaves .grad — a later materialisation must not redo them from
                                // the scaled g_mu (the product would round in another order); 0 = nothing was stored
-  // FOLDED conv reduction (learner.hip, RB_OPTS fold_reduce; hosted pass only): the learn call behind this gradient left the
-  // fixed-order sum of its conv weight-gradient slices (reduce_body.h) to THIS pass, its only consumer.  The first red_blocks
-  // hosted workgroups run it — gradients and sum-of-squares partials stored write-through — and arrive at red_ctr (zeroed by the
-  // learn call's last backward launch); every other workgroup waits for red_blocks arrivals before it reads the partial list or a
-  // gradient (the plain workgroups request theirs behind the wait, agent-coherently: the conv tensors are among them).
-  // The wait is bounded; an expiry (it cannot happen: producers have lower block indices and are dispatched first) is flagged in
-  // *red_err (pinned host word) and the next rb_learner_train_step refuses.
-  ReduceAllArgs red;
-  int red_blocks, red_slots;   // red_slots = partial slots the reduction writes (one per 64 elements)
-  unsigned* red_ctr;
-  int32_t* red_err;
 };
-// arrivals / polls on a counter whose address came out of device memory: pinned to the global address space (a generic pointer
-// would make these FLAT instructions)
-#define RB_FOLD_READY_WORD 1024      // the READY flag sits 4 KB behind the arrival counter: the waiters' polls and the arrivals' atomics
-                                     // then meet in different L2 channels (a thousand resident workgroups polling the counter itself
-                                     // held the arrivals back by ~25 us: profiles/round6_experiments.txt)
-__device__ __forceinline__ void rb_fold_arrive(unsigned* ctr, unsigned target) {   // all threads of the workgroup call; payload stored write-through
-#if defined(RB_HOST_INTERP)
-  __syncthreads();
-  if (threadIdx.x == 0) { *ctr = *ctr + 1u; if (*ctr == target) ctr[RB_FOLD_READY_WORD] = 1u; }
-#else
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's stores have left the CU
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned before = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (before + 1u == target)                                             // the last arriver: every other producer's payload drained before ITS arrival
-      __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(ctr + RB_FOLD_READY_WORD), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#endif
-}
-__device__ __forceinline__ void rb_fold_wait(const unsigned* ctr, int32_t* err_host) {   // all threads call
-#if defined(RB_HOST_INTERP)
-  if (threadIdx.x == 0 && ctr[RB_FOLD_READY_WORD] == 0u) *err_host = 1;    // blocks run in index order: the producers are done
-  __syncthreads();
-#else
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(ctr + RB_FOLD_READY_WORD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(40);                                        // ~1 us: a thousand workgroups may be waiting with this one
-      if (++spins > (1u << 18)) {
-        __hip_atomic_store((__attribute__((address_space(1))) int32_t*)err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-#endif
-}
 // (IEEE sqrt and divisions, as torch computes them: hardware rcp / approximate sqrt measured 1.5 us faster per launch
 // and stay far inside the test tolerance, but the update would no longer be the reference's formula rounding for rounding)
 __device__ __forceinline__ void rb_adam_elem(float& p, float& g, float& m, float& v, float coef, const ClipAdamArgs& a) {
@@ -130,20 +78,16 @@ __device__ __forceinline__ bool rb_adam_hosted_prologue(ClipAdamArgs& a, int eb,
     if (eb == 0 && threadIdx.x == 0 && a.norm_out) rb_st1_wt(a.norm_out, 0, 0.0f);
     return false;
   }
-  // the folded conv reduction (earlier workgroups of THIS launch) has delivered its gradients and partials
-  if (a.red_blocks > 0) rb_fold_wait(a.red_ctr, a.red_err);      // block-uniform
-
   float acc = 0.0f;
   {
-    // 16 partials in flight per trip, added in index order (a loop of single loads is one L2 round trip per iteration);
-    // agent-coherent loads: some of the partials may have been stored by other workgroups of this launch
+    // 16 partials in flight per trip, added in index order (a loop of single loads is one L2 round trip per iteration)
     const rb_buf bpart = rb_make_buf(a.part);
     for (int i0 = (int)threadIdx.x; i0 < a.nparts; i0 += 16 * (int)T) {
       float pv[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int i = i0 + u * (int)T;
-        pv[u] = rb_ld1_buf_sc1(bpart, 4u * (unsigned)(i < a.nparts ? i : a.nparts - 1), 0);
+        pv[u] = rb_ld1_buf(bpart, 4u * (unsigned)(i < a.nparts ? i : a.nparts - 1), 0);
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
@@ -210,10 +154,9 @@ __device__ __forceinline__ void rb_adam_hosted_pairs(ClipAdamArgs& a, int eb, in
     unsigned j = base + u * T;
     if (j >= len4) j = len4 - 1;                         // clamped loads (always legal), masked stores
     const unsigned i = mu4 + j, i2 = i + len4;
-    // (RB_ADAM_NT: experiment switch — the gradient and the moments are read once per step: non-temporal loads)
-    P[u] = rb_ld4_buf(bp, 16 * i, 0); G[u] = rb_ld4_buf_aux<RB_ADAM_NT>(bg, 16 * i, 0);
-    M[u] = rb_ld4_buf_aux<RB_ADAM_NT>(bm, 16 * i, 0); V[u] = rb_ld4_buf_aux<RB_ADAM_NT>(bv, 16 * i, 0);
-    P2[u] = rb_ld4_buf(bp, 16 * i2, 0); M2[u] = rb_ld4_buf_aux<RB_ADAM_NT>(bm, 16 * i2, 0); V2[u] = rb_ld4_buf_aux<RB_ADAM_NT>(bv, 16 * i2, 0);
+    P[u] = rb_ld4_buf(bp, 16 * i, 0); G[u] = rb_ld4_buf(bg, 16 * i, 0);
+    M[u] = rb_ld4_buf(bm, 16 * i, 0); V[u] = rb_ld4_buf(bv, 16 * i, 0);
+    P2[u] = rb_ld4_buf(bp, 16 * i2, 0); M2[u] = rb_ld4_buf(bm, 16 * i2, 0); V2[u] = rb_ld4_buf(bv, 16 * i2, 0);
   }
   float coef;
   if (!rb_adam_hosted_prologue(a, eb, st_lo, st_hi, s_red16, &coef)) return;
@@ -235,20 +178,9 @@ __device__ __forceinline__ void rb_adam_hosted_pairs(ClipAdamArgs& a, int eb, in
 }
 
 template <int UNROLL>
-__device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int eb, int nblk, float* s_red16 /* [18] */) {   // (eb, nblk: by value, adjusted below)
+__device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int eb, int nblk, float* s_red16 /* [18] */) {
   // (the branch is decided from two words; each role then reads the argument fields IT uses: the whole struct live on both
   // paths cost the hosting sampler kernel 18 spilled VGPRs and a scratch segment, and the whole step 10 us)
-  const int rblocks = ad->red_blocks;
-  if (eb < rblocks) {                                    // block-uniform: the folded conv slice reduction (reduce_body.h)
-    // (256 threads: each wave is one 64-element block of k_reduce_conv_dw_all — same element, same partial slot, same wave sum)
-    float my = rb_reduce_conv_elem_hosted(&ad->red, (int64_t)eb * (int64_t)blockDim.x + threadIdx.x);
-    my = rb_wave_sum(my);
-    const int slot = eb * (int)(blockDim.x >> 6) + rb_wave();
-    if (rb_lane() == 0 && ad->red.sq_part && slot < ad->red_slots) rb_st1_wt(ad->red.sq_part, 4u * (unsigned)slot, my);
-    rb_fold_arrive(ad->red_ctr, (unsigned)rblocks);
-    return;
-  }
-  eb -= rblocks; nblk -= rblocks;
   const int nplain = ad->hole4 > 0 ? ad->pair_blk0 : nblk;
   if (eb >= nplain) {                                    // block-uniform: a (mu, sigma) pair workgroup
     ClipAdamArgs ap = *ad;
@@ -270,27 +202,17 @@ __device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int
     const rb_buf bs = rb_make_buf(a.step_dev);
     st_lo = __builtin_bit_cast(unsigned, rb_ld1_buf(bs, 0, 0)); st_hi = __builtin_bit_cast(unsigned, rb_ld1_buf(bs, 4, 0));
   }
-  // The gradients are requested AFTER the prologue, agent-coherently: with the folded conv reduction (a.red_blocks > 0) the conv
-  // range of the gradient is written by earlier workgroups of THIS launch and is final only behind the prologue's wait.  (One rule
-  // for every plain workgroup: a path of its own for the few that reach into the conv range — or deferring G only there — cost the
-  // hosting sampler kernel 4-20 spilled registers; the plain workgroups are a fifth of the pass, the others' streams cover the trip.)
   float4 P[UNROLL], G[UNROLL], M[UNROLL], V[UNROLL];
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     unsigned j = base + u * T;
     if (j >= nv4) j = nv4 > 0 ? nv4 - 1 : 0;         // clamped load (always legal), masked store
     const unsigned i = real_of(j);
-    P[u] = rb_ld4_buf(bp, 16 * i, 0);
+    P[u] = rb_ld4_buf(bp, 16 * i, 0); G[u] = rb_ld4_buf(bg, 16 * i, 0);
     M[u] = rb_ld4_buf(bm, 16 * i, 0); V[u] = rb_ld4_buf(bv, 16 * i, 0);
   }
   float coef;
   if (!rb_adam_hosted_prologue(a, eb, st_lo, st_hi, s_red16, &coef)) return;
-#pragma unroll
-  for (int u = 0; u < UNROLL; ++u) {
-    unsigned j = base + u * T;
-    if (j >= nv4) j = nv4 > 0 ? nv4 - 1 : 0;
-    G[u] = rb_ld4_buf_sc1(bg, 16 * real_of(j), 0);
-  }
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const unsigned j = base + u * T;
@@ -305,7 +227,7 @@ __device__ __forceinline__ void rb_adam_hosted_block(const ClipAdamArgs* ad, int
     const int64_t t = ((a.n >> 2) << 2) + threadIdx.x;
     if (t < a.n) {
       const unsigned o = (unsigned)(4 * t);
-      float p = rb_ld1_buf(bp, o, 0), g = rb_ld1_buf_sc1(bg, o, 0), m = rb_ld1_buf(bm, o, 0), v = rb_ld1_buf(bv, o, 0);
+      float p = rb_ld1_buf(bp, o, 0), g = rb_ld1_buf(bg, o, 0), m = rb_ld1_buf(bm, o, 0), v = rb_ld1_buf(bv, o, 0);
       rb_adam_elem(p, g, m, v, coef, a);
       rb_st1_wt(a.p, o, p); rb_st1_wt(a.m, o, m); rb_st1_wt(a.v, o, v);
       if (coef < 1.0f) rb_st1_wt(a.g, o, g);

@@ -866,6 +866,159 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_multi(ConvLdsFwdAr
   RB_MSTAMP(61);
 }
 
+// ---- large batches, later layers, WHOLE-K tiles: k_conv_fwd_multi's image loop around the t16 body ------------------------------
+// k_conv_fwd_multi above splits the reduction over its 8 waves and sums the partial tiles through LDS — per image NT rounds of
+// (16 stores, barrier, 8-way sum, barrier) during which the MFMA pipe idles: MFMA-busy 0.53-0.57 at batch 256 (profiles/
+// round5_sq_counters_*).  Here the workgroup is the t16 body's (rb_conv_fwd_body<..., T16 = 1>): one wave per 16-position x 16-channel
+// tile over the WHOLE reduction, the epilogue straight from the accumulators — no partial sums, no reduction scratch, two barriers per
+// image (patch complete / patch free).  The row-major 32-channel slab (and the bias terms) are set up once per net, the next image's
+// patch is in flight (registers) under this image's MFMA loop.  Same LDS image as the one-image t16 kernel (117 / 95 KB for the
+// canonical layers 2 / 3).  Needs cin * KK == KMAX, cin % 4 == 0, KMAX % 16 == 0, cout % 32 == 0 (host-checked).
+// grid = (position chunks, cout / 32, image groups) or image-group-fastest (a.img_fast); block = 64 * NWV.
+template <class G, int NT, int PR, int KMAX, int PCH = 32 * NT>
+__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1>::NWV))
+void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
+  typedef ConvFwdLdsSize<G, NT, PR, KMAX, 1> SZ;
+  typedef ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1> WV;
+  constexpr int NWV = WV::NWV, THREADS = 64 * NWV, TILE_WAVES = WV::TILE_WAVES;
+  constexpr int WS = SZ::WS, PLANE = SZ::PLANE, SUB = SZ::SUB, RP = SZ::RP, CMAX = KMAX / G::KK;
+  constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4;
+  static_assert(KMAX % 16 == 0 && CMAX % 4 == 0, "t16: whole float4s per k-slot");
+  static_assert(SZ::KPAD == KMAX, "the slab has no padded columns");
+  __shared__ __attribute__((aligned(16))) float smem[SZ::FLOATS];
+  float* s_w = smem;
+  float* s_patch = smem + 32 * WS;
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int img0 = (a.img_fast ? (int)blockIdx.x : (int)blockIdx.z) * a.ipb;
+  const int img_end = img0 + a.ipb < a.rows_total ? img0 + a.ipb : a.rows_total;
+  const int cout0 = (int)blockIdx.y * 32;
+  const int p0 = (a.img_fast ? (int)blockIdx.z : (int)blockIdx.x) * PCH;
+  const int cin = a.cin;                              // == CMAX
+  const int oy0 = p0 / G::OH;
+  const int iy0 = oy0 * G::S;
+  int rows = G::IH - iy0;
+  if (rows > PR) rows = PR;
+  const int per_c = rows * G::IH;
+  auto pcell = [&](int c, int off) -> int {
+    const int r = off / G::IH, x = off - r * G::IH;
+    return c * PLANE + r * RP + (x % G::S) * SUB + x / G::S;
+  };
+  // ---- the patch of one image: loads into registers (issue), de-interleaved LDS stores later (commit): rb_conv_fwd_body's f32 paths
+  constexpr bool x_vec = (G::IH % 4) == 0;
+  constexpr int XV = x_vec ? (CMAX * PR * G::IH / 4 + THREADS - 1) / THREADS : 1;
+  constexpr int XS = x_vec ? 1 : (CMAX * PR * G::IH + THREADS - 1) / THREADS;
+  const int v4 = per_c >> 2, total4 = cin * v4, total1 = cin * per_c;
+  float4 xv[XV];
+  float xs[XS];
+  auto issue = [&](int img) {
+    const float* xbase = a.in_f + (int64_t)img * cin * G::IP;
+    if constexpr (x_vec) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int e = i * THREADS + t;
+        const int ec = e < total4 ? e : total4 - 1;
+        const int c = ec / v4, q = ec - c * v4;
+        xv[i] = rb_ld4(xbase + (int64_t)c * G::IP + iy0 * G::IH + q * 4);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XS; ++i) {
+        const int e = i * THREADS + t;
+        const int ec = e < total1 ? e : total1 - 1;
+        const int c = ec / per_c, q = ec - c * per_c;
+        xs[i] = xbase[(int64_t)c * G::IP + iy0 * G::IH + q];
+      }
+    }
+  };
+  auto commit = [&]() {
+    if constexpr (x_vec) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int e = i * THREADS + t;
+        if (e < total4) {
+          const int c = e / v4, q = e - c * v4;
+          if constexpr (G::S == 1) { rb_st4(s_patch + c * PLANE + q * 4, xv[i]); }
+          else if constexpr (G::S == 2 && (SUB % 2) == 0) {
+            const int off = q * 4, r = off / G::IH, x = off - r * G::IH;
+            float* cell = s_patch + c * PLANE + r * RP + x / 2;
+            *reinterpret_cast<float2*>(cell) = make_float2(xv[i].x, xv[i].z);
+            *reinterpret_cast<float2*>(cell + SUB) = make_float2(xv[i].y, xv[i].w);
+          } else {
+            s_patch[pcell(c, q * 4 + 0)] = xv[i].x; s_patch[pcell(c, q * 4 + 1)] = xv[i].y;
+            s_patch[pcell(c, q * 4 + 2)] = xv[i].z; s_patch[pcell(c, q * 4 + 3)] = xv[i].w;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XS; ++i) {
+        const int e = i * THREADS + t;
+        if (e < total1) { const int c = e / per_c, q = e - c * per_c; s_patch[pcell(c, q)] = xs[i]; }
+      }
+    }
+  };
+  // ---- this wave's tile (rb_conv_fwd_body, T16 section): position tile pt, channel tile ct0; lane (x, kq)
+  const bool tile_wave = wave < TILE_WAVES;
+  const int pt = wave % PT, ct0 = (wave / PT) % 2;
+  const int x = lane & 15, kq = lane >> 4;
+  int p = p0 + pt * 16 + x;
+  const bool pv = p < G::P && p < p0 + PCH;
+  if (p > G::P - 1) p = G::P - 1;                     // clamped lanes are never stored
+  const float* bp = s_patch + kq * CQ * PLANE + (p / G::OH - oy0) * G::S * RP + (p % G::OH);
+  const float* ap = s_w + (ct0 * 16 + x) * WS + kq * KQ;
+  float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  issue(img0);
+  for (int img = img0; img < img_end; ++img) {
+    if (img == img0 || img == a.n_on) {               // block-uniform: the slab (row-major, WS apart) and the bias terms of this net
+      const int net = img < a.n_on ? 0 : 1;           // (every wave is past the previous image's MFMA loop: the barrier below)
+      const int rows_valid_w = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
+      for (int e = t; e < 32 * (KMAX / 4); e += THREADS) {
+        const int m = e / (KMAX / 4), q = e - m * (KMAX / 4);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (m < rows_valid_w) v = rb_ld4(a.w[net] + (int64_t)(cout0 + m) * KMAX + 4 * q);
+        rb_st4(s_w + m * WS + 4 * q, v);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = cout0 + ct0 * 16 + 4 * kq + r;
+        bias4[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+      }
+    }
+    commit();
+    __syncthreads();                                  // patch (and slab) complete
+    if (img + 1 < img_end) issue(img + 1);
+    if (tile_wave) {                                  // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
+      rb_f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int jq = 0; jq < KQ / 4; ++jq) {
+        const float4 w4 = rb_ld4(ap + 4 * jq);
+        const float b0 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], b1 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)];
+        const float b2 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], b3 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)];
+        acc = rb_mfma16(w4.x, b0, acc);
+        acc = rb_mfma16(w4.y, b1, acc);
+        acc = rb_mfma16(w4.z, b2, acc);
+        acc = rb_mfma16(w4.w, b3, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                   // D[r]: channel 4 kq + r of the tile, position x
+        const int m = cout0 + ct0 * 16 + 4 * kq + r;
+        if (pv && m < a.cout) {
+          const float o = fmaxf(acc[r] + bias4[r], 0.0f);
+          a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+          if (a.out_blocked) {
+            const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+            a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+          }
+        }
+      }
+    }
+    __syncthreads();                                  // every wave is done reading this image's patch (and, at a net change, the slab)
+  }
+}
+
 // ---- large batches, FIRST layer: whole image per workgroup, no split of the reduction ---------------------------
 // The first layer's reduction is short (K = 256): splitting it over 8 waves leaves 16 MFMA steps per wave and tile, and
 // the cross-wave sum + barriers cost as much as the MFMAs (measured 2.7 us of 5.6 per 80-position chunk).  Here the whole
@@ -1588,27 +1741,9 @@ struct ConvDwAllArgs {
   int ipb;                 // images summed per workgroup
   int img_fast;            // decode with the image group as the FASTEST index (see k_conv_fwd_lds): needs block ranges and group
                            // counts that are multiples of 8
-  // ONE housekeeping workgroup behind the layers' (hk != 0; learner.hip: the slice reduction of this call is folded into the next
-  // call's sampler launch, so what its launch did besides summing happens here): copy hk_n floats (the learn call's online noise:
-  // the snapshot for the optimiser pass that forms the hidden layer's sigma gradient itself), clear *hk_clear
-  // (ClipAdamArgs::pair_clipped) and zero *hk_ctr (the folded reduction's arrival counter)
-  int hk;
-  const float* hk_src;
-  float* hk_dst;
-  int hk_n;
-  int32_t* hk_clear;
-  unsigned* hk_ctr;
 };
 template <class G0, int RC0, class G1, int RC1, int K1, class G2, int RC2, int K2, int NL>
 __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a) {
-  if (a.hk && (int)blockIdx.x == a.nblocks[0] + a.nblocks[1] + (NL > 2 ? a.nblocks[2] : 0)) {     // block-uniform
-    for (int j = (int)threadIdx.x; j < a.hk_n; j += (int)blockDim.x) a.hk_dst[j] = a.hk_src[j];
-    if (threadIdx.x == 0) {
-      if (a.hk_clear) *a.hk_clear = 0;
-      if (a.hk_ctr) { a.hk_ctr[0] = 0u; a.hk_ctr[1024] = 0u; }           // (arrivals, READY flag: adam_body.h RB_FOLD_READY_WORD)
-    }
-    return;
-  }
   typedef ConvDwLdsSize<G0, RC0, 4 * G0::KK> S0;
   typedef ConvDwLdsSize<G1, RC1, K1> S1;
   typedef ConvDwLdsSize<G2, RC2, K2> S2;

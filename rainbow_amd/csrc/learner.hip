@@ -163,7 +163,7 @@ struct rb_learner {
   int lazy_splits;
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
-  int opt_conv_multi, opt_conv_full, opt_dx_ipb, opt_img_fast;
+  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_img_fast;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   int opt_implicit_small;
@@ -239,16 +239,6 @@ struct rb_learner {
   // RB_LEARNER_IMPLICIT_SIGMA: the hidden layer's sigma-weight gradient is not stored by the backward; the hosted optimiser
   // pass forms it from g_mu and the noise the backward used (adam_body.h rb_adam_hosted_pairs).  sigma_implicit = the flat
   // gradient lacks that range right now; every other consumer of the gradient materialises it first (materialize_sigma)
-  // FOLDED conv reduction (RB_OPTS fold_reduce, default 1; adam_body.h ClipAdamArgs::red): a learn call issued by
-  // rb_learner_train_step with the deferred optimiser pass leaves the fixed-order sum of its conv weight-gradient slices (the 6 us
-  // k_reduce_conv_dw_all launch at the very end of the step) to that pass — its only consumer — where it runs as the first
-  // workgroups of the NEXT call's sampler launch, beside the streaming.  fold_next: set by train_step for the learn call it is
-  // about to issue; reduce_pending: that call left red_host un-launched; whoever needs the conv gradients first (the deferred
-  // pass, or flush_reduce as a launch of its own) clears it.
-  int opt_fold_reduce, fold_next, fold_now, reduce_pending;
-  ReduceAllArgs red_host;
-  unsigned* fold_ctr;       // device: arrivals of the folded reduction's workgroups (zeroed by k_conv_dw_all's housekeeping block)
-  int32_t* fold_err;        // pinned, device-mapped: an expired in-launch wait of the hosted pass (must stay 0)
   int sigma_implicit;
   float* noise_snap;        // [n_noise] the online noise of the learn call in flight, copied by its last backward launch
   int32_t* status_copy;     // this learn call's batch_status, copied by its head kernel: the hosted pass shares a launch with
@@ -261,7 +251,6 @@ struct rb_learner {
 #define RB_SPEC_DRAW_DEFAULT 0    // RB_OPTS spec_draw: see rb_learner::opt_spec_draw (opt-in: only append-free loops ever arm it)
 #endif
 static int flush_update(rb_learner* l, hipStream_t stream);
-static int flush_reduce(rb_learner* l, hipStream_t stream);
 #define RB_FLUSH_UPDATE(l, stream)                                  \
   do {                                                              \
     const int rcf_ = flush_update((l), (hipStream_t)(stream));      \
@@ -334,7 +323,39 @@ __global__ __launch_bounds__(256) void k_reduce_conv_dw(const float* part, int s
   }
 }
 
-// all conv layers' split slices in ONE launch (saves two dependent ~5 us launches per step); arguments and the hosted form: reduce_body.h
+// all conv layers' split slices in ONE launch (saves two dependent ~5 us launches per step)
+struct ReduceLayer {
+  const float* part;
+  float *gw, *gb;
+  int slices, cout, K;
+  int64_t begin;          // first flat output index of this layer in the fused index space
+};
+struct ReduceAllArgs {
+  ReduceLayer layer[3];
+  int n_layers;
+  int64_t total;
+  float* sq_part;         // optional: one slot per block = sum of squares of the gradients this block produced
+  // replica exchange: every reduced element is ALSO stored at copy_base + (its offset inside the flat gradient), i.e. into
+  // the conv segment of this rank's exchange block
+  const float* grads_base;
+  float* copy_base;
+  // tenant blocks behind the reduction's own: copy snap_n floats (the learn call's online noise, for the optimiser pass that
+  // forms the hidden layer's sigma gradient itself: the launch hosting that pass resamples the noise)
+  const float* snap_src;
+  float* snap_dst;
+  int snap_n;
+  int32_t* snap_clear;      // ... and clear this word (ClipAdamArgs::pair_clipped: no scaled gradient has been stored for this step yet)
+};
+template <int N>
+__device__ __forceinline__ float rb_sum_slices(const float* part, int64_t per, int64_t j, int slices) {
+  float v[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] = part[(int64_t)(u < slices ? u : slices - 1) * per + j];   // clamped: always legal
+  float acc = 0.0f;
+#pragma unroll
+  for (int u = 0; u < N; ++u) acc += (u < slices) ? v[u] : 0.0f;
+  return acc;
+}
 __global__ __launch_bounds__(64) void k_reduce_conv_dw_all(ReduceAllArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ((a.total + 63) / 64) * 64) {                  // block-uniform: a snapshot tenant
@@ -926,6 +947,15 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
         a.img_fast = 1;
         gridm = dim3(ngroups, (unsigned)rb_div_up(c.cout, 32), (unsigned)rb_div_up(G::P, PCH));
       }
+      if constexpr (KMAX % 16 == 0 && (KMAX / G::KK) % 4 == 0 && 2 * ((PCH + 15) / 16) <= 16 && (PCH % 16 == 0 || PCH >= G::P) && G::P > 16) {
+        // whole-K 16x16x4 tiles in the image loop as well (conv_lds.h k_conv_fwd_multi_t16; RB_OPTS conv_multi_t16=0: the split-K body)
+        if (l->opt_conv_multi_t16 && ((l->opt_t16 >> layer) & 1) && c.cin * G::KK == KMAX && c.cout % 32 == 0) {
+          constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1>::NWV;
+          RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi_t16<G, NT, PR, KMAX, PCH>), gridm, dim3(64 * NWV), stream, a);
+          RB_LAUNCH_CHECK();
+          return RB_OK;
+        }
+      }
       RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi<G, NT, PR, KMAX, FIRST, PCH>), gridm, dim3(RB_CONV_THREADS), stream, a);
       RB_LAUNCH_CHECK();
       return RB_OK;
@@ -1195,12 +1225,6 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   // image-fastest decode (an image group's workgroups of every layer on XCD group mod 8, where the input-gradient chain left
   // its dY): block ranges and the group count must be multiples of 8
   a.img_fast = (l->opt_img_fast && groups % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
-  a.hk = 0; a.hk_src = nullptr; a.hk_dst = nullptr; a.hk_n = 0; a.hk_clear = nullptr; a.hk_ctr = nullptr;
-  if (l->fold_now) {      // the slice reduction is left to the deferred optimiser pass: its launch's housekeeping happens here
-    a.hk = 1; a.hk_ctr = l->fold_ctr;
-    if (l->sigma_implicit) { a.hk_src = l->n_online; a.hk_dst = l->noise_snap; a.hk_n = (int)L.n_noise; a.hk_clear = l->status_copy + 2; }
-    total += 1;
-  }
   // (a pipelined body — two operand sets in LDS, the next image's loads in flight under this image's MFMAs — was built in round 5,
   // bit-identical, and measured SLOWER at batch 256: 75.9 against 64.5 us for this launch, profiles/round5_experiments.txt; removed)
   if (L.nconv == 3) {
@@ -1329,8 +1353,6 @@ int rb_learner_destroy(rb_learner_t* l) {
   if (l->status_copy) rb_dev_free(l->status_copy);
   if (l->adam_args_dev) rb_dev_free(l->adam_args_dev);
   if (l->go_flag) rb_dev_free(l->go_flag);
-  if (l->fold_ctr) rb_dev_free(l->fold_ctr);
-  if (l->fold_err) (void)hipHostFree(l->fold_err);
   delete l;
   return RB_OK;
 }
@@ -1368,6 +1390,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->fast_fc = (L.F % 32 == 0 && L.H % 32 == 0 && L.F <= RB_FWD2_KMAX && L.H <= RB_FWD2_KMAX && generic == 0) ? 1 : 0;
   l->fast_conv = (L.hist <= 4 && generic != 1) ? 1 : 0;
   l->opt_conv_multi = rb_opt("conv_multi", -1);       // images per workgroup of the conv forward (-1: by image count)
+  l->opt_conv_multi_t16 = rb_opt("conv_multi_t16", 1);    // the image loop on whole-K 16x16x4 tiles (0: the split-K body)
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
@@ -1444,15 +1467,6 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
 #undef RB_ALLOC
   RB_HIP_TRY(hipMemset(l->act_ctr, 0, (6 * RB_FAN_SHARDS * RB_FAN_STRIDE + 32) * 4));
   l->opt_act_fused = rb_opt("act_fused", 1);
-  l->opt_fold_reduce = rb_opt("fold_reduce", 1);
-  if (l->opt_fold_reduce) {
-    hipError_t e = rb_dev_malloc((void**)&l->fold_ctr, 8192);     // word 0: arrivals, word RB_FOLD_READY_WORD: the READY flag
-    if (e != hipSuccess) { rb_set_error("rb_learner_create: hipMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
-    RB_HIP_TRY(hipMemset(l->fold_ctr, 0, 8192));
-    e = hipHostMalloc((void**)&l->fold_err, 64, hipHostMallocMapped);
-    if (e != hipSuccess) { rb_set_error("rb_learner_create: hipHostMalloc failed: %s", hipGetErrorString(e)); rb_learner_destroy(l); return RB_ERR_OOM; }
-    *l->fold_err = 0;
-  }
   l->opt_spec_draw = rb_opt("spec_draw", RB_SPEC_DRAW_DEFAULT);
   l->opt_spec_stall = rb_opt("spec_stall", 0);
   if (l->opt_spec_draw) {
@@ -2008,10 +2022,6 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     RB_LAUNCH_CHECK();
   }
   }
-  // the conv slice reduction of this call folded into the deferred optimiser pass (rb_learner::fold_next): needs the fused norm
-  // partials (the pass reads them, k_sumsq would need the summed gradient) and the one-launch weight-gradient kernel
-  l->fold_now = (l->fold_next && l->fast_fc && l->fast_conv && l->norm_slots > 0 && !exch && !l->dw_deferred) ? 1 : 0;
-  l->fold_next = 0;
   if (l->fast_conv) {
     for (int layer = L.nconv - 1; layer > 0; --layer)                 // the input-gradient chain first ...
       if ((rc = conv_bwd(l, layer, states_dev, stream, 2)) != RB_OK) return rc;
@@ -2022,7 +2032,6 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
   }
   {   // one fixed-order reduction of every conv layer's split slices into the gradient buffer
     ReduceAllArgs ra;
-    memset(&ra, 0, sizeof(ra));          // (compared bytewise once it is part of the pending pass's arguments)
     int64_t off = 0;
     for (int layer = 0; layer < L.nconv; ++layer) {
       const ConvLayer& c = L.conv[layer];
@@ -2035,27 +2044,10 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     ra.grads_base = l->grads;
     ra.copy_base = exch ? l->fact_local + l->fact_off[5] : nullptr;
     ra.snap_src = nullptr; ra.snap_dst = nullptr; ra.snap_n = 0; ra.snap_clear = nullptr;
-    if (l->fold_now) {
-      // left to the deferred optimiser pass (clip_adam_impl attaches it; flush_reduce launches it otherwise).  The noise
-      // snapshot and the counter reset went with k_conv_dw_all's housekeeping block (conv_dw_all above).
-      l->red_host = ra;
-      l->reduce_pending = 1;
-      l->fold_now = 0;
-      return RB_OK;
-    }
     if (l->sigma_implicit) { ra.snap_src = l->n_online; ra.snap_dst = l->noise_snap; ra.snap_n = (int)L.n_noise; ra.snap_clear = l->status_copy + 2; }
     RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)(rb_div_up(off, 64) + rb_div_up(ra.snap_n, 64))), dim3(64), stream, ra);
     RB_LAUNCH_CHECK();
   }
-  return RB_OK;
-}
-
-// the conv slice reduction a learn call left pending, as a launch of its own (nobody will host it)
-static int flush_reduce(rb_learner* l, hipStream_t stream) {
-  if (!l->reduce_pending) return RB_OK;
-  RB_LAUNCH(k_reduce_conv_dw_all, dim3((unsigned)rb_div_up(l->red_host.total, 64)), dim3(64), stream, l->red_host);
-  RB_LAUNCH_CHECK();
-  l->reduce_pending = 0;
   return RB_OK;
 }
 
@@ -2097,13 +2089,12 @@ static int materialize_sigma(rb_learner* l, hipStream_t stream) {
   } while (0)
 
 static int flush_update(rb_learner* l, hipStream_t stream) {
-  if (!l->adam_pending) return flush_reduce(l, stream);     // (a learn call whose optimiser pass never came: its slices are summed now)
+  if (!l->adam_pending) return RB_OK;
   FusedDwAdamArgs f;
   memset(&f, 0, sizeof(f));
   ClipAdamArgs a = l->adam_args_host;
   int blocks = l->adam_blocks;
-  if (a.pair_len4 > 0 || a.red_blocks > 0) {   // the pending pass forms the sigma gradient itself and / or carries the folded conv
-                                               // reduction: the hosted body as a launch of its own
+  if (a.pair_len4 > 0) {        // the pending pass forms the sigma gradient itself: the hosted body as a launch of its own
     const int rc = rb_launch_adam_pending(l->adam_args_dev, blocks, stream);      // (its arguments are in device memory already)
     if (rc != RB_OK) return rc;
     l->adam_pending = 0;
@@ -2199,24 +2190,15 @@ static int train_step_impl(rb_learner_t* l, const rb_train_step_t* a, rb_comm_t*
     }
     if (l->opt_spec_draw && !capturing) rb_replay_spec_arm_accept(a->replay);     // only THIS caller reads the table of the accepted draw
   }
-  if (l->fold_err && *(volatile int32_t*)l->fold_err != 0) {
-    rb_set_error("rb_learner_train_step: an in-launch wait of the hosted optimiser pass expired (the folded conv reduction did not "
-                 "arrive): the parameters of that step are not to be trusted; RB_OPTS=fold_reduce=0 keeps the reduction a launch of its own");
-    return RB_ERR_STATE;
-  }
   int rc = rb_replay_sample_fused_noise(a->replay, a->batch, a->priority_weight, nullptr, a->max_attempts, a->tree_idx_dev, nullptr,
                                         nullptr, a->actions_dev, a->returns_dev, a->nonterminals_dev, a->weights_dev,
                                         job, stream);
   if (rc != RB_OK) { l->spec_now = 0; return rc; }
   if (hosted) l->adam_pending = 0;
-  // this call's conv slice reduction may ride in its own optimiser pass (deferred below: hosted by the NEXT call's sampler launch)
-  l->fold_next = (l->opt_fold_reduce && comm == nullptr && (l->flags & RB_LEARNER_DEFER_UPDATE) && a->step == 0 && l->step_ctr &&
-                  l->adam_args_dev && l->fold_ctr && l->fold_err && !rb_stream_capturing(stream)) ? 1 : 0;
   // (the window table of THIS draw: an accepted early draw filled the replay's other table)
   rc = rb_learner_learn_windows(l, a->frames_dev, rb_replay_current_windows(a->replay), a->window_len, a->actions_dev, a->returns_dev,
                                 a->nonterminals_dev, a->weights_dev, a->loss_dev, stream);
   l->spec_now = 0;
-  l->fold_next = 0;
   {
     auto& t = l->ts_last;
     t.replay = a->replay; t.batch = a->batch; t.max_attempts = a->max_attempts; t.beta = a->priority_weight; t.tree_idx = a->tree_idx_dev;
@@ -2279,14 +2261,6 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
   RB_REQUIRE(step >= 1 || (step == 0 && l->step_ctr), "rb_learner_clip_adam: step is 1-based (0 = take it from the device counter set "
              "with rb_learner_set_step_counter)");
   const int64_t n = l->L.n_params;
-  // a conv slice reduction left pending by the learn call (fold_next): it rides in this pass if the pass is going to be hosted /
-  // launched through the hosted body; otherwise it runs now, as the launch it used to be
-  const bool fold = l->reduce_pending && defer && step == 0 && l->step_ctr && l->norm_slots > 0 && l->adam_args_dev != nullptr &&
-                    !l->dw_deferred && (max_norm < INFINITY || norm_dev != nullptr);
-  if (l->reduce_pending && !fold) {
-    const int rcr = flush_reduce(l, stream);
-    if (rcr != RB_OK) return rcr;
-  }
   int nparts = l->norm_slots;
   if (!(max_norm < INFINITY) && norm_dev == nullptr) {
     nparts = 0;        // plain optimiser.step(): no clip, nobody wants the norm
@@ -2329,13 +2303,6 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
   } else {
     unsigned grid = (unsigned)rb_div_up(n4 > 0 ? n4 : 1, 256 * 4);
     const bool will_defer = defer && a.step_dev != nullptr && a.nparts > 0 && l->adam_args_dev != nullptr;
-    int red_blocks = 0;
-    if (fold) {           // (fold implies will_defer: same conditions)
-      const int64_t conv_slots = rb_div_up(l->red_host.total, 64);
-      a.red = l->red_host; a.red_slots = (int)conv_slots; a.red_blocks = red_blocks = (int)rb_div_up(conv_slots, 4);
-      a.red_ctr = l->fold_ctr; a.red_err = l->fold_err;
-      l->reduce_pending = 0;
-    }
     if (l->sigma_implicit && will_defer) {
       // the hosted pass updates (mu, sigma) quads of the hidden layer together and forms g_sigma itself (adam_body.h)
       const Layout& L = l->L;
@@ -2360,7 +2327,7 @@ static int clip_adam_impl(rb_learner* l, float max_norm, float* exp_avg, float* 
         l->adam_args_valid = 1;
       }
       l->adam_pending = 1;
-      l->adam_blocks = (int)grid + red_blocks;      // (the folded reduction's workgroups lead the hosted range)
+      l->adam_blocks = (int)grid;
       return RB_OK;
     }
     RB_LAUNCH_T("clip_adam:k_clip_adam", (k_clip_adam<4, true, false>), dim3(grid), dim3(256), stream, a, f);

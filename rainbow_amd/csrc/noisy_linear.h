@@ -22,9 +22,6 @@
 #pragma once
 #include "rb_device.h"
 #include "replay_internal.h"
-#ifndef RB_FWD_NT
-#define RB_FWD_NT 0
-#endif
 
 struct NlWeights {
   const float* mu;      // [N][K]
@@ -154,8 +151,8 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
     const unsigned so = (unsigned)b * 128u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      r_mu[d][i] = rb_ld4_buf_aux<RB_FWD_NT>(bmu, wo[i], so);      // (RB_FWD_NT: experiment switch, 2 = non-temporal weight stream)
-      r_sg[d][i] = rb_ld4_buf_aux<RB_FWD_NT>(bsg, wo[i], so);
+      r_mu[d][i] = rb_ld4_buf(bmu, wo[i], so);
+      r_sg[d][i] = rb_ld4_buf(bsg, wo[i], so);
     }
   };
   auto load_x = [&](int d, int b) {

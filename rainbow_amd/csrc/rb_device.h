@@ -265,20 +265,6 @@ __device__ __forceinline__ float4 rb_ld4_buf(const rb_buf& b, unsigned lane_off,
 #endif
 }
 
-// the same with a compile-time cache-policy operand (aux: 0 default, 2 = nt: a line that is read once should not displace others)
-template <int AUX>
-__device__ __forceinline__ float4 rb_ld4_buf_aux(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {
-#if defined(RB_HOST_INTERP)
-  return rb_ld4_buf(b, lane_off, uniform_off);
-#else
-  typedef unsigned int rb_v4u __attribute__((ext_vector_type(4)));
-  const rb_v4u t = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)lane_off, (int)uniform_off, AUX);
-  float4 v;
-  v.x = __uint_as_float(t.x); v.y = __uint_as_float(t.y); v.z = __uint_as_float(t.z); v.w = __uint_as_float(t.w);
-  return v;
-#endif
-}
-
 // agent-coherent variants (sc1): the load is served from the point where the XCDs agree (not from this CU's L1 / a stale
 // line of this XCD's L2) — for data another workgroup of the SAME launch produced (rb_chain_*)
 __device__ __forceinline__ float4 rb_ld4_buf_sc1(const rb_buf& b, unsigned lane_off, unsigned uniform_off) {

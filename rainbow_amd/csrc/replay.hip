@@ -63,10 +63,6 @@ struct rb_replay {
                                   // the public sample entry points always redraw into table 0 = rb_replay_buffers_t.window_dev)
   int spec_disabled;              // an expired cross-stream wait was seen (fail_host[2]): no early draw on this handle until
                                   // rb_replay_reset_failed_samples
-  // the sampler's CU kept out of the hosted optimiser stream (k_sample rb_iso_*; RB_OPTS iso, default 1)
-  unsigned* iso;                  // device, 64 words: [0] announcement, [32] done
-  unsigned iso_no;                // launch number of the last hosting launch (16 bits, never 0)
-  int opt_iso;
 };
 static int32_t* win_of(const rb_replay* r, int set) { return set ? r->win2 : r->win; }
 // every entry point that reads or writes the replay outside a draw: wait for an early draw in flight and discard it (its
@@ -497,48 +493,6 @@ __device__ __forceinline__ void rb_sample_main(const ReplayView& v, int32_t batc
                                                int* s_flag, float* s_red, float* s_top, bool top_staged, SpecResult* spec = nullptr,
                                                unsigned spec_epoch = 0u);
 __device__ __forceinline__ int rb_poll_epoch(const unsigned* flag, unsigned epoch, int32_t* err_host);
-// ---- the sampler's CU kept out of the hosted stream (k_sample) ----
-// iso[0] = (launch number << 16) | CU key of block 0, iso[32] = launch number once block 0 is done (another 128-byte line)
-__device__ __forceinline__ unsigned rb_cu_key() {
-#if defined(RB_HOST_INTERP)
-  return 0u;
-#else
-  // XCC_ID (4 bits) and the (se, sh, cu) bits of HW_ID: tools/wg_timeline.py counts 256 distinct values of this key
-  return ((unsigned)__builtin_amdgcn_s_getreg(6164) << 8) | (((unsigned)__builtin_amdgcn_s_getreg(63492) >> 8) & 0xffu);
-#endif
-}
-__device__ __forceinline__ void rb_iso_announce(unsigned* iso, unsigned no) {
-#if defined(RB_HOST_INTERP)
-  iso[0] = (no << 16) | rb_cu_key();
-#else
-  __hip_atomic_store(iso, (no << 16) | rb_cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ void rb_iso_done(unsigned* iso, unsigned no) {
-#if defined(RB_HOST_INTERP)
-  iso[32] = no;
-#else
-  __hip_atomic_store(iso + 32, no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ void rb_iso_yield(const unsigned* iso, unsigned no) {      // all threads of a streaming workgroup call
-#if !defined(RB_HOST_INTERP)
-  if (threadIdx.x == 0) {
-    const unsigned w = __hip_atomic_load(iso, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w == ((no << 16) | rb_cu_key())) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(iso + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != no) {
-        __builtin_amdgcn_s_sleep(20);
-        if (++spins > (1u << 12)) break;                  // ~2 ms: then stream anyway (a performance device, never a dependency)
-      }
-    }
-  }
-  __syncthreads();
-#else
-  (void)iso; (void)no;
-#endif
-}
-
 template <int MAXT, int AU>
 __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, float neg_beta_arg,
                                                   const float* neg_beta_ptr, const double* unit_uniforms, int32_t max_attempts, uint64_t seed,
@@ -547,17 +501,11 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
                                                   float* weights_out, const NoiseJob* job_dev, float* job_noise, float* job_noise2,
                                                   unsigned long long* job_ctr, int32_t* fail_count, int32_t lds_top,
                                                   int32_t noise_blocks, const ClipAdamArgs* adam_dev, SpecResult* spec,
-                                                  unsigned spec_epoch, int32_t spec_mode, unsigned* iso, unsigned iso_no) {
+                                                  unsigned spec_epoch, int32_t spec_mode) {
   if ((int)blockIdx.x > noise_blocks) {
     // co-tenant workgroups behind the noise ones: the previous learn call's optimiser pass (adam_body.h) — independent of
     // this batch's sampling, and 30 us of pure streaming that now runs beside the sampler's serial chain, not before it
     __shared__ float s_adam[18];
-    // THE SAMPLER'S CU STAYS OUT OF THE STREAM (iso != NULL): a dependent load of the sampler's chain waits in its OWN CU's memory
-    // queue behind every streaming wave that shares the CU (MI355X_MICROARCH hand-off table: 1.1 us with none, 3.5-5 us with 15), which
-    // is what stretches the chain from 20 to 50 us at batch 256.  A streaming workgroup that finds itself on the CU block 0 announced
-    // for THIS launch idles until block 0 is done — 1/256 of the stream's capacity for the length of the chain.  (A workgroup that
-    // starts before the announcement streams at once: harmless.)
-    if constexpr (MAXT > 256) { if (iso) rb_iso_yield(iso, iso_no); }      // (only the 1024-thread variant hosts)
     rb_adam_hosted_block<AU>(adam_dev, (int)blockIdx.x - 1 - noise_blocks, (int)gridDim.x - 1 - noise_blocks, s_adam);
     return;
   }
@@ -574,7 +522,6 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
   __shared__ int s_flag[16];
   __shared__ float s_red[16];
   __shared__ __attribute__((aligned(16))) float s_top[RB_TOP_NODES + 1];
-  if constexpr (MAXT > 256) { if (iso && threadIdx.x == 0) rb_iso_announce(iso, iso_no); }
   // spec_mode (the early draw, replay_internal.h): 1 = THIS is the tentative draw; 2 = an early draw is in flight on another stream
   // and is accepted: wait for it, commit its header effects, done; 3 = in flight but not acceptable (other arguments, or a public
   // entry point): wait, then draw as usual.  FAIL SAFE: when the wait expires, or the pair on the other stream reports that it
@@ -594,16 +541,12 @@ __global__ __launch_bounds__(MAXT) void k_sample(ReplayView v, int32_t batch, fl
       s_flag[15] = accept;
     }
     __syncthreads();
-    if (s_flag[15]) {                                     // block-uniform
-      if constexpr (MAXT > 256) { if (iso && threadIdx.x == 0) rb_iso_done(iso, iso_no); }
-      return;
-    }
+    if (s_flag[15]) return;                               // block-uniform
     __syncthreads();                                      // (s_flag is reused by the sampler proper)
   }
   rb_sample_main<MAXT>(v, batch, neg_beta_arg, neg_beta_ptr, unit_uniforms, max_attempts, seed, scaling, tree_idx_out, win, actions_out,
                        returns_out, nonterminals_out, weights_out, fail_count, lds_top, s_flag, s_red, s_top, false,
                        spec_mode == 1 ? spec : nullptr, spec_epoch);
-  if constexpr (MAXT > 256) { if (iso && threadIdx.x == 0) rb_iso_done(iso, iso_no); }  // (thread 0's part of the draw is behind it: the stream may have the CU)
 }
 
 // The sampler proper (one workgroup, thread i = sample i): shared by k_sample (block 0) and k_update_sample.  top_staged: the
@@ -1044,7 +987,6 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   r->tree = nullptr; r->frames = nullptr; r->timestep = nullptr; r->action = nullptr; r->reward = nullptr;
   r->nonterminal = nullptr; r->hdr = nullptr; r->win = nullptr; r->scaling_dev = nullptr; r->fail_host = nullptr;
   r->win2 = nullptr; r->win_sel = 0; r->spec_stream = nullptr; r->spec_res = nullptr; r->spec_epoch = 0; r->spec_inflight = 0; r->spec_accept_armed = 0; r->spec_disabled = 0;
-  r->iso = nullptr; r->iso_no = 0; r->opt_iso = rb_opt("iso", 1);
   r->mutations = 0;
 #define RB_ALLOC(ptr, bytes)                                                                      \
   do {                                                                                            \
@@ -1065,7 +1007,6 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_ALLOC(r->win, (int64_t)r->max_batch * 64 * sizeof(int32_t));
   RB_ALLOC(r->win2, (int64_t)r->max_batch * 64 * sizeof(int32_t));
   RB_ALLOC(r->spec_res, sizeof(SpecResult));
-  RB_ALLOC(r->iso, 64 * sizeof(unsigned));
   RB_ALLOC(r->scaling_dev, 64 * sizeof(float));
 #undef RB_ALLOC
   {
@@ -1086,7 +1027,6 @@ int rb_replay_create(rb_replay_t** out, int64_t capacity, int32_t history, int32
   RB_HIP_TRY(hipMemset(r->nonterminal, 0, capacity));
   RB_HIP_TRY(hipMemcpy(r->scaling_dev, r->scaling, 64 * sizeof(float), hipMemcpyHostToDevice));
   RB_HIP_TRY(hipMemset(r->spec_res, 0, sizeof(SpecResult)));
-  RB_HIP_TRY(hipMemset(r->iso, 0, 64 * sizeof(unsigned)));
   RB_LAUNCH(k_replay_init, dim3(1), dim3(64), nullptr, r->hdr);
   RB_LAUNCH_CHECK();
   RB_HIP_TRY(hipDeviceSynchronize());
@@ -1104,7 +1044,6 @@ int rb_replay_destroy(rb_replay_t* r) {
   live_del(r);
   if (r->win2) rb_dev_free(r->win2);
   if (r->spec_res) rb_dev_free(r->spec_res);
-  if (r->iso) rb_dev_free(r->iso);
   if (r->tree) rb_dev_free(r->tree);
   if (r->frames) rb_dev_free(r->frames);
   if (r->timestep) rb_dev_free(r->timestep);
@@ -1329,17 +1268,13 @@ static int sample_impl(rb_replay_t* r, int32_t batch, double priority_weight, co
   // (the tree search keeps its top 4095 nodes in LDS: measured against an all-global search, B = 32 / 1M leaves: 11.1 vs
   // 11.6 us, n = 20 / 100k: 14.3 vs 16.1, B = 256: 20.0 vs 24.4 — a trip costs ~1.3 us of issue, more than the staging)
   const int lds_top = 1;
-  // the hosting launch keeps its streaming workgroups off the sampler's CU (k_sample: rb_iso_*); launch numbers are 16 bits, never 0
-  unsigned* iso_dev = (adam_dev && r->opt_iso) ? r->iso : nullptr;
-  unsigned iso_no = 0;
-  if (iso_dev) { r->iso_no = (r->iso_no % 65535u) + 1u; iso_no = r->iso_no; }
   if (threads <= 256 && host_mode != 1) {
     RB_LAUNCH_T("sample:k_sample", (k_sample<256, 8>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, win_cur, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev, r->spec_res, r->spec_epoch, spec_mode, iso_dev, iso_no);
+                r->scaling_dev, tree_idx_dev, win_cur, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev, r->spec_res, r->spec_epoch, spec_mode);
   } else {
     RB_REQUIRE(r->history + r->n <= 24, "rb_replay_sample: the 1024-thread sampler (batch > 256) supports history + multi_step <= 24");
     RB_LAUNCH_T("sample:k_sample", (k_sample<1024, RB_HOST_AU_WIDE>), dim3(blocks), dim3(threads), stream, v, batch, neg_beta, r->neg_beta_dev, unit_uniforms_dev, max_attempts, r->seed,
-                r->scaling_dev, tree_idx_dev, win_cur, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev, r->spec_res, r->spec_epoch, spec_mode, iso_dev, iso_no);
+                r->scaling_dev, tree_idx_dev, win_cur, actions_dev, returns_dev, nonterminals_dev, weights_dev, job.dev, job.noise, job.noise2, job.ctr, r->fail_host, lds_top, noise_blocks, adam_dev, r->spec_res, r->spec_epoch, spec_mode);
   }
   RB_LAUNCH_CHECK();
   if (states_dev && next_states_dev) {

@@ -79,14 +79,16 @@ def test_conv_forward_tile_variants_match_golden(emu, monkeypatch, t16):
     ad.close()
 
 
-@pytest.mark.parametrize("name,steps,full", [("dataeff", None, "1"), ("canon", 1, "1"), ("canon", 1, "0")])
-def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, full):
+@pytest.mark.parametrize("name,steps,full,t16", [("dataeff", None, "1", 1), ("canon", 1, "1", 1), ("canon", 1, "0", 1), ("canon", 1, "1", 0)])
+def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, full, t16):
     """Large batches run the conv forward and data-gradient kernels with one weight slab per workgroup and a loop over
-    images (k_conv_fwd_multi, k_conv_dx_lds<..., MULTI>); RB_OPTS conv_multi / dx_ipb force those paths (ragged: neither
-    divides the batch) on the small fixtures, with the last layer's dY formed from the row-split partials in the loop."""
+    images (k_conv_fwd_multi_t16 — whole-K 16x16x4 tiles, round 6 — or, conv_multi_t16=0, the split-K k_conv_fwd_multi;
+    k_conv_dx_lds<..., MULTI>); RB_OPTS conv_multi / dx_ipb force those paths (ragged: neither divides the batch; the group of 5
+    that holds the last online and the first target image re-stages its slab) on the small fixtures, with the last layer's dY
+    formed from the row-split partials in the loop."""
     # dx_ipb / conv_multi: ragged image groups in the input-gradient and forward kernels; conv_full: the first layer's
     # whole-image kernel (k_conv_fwd_full) or, 0, the one-image kernel
-    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s" % full)
+    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s,conv_multi_t16=%d" % (full, t16))
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=steps)
     golden = load_golden("learn_%s.npz" % name)
@@ -416,10 +418,6 @@ def test_deferred_optimiser_pass_is_hosted_by_the_next_sampler_launch(emu, monke
         if implicit_sigma:      # the hidden layer's sigma gradient of THIS step is not in the flat gradient (its mu part is)
             sg = h1[2].layout["fc_h_v.weight_sigma"][0]
             assert not np.array_equal(a["grads"][sg:sg + 512], b["grads"][sg:sg + 512])
-        # the conv gradients of THIS step are not in the flat gradient either: the fixed-order sum of their slices is folded into
-        # the pending pass (RB_OPTS fold_reduce, reduce_body.h) — the twin's k_reduce_conv_dw_all has run
-        cw = h1[2].layout["convs.0.weight"][0]
-        assert not np.array_equal(a["grads"][cw:cw + 512], b["grads"][cw:cw + 512]), "the conv slice reduction was not folded"
         for k in ("idx", "loss", "w", "noise", "tree"):             # the step itself never waits for the pending pass' results
             assert np.array_equal(a[k], b[k]), (step, k)            # ... because it has run by then (same launch as the sampler)
         if prev_twin is not None:                                   # one update behind, exactly

