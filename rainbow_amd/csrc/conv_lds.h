@@ -885,7 +885,8 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
   constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4;
   static_assert(KMAX % 16 == 0 && CMAX % 4 == 0, "t16: whole float4s per k-slot");
   static_assert(SZ::KPAD == KMAX, "the slab has no padded columns");
-  __shared__ __attribute__((aligned(16))) float smem[SZ::FLOATS];
+  constexpr bool DB = (32 * WS + 2 * CMAX * PLANE) * 4 <= 150 * 1024;      // room for a second patch buffer
+  __shared__ __attribute__((aligned(16))) float smem[SZ::FLOATS + (DB ? CMAX * PLANE : 0)];
   float* s_w = smem;
   float* s_patch = smem + 32 * WS;
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -930,22 +931,22 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](float* dst) {
     if constexpr (x_vec) {
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int e = i * THREADS + t;
         if (e < total4) {
           const int c = e / v4, q = e - c * v4;
-          if constexpr (G::S == 1) { rb_st4(s_patch + c * PLANE + q * 4, xv[i]); }
+          if constexpr (G::S == 1) { rb_st4(dst + c * PLANE + q * 4, xv[i]); }
           else if constexpr (G::S == 2 && (SUB % 2) == 0) {
             const int off = q * 4, r = off / G::IH, x = off - r * G::IH;
-            float* cell = s_patch + c * PLANE + r * RP + x / 2;
+            float* cell = dst + c * PLANE + r * RP + x / 2;
             *reinterpret_cast<float2*>(cell) = make_float2(xv[i].x, xv[i].z);
             *reinterpret_cast<float2*>(cell + SUB) = make_float2(xv[i].y, xv[i].w);
           } else {
-            s_patch[pcell(c, q * 4 + 0)] = xv[i].x; s_patch[pcell(c, q * 4 + 1)] = xv[i].y;
-            s_patch[pcell(c, q * 4 + 2)] = xv[i].z; s_patch[pcell(c, q * 4 + 3)] = xv[i].w;
+            dst[pcell(c, q * 4 + 0)] = xv[i].x; dst[pcell(c, q * 4 + 1)] = xv[i].y;
+            dst[pcell(c, q * 4 + 2)] = xv[i].z; dst[pcell(c, q * 4 + 3)] = xv[i].w;
           }
         }
       }
@@ -953,7 +954,7 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
 #pragma unroll
       for (int i = 0; i < XS; ++i) {
         const int e = i * THREADS + t;
-        if (e < total1) { const int c = e / per_c, q = e - c * per_c; s_patch[pcell(c, q)] = xs[i]; }
+        if (e < total1) { const int c = e / per_c, q = e - c * per_c; dst[pcell(c, q)] = xs[i]; }
       }
     }
   };
@@ -968,54 +969,81 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
   const float* ap = s_w + (ct0 * 16 + x) * WS + kq * KQ;
   float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  issue(img0);
-  for (int img = img0; img < img_end; ++img) {
-    if (img == img0 || img == a.n_on) {               // block-uniform: the slab (row-major, WS apart) and the bias terms of this net
-      const int net = img < a.n_on ? 0 : 1;           // (every wave is past the previous image's MFMA loop: the barrier below)
-      const int rows_valid_w = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
-      for (int e = t; e < 32 * (KMAX / 4); e += THREADS) {
-        const int m = e / (KMAX / 4), q = e - m * (KMAX / 4);
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (m < rows_valid_w) v = rb_ld4(a.w[net] + (int64_t)(cout0 + m) * KMAX + 4 * q);
-        rb_st4(s_w + m * WS + 4 * q, v);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = cout0 + ct0 * 16 + 4 * kq + r;
-        bias4[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
-      }
+  auto stage_slab = [&](int img) {                    // the slab (row-major, WS apart) and the bias terms of image img's net
+    const int net = img < a.n_on ? 0 : 1;
+    const int rows_valid_w = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
+    for (int e = t; e < 32 * (KMAX / 4); e += THREADS) {
+      const int m = e / (KMAX / 4), q = e - m * (KMAX / 4);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (m < rows_valid_w) v = rb_ld4(a.w[net] + (int64_t)(cout0 + m) * KMAX + 4 * q);
+      rb_st4(s_w + m * WS + 4 * q, v);
     }
-    commit();
-    __syncthreads();                                  // patch (and slab) complete
-    if (img + 1 < img_end) issue(img + 1);
-    if (tile_wave) {                                  // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
-      rb_f32x4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 4; ++r) {
+      const int m = cout0 + ct0 * 16 + 4 * kq + r;
+      bias4[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+    }
+  };
+  auto tile = [&](int img, const float* bpi) {        // this wave's tile of image img from the patch bpi points into: MFMAs + epilogue
+    rb_f32x4 acc;
 #pragma unroll
-      for (int jq = 0; jq < KQ / 4; ++jq) {
-        const float4 w4 = rb_ld4(ap + 4 * jq);
-        const float b0 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], b1 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)];
-        const float b2 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], b3 = bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)];
-        acc = rb_mfma16(w4.x, b0, acc);
-        acc = rb_mfma16(w4.y, b1, acc);
-        acc = rb_mfma16(w4.z, b2, acc);
-        acc = rb_mfma16(w4.w, b3, acc);
-      }
+    for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {                   // D[r]: channel 4 kq + r of the tile, position x
-        const int m = cout0 + ct0 * 16 + 4 * kq + r;
-        if (pv && m < a.cout) {
-          const float o = fmaxf(acc[r] + bias4[r], 0.0f);
-          a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
-          if (a.out_blocked) {
-            const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
-            a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
-          }
+    for (int jq = 0; jq < KQ / 4; ++jq) {
+      const float4 w4 = rb_ld4(ap + 4 * jq);
+      const float b0 = bpi[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], b1 = bpi[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)];
+      const float b2 = bpi[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], b3 = bpi[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)];
+      acc = rb_mfma16(w4.x, b0, acc);
+      acc = rb_mfma16(w4.y, b1, acc);
+      acc = rb_mfma16(w4.z, b2, acc);
+      acc = rb_mfma16(w4.w, b3, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                     // D[r]: channel 4 kq + r of the tile, position x
+      const int m = cout0 + ct0 * 16 + 4 * kq + r;
+      if (pv && m < a.cout) {
+        const float o = fmaxf(acc[r] + bias4[r], 0.0f);
+        a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+        if (a.out_blocked) {
+          const int k = m * G::P + p;                                   // x.view(-1, conv_output_size), model.py:71
+          a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
         }
       }
     }
-    __syncthreads();                                  // every wave is done reading this image's patch (and, at a net change, the slab)
+  };
+
+  issue(img0);
+  if constexpr (DB) {
+    // TWO patch buffers (they fit beside the slab: the third canonical layer): image i + 1's patch is written to the other buffer
+    // at the START of iteration i — its LDS stores overlap the first MFMAs of image i — and image i + 2's loads are requested right
+    // behind it; ONE barrier per image (patch i + 1 complete, patch i free).
+    stage_slab(img0);
+    commit(s_patch);
+    __syncthreads();
+    if (img0 + 1 < img_end) issue(img0 + 1);
+    int cur = 0;
+    for (int img = img0; img < img_end; ++img) {
+      if (img != img0 && img == a.n_on) {             // block-uniform: the net changes inside this group (every wave is past the barrier)
+        stage_slab(img);
+        __syncthreads();
+      }
+      if (img + 1 < img_end) {
+        commit(s_patch + (cur ^ 1) * (CMAX * PLANE));
+        if (img + 2 < img_end) issue(img + 2);
+      }
+      if (tile_wave) tile(img, bp + cur * (CMAX * PLANE));
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    for (int img = img0; img < img_end; ++img) {
+      if (img == img0 || img == a.n_on) stage_slab(img);   // block-uniform (every wave is past the previous image's MFMA loop: the barrier below)
+      commit(s_patch);
+      __syncthreads();                                // patch (and slab) complete
+      if (img + 1 < img_end) issue(img + 1);
+      if (tile_wave) tile(img, bp);                   // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
+      __syncthreads();                                // every wave is done reading this image's patch (and, at a net change, the slab)
+    }
   }
 }
 
