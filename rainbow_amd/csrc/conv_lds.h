@@ -920,11 +920,10 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
   unsigned xd[XD];
   float4 xv[XV];
   float xs[XS];
-  // FIRST, zero-copy frames: the window-table entries gate the frame addresses — two DEPENDENT round trips.  They are requested
-  // one image further ahead than the frames (lookup(i + 2) behind issue(i + 1)), so that issue() never waits inside the loop
-  int32_t widx[XD];
-  auto lookup = [&](int img) {
+  auto issue = [&](int img) {
     if constexpr (FIRST) {
+      // (the window-table entries of a thread's dwords first — they gate the frame addresses —, then the frame loads)
+      int32_t widx[XD];
 #pragma unroll
       for (int i = 0; i < XD; ++i) {
         const int e = i * THREADS + t;
@@ -935,10 +934,6 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
           widx[i] = a.src.win[(int64_t)sample * a.src.win_len + (img < a.src.B ? c : a.src.n_step + c)];
         }
       }
-    }
-  };
-  auto issue = [&](int img) {
-    if constexpr (FIRST) {
 #pragma unroll
       for (int i = 0; i < XD; ++i) {
         const int e = i * THREADS + t;
@@ -1071,9 +1066,7 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
     }
   };
 
-  lookup(img0);
   issue(img0);
-  if (img0 + 1 < img_end) lookup(img0 + 1);
   if constexpr (DB) {
     // TWO patch buffers (they fit beside the slab: the third canonical layer): image i + 1's patch is written to the other buffer
     // at the START of iteration i — its LDS stores overlap the first MFMAs of image i — and image i + 2's loads are requested right
@@ -1101,10 +1094,7 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
       if (img == img0 || img == a.n_on) stage_slab(img);   // block-uniform (every wave is past the previous image's MFMA loop: the barrier below)
       commit(s_patch);
       __syncthreads();                                // patch (and slab) complete
-      if (img + 1 < img_end) {
-        issue(img + 1);
-        if (img + 2 < img_end) lookup(img + 2);
-      }
+      if (img + 1 < img_end) issue(img + 1);
       if (tile_wave) tile(img, bp);                   // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
       __syncthreads();                                // every wave is done reading this image's patch (and, at a net change, the slab)
     }
