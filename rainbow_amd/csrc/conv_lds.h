@@ -875,22 +875,17 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_multi(ConvLdsFwdAr
 // patch is in flight (registers) under this image's MFMA loop.  Same LDS image as the one-image t16 kernel (117 / 95 KB for the
 // canonical layers 2 / 3).  Needs cin * KK == KMAX, cin % 4 == 0, KMAX % 16 == 0, cout % 32 == 0 (host-checked).
 // grid = (position chunks, cout / 32, image groups) or image-group-fastest (a.img_fast); block = 64 * NWV.
-// FIRST (the first layer on u8 frames, stride-4 geometry): the patch comes as DWORDS of the frames — through the sampler's window
-// table in zero-copy mode — and is decoded to exact x / 255 on the way into LDS, as in rb_conv_fwd_body; a workgroup owns a chunk
-// of PCH positions of its images and TWO workgroups share a CU (60 KB each): their phases are not in lockstep, one stages while
-// the other multiplies.  (k_conv_fwd_full, which this replaces at batch >= 256, keeps one LDS-filling workgroup per CU in
-// lockstep: MFMA-busy 0.54, LDS bank conflicts on 66 % of its LDS cycles.)
-template <class G, int NT, int PR, int KMAX, int PCH = 32 * NT, bool FIRST = false>
-__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, 1>::NWV))
+template <class G, int NT, int PR, int KMAX, int PCH = 32 * NT>
+__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1>::NWV))
 void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
   typedef ConvFwdLdsSize<G, NT, PR, KMAX, 1> SZ;
-  typedef ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, 1> WV;
+  typedef ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1> WV;
   constexpr int NWV = WV::NWV, THREADS = 64 * NWV, TILE_WAVES = WV::TILE_WAVES;
   constexpr int WS = SZ::WS, PLANE = SZ::PLANE, SUB = SZ::SUB, RP = SZ::RP, CMAX = KMAX / G::KK;
   constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4;
   static_assert(KMAX % 16 == 0 && CMAX % 4 == 0, "t16: whole float4s per k-slot");
   static_assert(SZ::KPAD == KMAX, "the slab has no padded columns");
-  constexpr bool DB = !FIRST && (32 * WS + 2 * CMAX * PLANE) * 4 <= 150 * 1024;      // room for a second patch buffer (FIRST: a second WORKGROUP instead)
+  constexpr bool DB = (32 * WS + 2 * CMAX * PLANE) * 4 <= 150 * 1024;      // room for a second patch buffer
   __shared__ __attribute__((aligned(16))) float smem[SZ::FLOATS + (DB ? CMAX * PLANE : 0)];
   float* s_w = smem;
   float* s_patch = smem + 32 * WS;
@@ -909,50 +904,14 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
     const int r = off / G::IH, x = off - r * G::IH;
     return c * PLANE + r * RP + (x % G::S) * SUB + x / G::S;
   };
-  // ---- the patch of one image: loads into registers (issue), de-interleaved LDS stores later (commit): rb_conv_fwd_body's paths
-  static_assert(!FIRST || (G::S == 4 && (G::IH % 4) == 0), "first layer: the dword path of the stride-4 frame geometry");
-  constexpr bool x_vec = !FIRST && (G::IH % 4) == 0;
-  constexpr int XD = FIRST ? (CMAX * PR * G::IH / 4 + THREADS - 1) / THREADS : 1;
+  // ---- the patch of one image: loads into registers (issue), de-interleaved LDS stores later (commit): rb_conv_fwd_body's f32 paths
+  constexpr bool x_vec = (G::IH % 4) == 0;
   constexpr int XV = x_vec ? (CMAX * PR * G::IH / 4 + THREADS - 1) / THREADS : 1;
-  constexpr int XS = (FIRST || x_vec) ? 1 : (CMAX * PR * G::IH + THREADS - 1) / THREADS;
+  constexpr int XS = x_vec ? 1 : (CMAX * PR * G::IH + THREADS - 1) / THREADS;
   const int v4 = per_c >> 2, total4 = cin * v4, total1 = cin * per_c;
-  const int dpc = per_c >> 2, total_dw = cin * dpc;   // FIRST: dwords per channel of the patch
-  unsigned xd[XD];
   float4 xv[XV];
   float xs[XS];
   auto issue = [&](int img) {
-    if constexpr (FIRST) {
-      // (the window-table entries of a thread's dwords first — they gate the frame addresses —, then the frame loads)
-      int32_t widx[XD];
-#pragma unroll
-      for (int i = 0; i < XD; ++i) {
-        const int e = i * THREADS + t;
-        const int c = e / dpc;
-        widx[i] = -1;
-        if (e < total_dw && a.src.ring) {
-          const int sample = img < a.src.B ? img : (img - a.src.B) % a.src.B;
-          widx[i] = a.src.win[(int64_t)sample * a.src.win_len + (img < a.src.B ? c : a.src.n_step + c)];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < XD; ++i) {
-        const int e = i * THREADS + t;
-        const int c = e / dpc;
-        xd[i] = 0u;
-        if (e < total_dw) {
-          const uint8_t* fp;
-          bool ok;
-          if (a.src.ring) { ok = widx[i] >= 0; fp = a.src.ring + (int64_t)(widx[i] < 0 ? 0 : widx[i]) * G::IP; }
-          else {
-            ok = true;
-            fp = img < a.src.B ? a.src.u8_states + ((int64_t)img * cin + c) * G::IP
-                               : a.src.u8_next + ((int64_t)((img - a.src.B) % a.src.B) * cin + c) * G::IP;
-          }
-          if (ok) xd[i] = rb_ldg_u32(fp + iy0 * G::IH + 4 * (e - c * dpc));
-        }
-      }
-      return;
-    }
     const float* xbase = a.in_f + (int64_t)img * cin * G::IP;
     if constexpr (x_vec) {
 #pragma unroll
@@ -973,20 +932,7 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
     }
   };
   auto commit = [&](float* dst) {
-    if constexpr (FIRST) {
-      constexpr int DPR = G::IH / 4;                       // dwords per input row
-#pragma unroll
-      for (int i = 0; i < XD; ++i) {
-        const int e = i * THREADS + t;
-        if (e < total_dw) {
-          const int c = e / dpc, d = e - c * dpc;
-          const int r = d / DPR, xi = d - r * DPR;        // bytes 4 xi .. 4 xi + 3 of row r: phases 0..3 of de-interleaved index xi
-          float* cell = dst + c * PLANE + r * RP + xi;
-#pragma unroll
-          for (int b = 0; b < 4; ++b) cell[b * SUB] = rb_unit((uint8_t)((xd[i] >> (8 * b)) & 0xFFu));
-        }
-      }
-    } else if constexpr (x_vec) {
+    if constexpr (x_vec) {
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int e = i * THREADS + t;

@@ -925,23 +925,6 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
     const int per_img = (int)(rb_div_up(G::P, PCH) * rb_div_up(c.cout, 32));
     ipb = (int)rb_div_up((int64_t)(n_on + n_tg) * per_img, 256);
   }
-  if constexpr (FIRST && G::S == 4 && (G::IH % 4) == 0 && KMAX % 16 == 0 && (KMAX / G::KK) % 4 == 0 && 2 * ((PCH + 15) / 16) <= 16 &&
-                (PCH % 16 == 0 || PCH >= G::P) && G::P > 16) {
-    // first layer at large batches on whole-K 16x16x4 tiles too (conv_lds.h k_conv_fwd_multi_t16<..., FIRST>): position chunks of
-    // PCH, two workgroups per CU, each walking ~1/512 of the (image, chunk) units (RB_OPTS conv_multi_t16=0: k_conv_fwd_full)
-    if (ipb > 0 && l->opt_conv_multi_t16 && (l->opt_t16 & 1) && !src.f32 && c.cout == 32 && !a.out_blocked && c.cin * G::KK == KMAX &&
-        (src.ring || src.u8_states)) {
-      const int chunks = (int)rb_div_up(G::P, PCH);
-      int fi = multi_forced ? ipb : (int)rb_div_up((int64_t)(n_on + n_tg) * chunks, 512);
-      if (fi < 1) fi = 1;
-      a.ipb = fi;
-      constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, true, PCH, false, 1>::NWV;
-      RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi_t16<G, NT, PR, KMAX, PCH, true>), dim3((unsigned)chunks, 1, (unsigned)rb_div_up(n_on + n_tg, fi)),
-                  dim3(64 * NWV), stream, a);
-      RB_LAUNCH_CHECK();
-      return RB_OK;
-    }
-  }
   if constexpr (FIRST && ConvFwdFullLds<G, KMAX>::FITS) {
     // first layer: whole image per workgroup, whole reduction per wave (RB_CONV_FULL=0: the chunked kernel below)
     const bool full_off = !l->opt_conv_full;
