@@ -1019,7 +1019,7 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
     // behind it; ONE barrier per image (patch i + 1 complete, patch i free).
     stage_slab(img0);
     commit(s_patch);
-    __syncthreads();
+    __syncthreads();                                  // (the slab's stores and the first patch: once)
     if (img0 + 1 < img_end) issue(img0 + 1);
     int cur = 0;
     for (int img = img0; img < img_end; ++img) {
@@ -1032,17 +1032,18 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
         if (img + 2 < img_end) issue(img + 2);
       }
       if (tile_wave) tile(img, bp + cur * (CMAX * PLANE));
-      __syncthreads();
+      rb_lds_barrier();                               // LDS only: the epilogue's global stores and the prefetch stay in flight
       cur ^= 1;
     }
   } else {
     for (int img = img0; img < img_end; ++img) {
       if (img == img0 || img == a.n_on) stage_slab(img);   // block-uniform (every wave is past the previous image's MFMA loop: the barrier below)
       commit(s_patch);
-      __syncthreads();                                // patch (and slab) complete
+      rb_lds_barrier();                               // patch (and slab) complete — LDS only: the next image's prefetch stays in flight
       if (img + 1 < img_end) issue(img + 1);
       if (tile_wave) tile(img, bp);                   // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
-      __syncthreads();                                // every wave is done reading this image's patch (and, at a net change, the slab)
+      rb_lds_barrier();                               // every wave is done reading this image's patch (and, at a net change, the slab);
+                                                      // the epilogue's global stores are NOT waited for
     }
   }
 }
