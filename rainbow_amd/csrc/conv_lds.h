@@ -875,27 +875,24 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_multi(ConvLdsFwdAr
 // patch is in flight (registers) under this image's MFMA loop.  Same LDS image as the one-image t16 kernel (117 / 95 KB for the
 // canonical layers 2 / 3).  Needs cin * KK == KMAX, cin % 4 == 0, KMAX % 16 == 0, cout % 32 == 0 (host-checked).
 // grid = (position chunks, cout / 32, image groups) or image-group-fastest (a.img_fast); block = 64 * NWV.
-// CT = 16-channel tiles per workgroup (2: the 32-channel slab of the one-image kernel; 1: a 16-channel slab — half the LDS, so that TWO
-// workgroups share a CU where the patch is small (the third canonical layer): they are not in lockstep, one stages / stores while the
-// other multiplies).  grid.y = cout / (16 CT).
-template <class G, int NT, int PR, int KMAX, int PCH = 32 * NT, int CT = 2>
-__global__ __launch_bounds__((64 * ((CT * ((PCH + 15) / 16) + 3) / 4 * 4)))
+template <class G, int NT, int PR, int KMAX, int PCH = 32 * NT>
+__global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1>::NWV))
 void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
   typedef ConvFwdLdsSize<G, NT, PR, KMAX, 1> SZ;
-  constexpr int ROWS = 16 * CT;                          // channels of the slab
-  constexpr int TILE_WAVES = CT * ((PCH + 15) / 16), NWV = (TILE_WAVES + 3) / 4 * 4, THREADS = 64 * NWV;
+  typedef ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1> WV;
+  constexpr int NWV = WV::NWV, THREADS = 64 * NWV, TILE_WAVES = WV::TILE_WAVES;
   constexpr int WS = SZ::WS, PLANE = SZ::PLANE, SUB = SZ::SUB, RP = SZ::RP, CMAX = KMAX / G::KK;
   constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4;
   static_assert(KMAX % 16 == 0 && CMAX % 4 == 0, "t16: whole float4s per k-slot");
   static_assert(SZ::KPAD == KMAX, "the slab has no padded columns");
-  constexpr bool DB = CT == 2 && (32 * WS + 2 * CMAX * PLANE) * 4 <= 150 * 1024;      // room for a second patch buffer (CT == 1: a second WORKGROUP)
-  __shared__ __attribute__((aligned(16))) float smem[ROWS * WS + CMAX * PLANE * (DB ? 2 : 1)];
+  constexpr bool DB = (32 * WS + 2 * CMAX * PLANE) * 4 <= 150 * 1024;      // room for a second patch buffer
+  __shared__ __attribute__((aligned(16))) float smem[SZ::FLOATS + (DB ? CMAX * PLANE : 0)];
   float* s_w = smem;
-  float* s_patch = smem + ROWS * WS;
+  float* s_patch = smem + 32 * WS;
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int img0 = (a.img_fast ? (int)blockIdx.x : (int)blockIdx.z) * a.ipb;
   const int img_end = img0 + a.ipb < a.rows_total ? img0 + a.ipb : a.rows_total;
-  const int cout0 = (int)blockIdx.y * ROWS;
+  const int cout0 = (int)blockIdx.y * 32;
   const int p0 = (a.img_fast ? (int)blockIdx.z : (int)blockIdx.x) * PCH;
   const int cin = a.cin;                              // == CMAX
   const int oy0 = p0 / G::OH;
@@ -963,7 +960,7 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
   };
   // ---- this wave's tile (rb_conv_fwd_body, T16 section): position tile pt, channel tile ct0; lane (x, kq)
   const bool tile_wave = wave < TILE_WAVES;
-  const int pt = wave % PT, ct0 = (wave / PT) % CT;
+  const int pt = wave % PT, ct0 = (wave / PT) % 2;
   const int x = lane & 15, kq = lane >> 4;
   int p = p0 + pt * 16 + x;
   const bool pv = p < G::P && p < p0 + PCH;
@@ -974,8 +971,8 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
 
   auto stage_slab = [&](int img) {                    // the slab (row-major, WS apart) and the bias terms of image img's net
     const int net = img < a.n_on ? 0 : 1;
-    const int rows_valid_w = a.cout - cout0 < ROWS ? a.cout - cout0 : ROWS;
-    for (int e = t; e < ROWS * (KMAX / 4); e += THREADS) {
+    const int rows_valid_w = a.cout - cout0 < 32 ? a.cout - cout0 : 32;
+    for (int e = t; e < 32 * (KMAX / 4); e += THREADS) {
       const int m = e / (KMAX / 4), q = e - m * (KMAX / 4);
       float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (m < rows_valid_w) v = rb_ld4(a.w[net] + (int64_t)(cout0 + m) * KMAX + 4 * q);

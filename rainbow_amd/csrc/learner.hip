@@ -950,21 +950,6 @@ static int launch_conv_fwd_lds(rb_learner* l, int layer, int n_on, int n_tg, con
       if constexpr (KMAX % 16 == 0 && (KMAX / G::KK) % 4 == 0 && 2 * ((PCH + 15) / 16) <= 16 && (PCH % 16 == 0 || PCH >= G::P) && G::P > 16) {
         // whole-K 16x16x4 tiles in the image loop as well (conv_lds.h k_conv_fwd_multi_t16; RB_OPTS conv_multi_t16=0: the split-K body)
         if (l->opt_conv_multi_t16 && ((l->opt_t16 >> layer) & 1) && c.cin * G::KK == KMAX && c.cout % 32 == 0) {
-          // 16-channel slabs (two workgroups per CU, out of lockstep) where slab + patch stay under 80 KB: the third canonical layer
-          constexpr bool HALF = (16 * ConvFwdLdsSize<G, NT, PR, KMAX, 1>::WS + (KMAX / G::KK) * ConvFwdLdsSize<G, NT, PR, KMAX, 1>::PLANE) * 4 <= 79 * 1024;
-          if (HALF && l->opt_conv_multi_t16 != 2) {
-            constexpr int NWV1 = (((PCH + 15) / 16) + 3) / 4 * 4;
-            const unsigned chunks = (unsigned)rb_div_up(G::P, PCH), slabs = (unsigned)rb_div_up(c.cout, 16);
-            int hi = multi_forced ? ipb : (int)rb_div_up((int64_t)(n_on + n_tg) * chunks * slabs, 512);     // one round at two per CU
-            if (hi < 1) hi = 1;
-            a.ipb = hi;
-            const unsigned ng = (unsigned)rb_div_up(n_on + n_tg, hi);
-            a.img_fast = (l->opt_img_fast && ng % 8 == 0) ? 1 : 0;
-            const dim3 gh = a.img_fast ? dim3(ng, slabs, chunks) : dim3(chunks, slabs, ng);
-            RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi_t16<G, NT, PR, KMAX, PCH, 1>), gh, dim3(64 * NWV1), stream, a);
-            RB_LAUNCH_CHECK();
-            return RB_OK;
-          }
           constexpr int NWV = ConvFwdWaves<G, NT, PR, KMAX, false, PCH, false, 1>::NWV;
           RB_LAUNCH_T(tags[layer], (k_conv_fwd_multi_t16<G, NT, PR, KMAX, PCH>), gridm, dim3(64 * NWV), stream, a);
           RB_LAUNCH_CHECK();
