@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 #if defined(RB_STAMP) && defined(RB_STAMP_FINE)
   RB_WGT(WK + 3, wgi, 3);
 #endif
-  if (PW > G::OH) __syncthreads();                    // the zero fill (other threads' cells) precedes the interior stores
+  if (PW > G::OH) RB_LDS_SYNC();                    // the zero fill (other threads' cells) precedes the interior stores
   for (int ii = 0; ii < ipb; ++ii) {
     const int img = img0 + ii;
     if (MULTI && img >= a.batch) break;               // block-uniform
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
     float mask[EIT];
 #pragma unroll
     for (int it = 0; it < EIT; ++it) mask[it] = xa[eoff[it] >= 0 ? eoff[it] : 0];
-    __syncthreads();            // operands complete (and, MULTI, the previous image's reduction scratch has been consumed)
+    RB_LDS_SYNC();            // operands complete (and, MULTI, the previous image's reduction scratch has been consumed)
     if (ii == 0) { RB_WGT(WK, wgi, 1); RB_WGT(WK, wgi, 2); RB_WGT(WK, wgi, 3); }
     if (MULTI && ii + 1 < ipb && img + 1 < a.batch) issue(img + 1);
     if (ii == 0) {
@@ -1482,12 +1482,12 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_dy[kos[j] + noff[nt]], acc[nt]);
     }
     if (ii == 0) RB_WGT(WK, wgi, 4);
-    if (!MULTI) __syncthreads();                      // the scratch overlays the operands
+    if (!MULTI) RB_LDS_SYNC();                      // the scratch overlays the operands
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_red[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
-    __syncthreads();                                  // (MULTI: every wave is also done reading this image's dY)
+    RB_LDS_SYNC();                                  // (MULTI: every wave is also done reading this image's dY)
     float* dxi = a.dx + (int64_t)img * a.cin * G::IP;
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {

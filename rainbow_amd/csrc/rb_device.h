@@ -324,6 +324,15 @@ __device__ __forceinline__ void rb_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
+// (RB_LDSBAR=0: variant builds for A/B runs put __syncthreads() back where a kernel uses RB_LDS_SYNC)
+#ifndef RB_LDSBAR
+#define RB_LDSBAR 1
+#endif
+#if RB_LDSBAR
+#define RB_LDS_SYNC() rb_lds_barrier()
+#else
+#define RB_LDS_SYNC() __syncthreads()
+#endif
 __device__ __forceinline__ void rb_wave_sync() {
 #if defined(RB_HOST_INTERP)
   hipemu::wave_barrier();
