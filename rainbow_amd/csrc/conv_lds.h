@@ -1032,18 +1032,17 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
         if (img + 2 < img_end) issue(img + 2);
       }
       if (tile_wave) tile(img, bp + cur * (CMAX * PLANE));
-      rb_lds_barrier();                               // LDS only: the epilogue's global stores and the prefetch stay in flight
+      __syncthreads();
       cur ^= 1;
     }
   } else {
     for (int img = img0; img < img_end; ++img) {
       if (img == img0 || img == a.n_on) stage_slab(img);   // block-uniform (every wave is past the previous image's MFMA loop: the barrier below)
       commit(s_patch);
-      rb_lds_barrier();                               // patch (and slab) complete — LDS only: the next image's prefetch stays in flight
+      __syncthreads();                                // patch (and slab) complete
       if (img + 1 < img_end) issue(img + 1);
       if (tile_wave) tile(img, bp);                   // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
-      rb_lds_barrier();                               // every wave is done reading this image's patch (and, at a net change, the slab);
-                                                      // the epilogue's global stores are NOT waited for
+      __syncthreads();                                // every wave is done reading this image's patch (and, at a net change, the slab)
     }
   }
 }
@@ -1449,7 +1448,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
 #if defined(RB_STAMP) && defined(RB_STAMP_FINE)
   RB_WGT(WK + 3, wgi, 3);
 #endif
-  if (PW > G::OH) RB_LDS_SYNC();                    // the zero fill (other threads' cells) precedes the interior stores
+  if (PW > G::OH) __syncthreads();                    // the zero fill (other threads' cells) precedes the interior stores
   for (int ii = 0; ii < ipb; ++ii) {
     const int img = img0 + ii;
     if (MULTI && img >= a.batch) break;               // block-uniform
@@ -1463,7 +1462,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
     float mask[EIT];
 #pragma unroll
     for (int it = 0; it < EIT; ++it) mask[it] = xa[eoff[it] >= 0 ? eoff[it] : 0];
-    RB_LDS_SYNC();            // operands complete (and, MULTI, the previous image's reduction scratch has been consumed)
+    __syncthreads();            // operands complete (and, MULTI, the previous image's reduction scratch has been consumed)
     if (ii == 0) { RB_WGT(WK, wgi, 1); RB_WGT(WK, wgi, 2); RB_WGT(WK, wgi, 3); }
     if (MULTI && ii + 1 < ipb && img + 1 < a.batch) issue(img + 1);
     if (ii == 0) {
@@ -1482,12 +1481,12 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
       for (int nt = 0; nt < NT; ++nt) acc[nt] = rb_mfma32(av, s_dy[kos[j] + noff[nt]], acc[nt]);
     }
     if (ii == 0) RB_WGT(WK, wgi, 4);
-    if (!MULTI) RB_LDS_SYNC();                      // the scratch overlays the operands
+    if (!MULTI) __syncthreads();                      // the scratch overlays the operands
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_red[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
-    RB_LDS_SYNC();                                  // (MULTI: every wave is also done reading this image's dY)
+    __syncthreads();                                  // (MULTI: every wave is also done reading this image's dY)
     float* dxi = a.dx + (int64_t)img * a.cin * G::IP;
 #pragma unroll
     for (int it = 0; it < EIT; ++it) {

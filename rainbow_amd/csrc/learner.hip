@@ -509,7 +509,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   for (int z = t; z < Z; z += T) s_sup[z] = support[z];  // requested with the logits: one memory round trip, not two
   const float R = returns[b], nt = nonterminals[b], wgt = weights[b];
   const int act = (int)actions[b];
-  RB_LDS_SYNC();
+  __syncthreads();
   RB_WGT(7, b, 1);
   HeadWave<ZI> hw;
   hw.lane = lane;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
       }
     }
   }
-  RB_LDS_SYNC();
+  __syncthreads();
   RB_WGT(7, b, 2);
   int a_star = 0;
   {
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     s_hi[z] = p * (bq - (float)l);                            // agent.py:92
     s_m[z] = 0.0f;
   }
-  RB_LDS_SYNC();
+  __syncthreads();
   RB_WGT(7, b, 3);
   // ---------------- scatter into atom bins in the reference's accumulation order   agent.py:89-92
   // b is monotone in the atom index (support increasing, nt*gamma^n >= 0), so equal l (and equal u) form
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
         s_m[key] = acc;
       }
     }
-    RB_LDS_SYNC();
+    __syncthreads();
     for (int j = t; j < Z; j += T) {
       const int key = s_u[j];
       if (j == 0 || s_u[j - 1] != key) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
       }
     }
   }
-  RB_LDS_SYNC();
+  __syncthreads();
   RB_WGT(7, b, 4);
   for (int k = t; k < Z; k += T) m_out[(int64_t)b * Z + k] = s_m[k];
   if (wave == 0) {                                                // loss = -sum m * log p   agent.py:94
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
     pm = rb_wave_sum(pm);
     if (lane == 0) { s_scal[0] = pm; s_scal[1] = pl; loss_out[b] = -pl; }
   }
-  RB_LDS_SYNC();
+  __syncthreads();
   // ---------------- backward of mean(w * loss) to the logits     agent.py:96
   // d/dq[z] = (w/B) * (p[z] * sum(m) - m[z]) on the taken action; dueling adjoint:
   // dv[z] = g[z] ; da[a'][z] = (delta(a',act) - 1/A) * g[z]

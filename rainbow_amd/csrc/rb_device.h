@@ -312,27 +312,6 @@ __device__ __forceinline__ int rb_wave_uniform(int v) {
 // Ordering point for LDS traffic that stays inside one wave (a lane reads what another lane of the SAME wave wrote):
 // the hardware executes a wave's LDS operations in order, so no s_barrier is needed — this only pins the compiler's
 // (and the host interpreter's) ordering.
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0)` + `s_barrier`: on gfx9 vmcnt counts
-// global STORES as well as loads, so a barrier behind an epilogue's global stores (or in front of a prefetch that is meant to stay in
-// flight) stalls every wave for a memory round trip.  Where the barrier only orders LDS traffic — "the tile is complete" / "the tile
-// is free" — the LDS counter is all that has to drain.  NOT a substitute where a later access depends on a global store or load
-// of another wave.
-__device__ __forceinline__ void rb_lds_barrier() {
-#if defined(RB_HOST_INTERP)
-  __syncthreads();
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-// (RB_LDSBAR=0: variant builds for A/B runs put __syncthreads() back where a kernel uses RB_LDS_SYNC)
-#ifndef RB_LDSBAR
-#define RB_LDSBAR 1
-#endif
-#if RB_LDSBAR
-#define RB_LDS_SYNC() rb_lds_barrier()
-#else
-#define RB_LDS_SYNC() __syncthreads()
-#endif
 __device__ __forceinline__ void rb_wave_sync() {
 #if defined(RB_HOST_INTERP)
   hipemu::wave_barrier();
