@@ -167,7 +167,7 @@ def step_work(cfg, n_params):
 
 
 # rocprofv3's own mean duration of the launch behind a profiling tag, from the committed kernel-stats summary of the same
-# config (profiles/round*_final_cfg<N>_kernel_stats.csv, tools/gpu_evidence.sh): a bracket can read SHORTER than the launch
+# config (profiles/round*_final_cfg<N>_kernel_stats.csv, tools/gpu_r6_evidence.sh): a bracket can read SHORTER than the launch
 # takes back to back in the step (the event in front of it absorbs part of what the launch pays in situ: k_conv_dw_all at
 # batch 256 read 38 us between two events and 64 us in the kernel trace), so every roofline object carries both and prices
 # `frac` with the larger.  Tags whose kernel name is shared with another launch of the step (k_nl_fwd3: hidden and output layer)
@@ -497,7 +497,7 @@ def main():
                                "binding": "latency: one batch in flight = 2 dependent launches (update of batch k + draw of batch k + 1 "
                                           "as one single-workgroup chain, then the frame gather); up to 64 leaves per write-back, "
                                           "else 3 launches; bytes are 0.1% of what HBM moves in that time"}
-        # counter traffic: only from a PMC pass of THIS config that is committed under profiles/ (tools/gpu_pmc.sh);
+        # counter traffic: only from a PMC pass of THIS config that is committed under profiles/ (tools/gpu_r6_evidence.sh);
         # null otherwise — never a number measured on another workload
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_%s.json" % opt.config)))   # newest round last
