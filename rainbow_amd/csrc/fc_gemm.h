@@ -515,6 +515,160 @@ __device__ __forceinline__ void rb_fc_gemm_dw(const NlDwArgs& a, int ntile, int 
   }
 }
 
+// ---- the same weight gradient for the REPLICA EXCHANGE (rb_learner_finish_grads): the reduction rows are the gathered
+// factor blocks of M / rpb ranks (noisy_linear.h NlDwArgs: rpb, bstride, noise_blocks), and every rank's gradient is noisy with ITS
+// OWN epsilon:  g_mu = (1 / world) sum_r acc_r,  g_sigma = (1 / world) sum_r acc_r * (eps_out_r[n] * eps_in_r[k]),  acc_r = dY_r^T X_r.
+// rb_nl_dw_body_ranks does this one 16 x 64 tile per wave: at config 5's size (M = 8 x 32 rows, [1024 x 3136] weights) every
+// 16-row tile re-reads all of X — 0.5 GB of L2 traffic, 58 us per launch (profiles/round6_experiments.txt).  Here a workgroup owns
+// a 128 x 128 tile: a rank's 32-row slab of dY and X goes through double-buffered LDS once (both MC), 8 waves multiply it with
+// 32x32x2 MFMAs, and at the END of each rank's slabs the wave folds its accumulators into the running g_mu / g_sigma with that rank's
+// noise (rank order, the same (eo * ei) product as the one-device bodies).  One barrier per slab, the next slab's global loads in
+// flight under the MFMAs.  Every replica runs the same code on the same gathered blocks: identical bits on every replica.
+// The bias gradients (column sums of dY per rank) are formed by the first column tile's workgroup in a loop of its own.
+__device__ __forceinline__ void rb_fc_gemm_dw_ranks(const NlDwArgs& a, int ntile, int ktile, int slot_base, float* lds) {
+  const int lane = rb_lane(), wave = rb_wave(), tid = (int)threadIdx.x;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int K = a.K;
+  const int N = a.prob[a.n_prob - 1].row_begin + a.prob[a.n_prob - 1].row_cnt;
+  const int nt = ntile * RB_TG_T, kt = ktile * RB_TG_T;
+  const int x_off = a.prob[0].x_off;
+  const int rpb = a.rpb, nranks = a.M / a.rpb;
+  const int spr = (rpb + RB_TG_KS - 1) / RB_TG_KS;          // slabs per rank
+  const int total = nranks * spr;
+  const int c32 = tid & 31, mm0 = tid >> 5;
+  int ncol4 = nt + 4 * c32, kcol4 = kt + 4 * c32;
+  const bool nv = ncol4 < N, kv = kcol4 < K;               // (N and K are multiples of 4: all in or all out)
+  if (!nv) ncol4 = N - 4;
+  if (!kv) kcol4 = K - 4;
+  const int p1 = a.n_prob > 1 ? a.prob[1].row_begin : (1 << 30);
+  const int ein0 = a.prob[0].ein_off, ein1 = a.prob[a.n_prob - 1].ein_off;
+  auto load = [&](FcDwRegs& r, int idx) {
+    const int rk = idx / spr, s = idx - rk * spr;
+    const float* dy = a.dy + (int64_t)rk * a.bstride;
+    const float* x = a.x + (int64_t)rk * a.bstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = s * RB_TG_KS + mm0 + 16 * i;
+      const bool ok = m < rpb;
+      const int mc = ok ? m : rpb - 1;
+      r.y[i] = rb_sel4(ok && nv, rb_ld4(dy + (int64_t)mc * a.ldy + ncol4));
+      r.x[i] = rb_sel4(ok && kv, rb_ld4(x + (int64_t)mc * a.ldx + x_off + kcol4));
+    }
+  };
+  auto store = [&](const FcDwRegs& r, int buf) {
+    float* sa = lds + buf * 2 * RB_TG_OP;
+    float* sb = sa + RB_TG_OP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&sa[(mm0 + 16 * i) * RB_TG_LDM + 4 * c32]) = r.y[i];
+      *reinterpret_cast<float4*>(&sb[(mm0 + 16 * i) * RB_TG_LDM + 4 * c32]) = r.x[i];
+    }
+  };
+  // this lane's cells: rows n(e) = nt + 32 wm + mfma_row(e), columns k(t) = kt + 64 wn + 32 t + (lane & 31)
+  int kcol[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { kcol[t] = kt + 64 * wn + 32 * t + (lane & 31); if (kcol[t] > K - 1) kcol[t] = K - 1; }
+  rb_f32x16 gm[2], gs[2], acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { gm[t][e] = 0.0f; gs[t][e] = 0.0f; acc[t][e] = 0.0f; }
+  FcDwRegs R;
+  load(R, 0);
+  float eo[16], ei[2][2];
+  for (int idx = 0; idx < total; ++idx) {
+    const int rk = idx / spr, s = idx - rk * spr;
+    store(R, idx & 1);
+    __syncthreads();                                        // slab idx is in LDS; its buffer was last read two slabs ago
+    if (idx + 1 < total) load(R, idx + 1);
+    if (s == 0) {                                           // this rank's noise for the fold below: requested with the slab (block-uniform)
+      const float* nz = a.noise_blocks + (int64_t)rk * a.bstride;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = nt + 32 * wm + rb_mfma_row(e, lane);
+        eo[e] = nz[a.eout_noff + (n < N ? n : N - 1)];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { ei[t][0] = nz[a.ein_noff + ein0 + kcol[t]]; ei[t][1] = nz[a.ein_noff + ein1 + kcol[t]]; }
+    }
+    const float* sa = lds + (idx & 1) * 2 * RB_TG_OP;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      TgFrag f;
+      rb_tg_ldfrag<false, false>(sa, sa + RB_TG_OP, g, wm, wn, lane, f);
+      rb_tg_mfma(f, acc);
+    }
+    if (s == spr - 1) {                                     // the rank is complete: fold (rank order), restart the accumulators
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = nt + 32 * wm + rb_mfma_row(e, lane);
+          gm[t][e] = gm[t][e] + acc[t][e];
+          gs[t][e] = gs[t][e] + acc[t][e] * (eo[e] * (n >= p1 ? ei[t][1] : ei[t][0]));
+          acc[t][e] = 0.0f;
+        }
+    }
+  }
+  __syncthreads();                                          // every wave is done with the operand buffers
+  // bias gradients (first column tile only): g_bmu[n] = scale * sum_r colsum_r[n], g_bsigma[n] = scale * sum_r colsum_r[n] * eps_out_r[n]
+  const bool do_bias = ktile == 0 && tid < RB_TG_T && nt + tid < N;
+  float gb = 0.0f, gbs = 0.0f;
+  if (do_bias) {
+    const int n = nt + tid;
+    for (int rk = 0; rk < nranks; ++rk) {
+      const float* dy = a.dy + (int64_t)rk * a.bstride;
+      float cs = 0.0f;
+      for (int m0 = 0; m0 < rpb; m0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = dy[(int64_t)(m0 + u < rpb ? m0 + u : rpb - 1) * a.ldy + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cs += (m0 + u < rpb) ? v[u] : 0.0f;
+      }
+      gb = gb + cs;
+      gbs = gbs + cs * a.noise_blocks[(int64_t)rk * a.bstride + a.eout_noff + n];
+    }
+  }
+  // epilogue: the two finished tiles through LDS, 16-byte row-segment stores, sum of squares of everything this wave wrote
+  float sq = 0.0f;
+  const int rr = tid >> 5;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    rb_f32x16 (&src)[2] = which == 0 ? gm : gs;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) src[t][e] = src[t][e] * a.scale;
+    if (which == 1) __syncthreads();                        // the first tile has been read out of LDS
+    rb_tg_acc_to_lds(src, lds, wm, wn, lane);
+    if (kv) {
+      float* dst = which == 0 ? a.g_mu : a.g_sigma;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = rr + 16 * it;
+        const int n = nt + r;
+        if (n >= N) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&lds[r * RB_TG_LDE + 4 * c32]);
+        rb_st4_wt(dst, (unsigned)(((int64_t)n * K + kcol4) * 4), v);
+        sq = fmaf(v.x, v.x, sq); sq = fmaf(v.y, v.y, sq); sq = fmaf(v.z, v.z, sq); sq = fmaf(v.w, v.w, sq);
+      }
+    }
+  }
+  if (do_bias) {
+    const int n = nt + tid;
+    const float b0 = gb * a.scale, b1 = gbs * a.scale;
+    a.g_bmu[n] = b0;
+    a.g_bsigma[n] = b1;
+    sq = fmaf(b0, b0, sq);
+    sq = fmaf(b1, b1, sq);
+  }
+  if (a.sq_part) {
+    sq = rb_wave_sum(sq);
+    if (lane == 0) a.sq_part[slot_base + wave] = sq;
+  }
+}
+
 #if defined(RB_HOST_INTERP)
 #define RB_TG_TWO_PER_CU
 #else

@@ -163,7 +163,7 @@ struct rb_learner {
   int lazy_splits;
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
-  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_img_fast;
+  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_img_fast, opt_finish_tiled;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   int opt_implicit_small;
@@ -675,6 +675,31 @@ __global__ __launch_bounds__(256) void k_finish_grads(FinishArgs a) {
   b -= a.h_n;
   float acc = 0.0f;
   for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < a.n; i += (int64_t)a.nparts * 256) {
+    float v = 0.0f;
+    for (int r = 0; r < a.world; ++r) v += a.blocks[(int64_t)r * a.bstride + i];
+    v *= a.scale;
+    a.g[i] = v;
+    acc = fmaf(v, v, acc);
+  }
+  acc = rb_block_sum(acc, s_red);
+  if (threadIdx.x == 0) a.part[b] = acc;
+}
+// The same launch with the hidden layer's weight gradient on 128 x 128 LDS tiles (fc_gemm.h rb_fc_gemm_dw_ranks; 512-thread
+// workgroups): block ranges [fc_h tiles | fc_z 16-row tiles (first four waves) | conv range]
+__global__ __launch_bounds__(RB_TG_THREADS) void k_finish_grads_tiled(FinishArgs a, int h_nt, int h_kt) {
+  __shared__ __attribute__((aligned(16))) float lds[RB_TG_LDS];
+  __shared__ float s_red[16];
+  int b = (int)blockIdx.x;
+  const int h_n = h_nt * h_kt;
+  if (b < h_n) { rb_fc_gemm_dw_ranks(a.h, b / h_kt, b % h_kt, 8 * b, lds); return; }
+  b -= h_n;
+  if (b < a.z_n) {
+    if (threadIdx.x < 256) rb_nl_dw_body_ranks(a.z, b % a.z_x, b / a.z_x, 4 * b);     // (a four-wave body without barriers)
+    return;
+  }
+  b -= a.z_n;
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)a.nparts * blockDim.x) {
     float v = 0.0f;
     for (int r = 0; r < a.world; ++r) v += a.blocks[(int64_t)r * a.bstride + i];
     v *= a.scale;
@@ -1391,6 +1416,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->fast_conv = (L.hist <= 4 && generic != 1) ? 1 : 0;
   l->opt_conv_multi = rb_opt("conv_multi", -1);       // images per workgroup of the conv forward (-1: by image count)
   l->opt_conv_multi_t16 = rb_opt("conv_multi_t16", 1);    // the image loop on whole-K 16x16x4 tiles (0: the split-K body)
+  l->opt_finish_tiled = rb_opt("finish_tiled", 1);        // rb_learner_finish_grads: the hidden layer's replica-mean weight gradient on 128 x 128 tiles
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
@@ -2522,15 +2548,24 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   }
   zp.a.eout_noff = L.z_eout; zp.a.ein_noff = L.z_ein;
   hp.a.eout_noff = L.h_eout; hp.a.ein_noff = L.h_ein;
-  zp.a.sq_part = l->norm_part;
-  hp.a.sq_part = l->norm_part + zp.slots;
+  // the hidden layer on 128 x 128 LDS tiles (fc_gemm.h rb_fc_gemm_dw_ranks; RB_OPTS finish_tiled=0: the 16-row-tile body): a
+  // rank's slab of the gathered factors is read once per 128 weight rows instead of once per 16
+  const bool tiled = l->opt_finish_tiled && 2 * L.H >= 64 && L.F >= 64;
+  const int h_nt = (int)rb_div_up(2 * L.H, RB_TG_T), h_kt = (int)rb_div_up(L.F, RB_TG_T);
+  if (tiled) hp.slots = 8 * h_nt * h_kt;
   FinishArgs fa;
+  if (tiled) { hp.a.sq_part = l->norm_part; zp.a.sq_part = l->norm_part + hp.slots; }
+  else { zp.a.sq_part = l->norm_part; hp.a.sq_part = l->norm_part + zp.slots; }
   fa.z = zp.a; fa.h = hp.a;
   fa.z_x = zp.dw_x; fa.z_n = zp.dw_x * zp.dw_y; fa.h_x = hp.dw_x; fa.h_n = hp.dw_x * hp.dw_y;
   // the conv gradients travel in the same blocks: their replica mean (rank order) and its sum of squares (0.3 MB per rank)
   fa.g = l->grads; fa.n = conv_n; fa.part = l->norm_part + zp.slots + hp.slots; fa.nparts = c_slots;
   fa.blocks = f + l->fact_off[5]; fa.bstride = l->fact_stride; fa.world = l->world; fa.scale = 1.0f / (float)l->world;
-  RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads, dim3((unsigned)(fa.z_n + fa.h_n + c_slots)), dim3(256), stream, fa);
+  if (tiled) {
+    RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads_tiled, dim3((unsigned)(h_nt * h_kt + fa.z_n + c_slots)), dim3(RB_TG_THREADS), stream, fa, h_nt, h_kt);
+  } else {
+    RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads, dim3((unsigned)(fa.z_n + fa.h_n + c_slots)), dim3(256), stream, fa);
+  }
   RB_LAUNCH_CHECK();
   l->norm_slots = zp.slots + hp.slots + c_slots;
   l->exch_pending = 0;
