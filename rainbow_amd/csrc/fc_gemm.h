@@ -611,24 +611,40 @@ __device__ __forceinline__ void rb_fc_gemm_dw_ranks(const NlDwArgs& a, int ntile
     }
   }
   __syncthreads();                                          // every wave is done with the operand buffers
-  // bias gradients (first column tile only): g_bmu[n] = scale * sum_r colsum_r[n], g_bsigma[n] = scale * sum_r colsum_r[n] * eps_out_r[n]
-  const bool do_bias = ktile == 0 && tid < RB_TG_T && nt + tid < N;
+  // bias gradients (first column tile only): g_bmu[n] = scale * sum_r colsum_r[n], g_bsigma[n] = scale * sum_r colsum_r[n] * eps_out_r[n].
+  // Column sums of a rank's dY by ALL 512 threads — thread (n = tid & 127, group tid >> 7) takes every fourth rank, a rank's rows 32
+  // loads at a time — parked in LDS [rank][128]; then thread n folds them in rank order.  (As one thread per column walking all
+  // ranks 8 loads at a time this was a chain of 32 round trips: the launch's pole at 47 us.)
+  const bool bias_wg = ktile == 0;                          // block-uniform
+  const bool do_bias = bias_wg && tid < RB_TG_T && nt + tid < N;
   float gb = 0.0f, gbs = 0.0f;
-  if (do_bias) {
-    const int n = nt + tid;
-    for (int rk = 0; rk < nranks; ++rk) {
+  if (bias_wg) {
+    const int nb = tid & (RB_TG_T - 1), rg = tid >> 7;
+    const int n = nt + nb < N ? nt + nb : N - 1;
+    for (int rk = rg; rk < nranks; rk += RB_TG_THREADS / RB_TG_T) {
       const float* dy = a.dy + (int64_t)rk * a.bstride;
       float cs = 0.0f;
-      for (int m0 = 0; m0 < rpb; m0 += 8) {
-        float v[8];
+      for (int m0 = 0; m0 < rpb; m0 += 32) {
+        float v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = dy[(int64_t)(m0 + u < rpb ? m0 + u : rpb - 1) * a.ldy + n];
+        for (int u = 0; u < 32; ++u) v[u] = dy[(int64_t)(m0 + u < rpb ? m0 + u : rpb - 1) * a.ldy + n];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cs += (m0 + u < rpb) ? v[u] : 0.0f;
+        for (int u = 0; u < 32; ++u) cs += (m0 + u < rpb) ? v[u] : 0.0f;
       }
-      gb = gb + cs;
-      gbs = gbs + cs * a.noise_blocks[(int64_t)rk * a.bstride + a.eout_noff + n];
+      if (rk < RB_TG_LDS / (2 * RB_TG_T)) {                   // (world <= 64: rb_learner_set_exchange)
+        lds[rk * RB_TG_T + nb] = cs;
+        lds[(RB_TG_LDS / (2 * RB_TG_T) + rk) * RB_TG_T + nb] = a.noise_blocks[(int64_t)rk * a.bstride + a.eout_noff + n];
+      }
     }
+    __syncthreads();
+    if (do_bias) {
+      for (int rk = 0; rk < nranks; ++rk) {
+        const float cs = lds[rk * RB_TG_T + tid];
+        gb = gb + cs;
+        gbs = gbs + cs * lds[(RB_TG_LDS / (2 * RB_TG_T) + rk) * RB_TG_T + tid];
+      }
+    }
+    __syncthreads();                                        // the tiles below reuse the buffer
   }
   // epilogue: the two finished tiles through LDS, 16-byte row-segment stores, sum of squares of everything this wave wrote
   float sq = 0.0f;
