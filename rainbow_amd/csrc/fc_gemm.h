@@ -573,14 +573,17 @@ __device__ __forceinline__ void rb_fc_gemm_dw_ranks(const NlDwArgs& a, int ntile
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { gm[t][e] = 0.0f; gs[t][e] = 0.0f; acc[t][e] = 0.0f; }
-  FcDwRegs R;
-  load(R, 0);
+  // TWO slabs of global loads in flight (two register sets, the loop unrolled by two so that they stay registers): one workgroup
+  // per CU at two waves per SIMD has nothing else to hide a slab's ~2.5 us of load latency behind (one slab ahead: 39 us per launch)
+  FcDwRegs R0, R1;
+  load(R0, 0);
+  if (total > 1) load(R1, 1);
   float eo[16], ei[2][2];
-  for (int idx = 0; idx < total; ++idx) {
+  auto step = [&](int idx, FcDwRegs& R) {
     const int rk = idx / spr, s = idx - rk * spr;
     store(R, idx & 1);
     __syncthreads();                                        // slab idx is in LDS; its buffer was last read two slabs ago
-    if (idx + 1 < total) load(R, idx + 1);
+    if (idx + 2 < total) load(R, idx + 2);
     if (s == 0) {                                           // this rank's noise for the fold below: requested with the slab (block-uniform)
       const float* nz = a.noise_blocks + (int64_t)rk * a.bstride;
 #pragma unroll
@@ -609,6 +612,10 @@ __device__ __forceinline__ void rb_fc_gemm_dw_ranks(const NlDwArgs& a, int ntile
           acc[t][e] = 0.0f;
         }
     }
+  };
+  for (int idx = 0; idx < total; idx += 2) {
+    step(idx, R0);
+    if (idx + 1 < total) step(idx + 1, R1);
   }
   __syncthreads();                                          // every wave is done with the operand buffers
   // bias gradients (first column tile only): g_bmu[n] = scale * sum_r colsum_r[n], g_bsigma[n] = scale * sum_r colsum_r[n] * eps_out_r[n].
