@@ -578,21 +578,31 @@ __device__ __forceinline__ void rb_fc_gemm_dw_ranks(const NlDwArgs& a, int ntile
   FcDwRegs R0, R1;
   load(R0, 0);
   if (total > 1) load(R1, 1);
-  float eo[16], ei[2][2];
+  // a rank's noise for its fold: requested one RANK ahead (a second register set), so that the fold at the end of a rank's last slab
+  // never waits for it
+  float eo[16], ei[2][2], eo_n[16], ei_n[2][2];
+  auto load_noise = [&](int rk, float (&o)[16], float (&i2)[2][2]) {
+    const float* nz = a.noise_blocks + (int64_t)(rk < nranks ? rk : nranks - 1) * a.bstride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = nt + 32 * wm + rb_mfma_row(e, lane);
+      o[e] = nz[a.eout_noff + (n < N ? n : N - 1)];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { i2[t][0] = nz[a.ein_noff + ein0 + kcol[t]]; i2[t][1] = nz[a.ein_noff + ein1 + kcol[t]]; }
+  };
+  load_noise(0, eo_n, ei_n);
   auto step = [&](int idx, FcDwRegs& R) {
     const int rk = idx / spr, s = idx - rk * spr;
     store(R, idx & 1);
     __syncthreads();                                        // slab idx is in LDS; its buffer was last read two slabs ago
     if (idx + 2 < total) load(R, idx + 2);
-    if (s == 0) {                                           // this rank's noise for the fold below: requested with the slab (block-uniform)
-      const float* nz = a.noise_blocks + (int64_t)rk * a.bstride;
+    if (s == 0) {                                           // (block-uniform) this rank's noise has landed; the next rank's is requested
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = nt + 32 * wm + rb_mfma_row(e, lane);
-        eo[e] = nz[a.eout_noff + (n < N ? n : N - 1)];
-      }
+      for (int e = 0; e < 16; ++e) eo[e] = eo_n[e];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { ei[t][0] = nz[a.ein_noff + ein0 + kcol[t]]; ei[t][1] = nz[a.ein_noff + ein1 + kcol[t]]; }
+      for (int t = 0; t < 2; ++t) { ei[t][0] = ei_n[t][0]; ei[t][1] = ei_n[t][1]; }
+      load_noise(rk + 1, eo_n, ei_n);
     }
     const float* sa = lds + (idx & 1) * 2 * RB_TG_OP;
 #pragma unroll
