@@ -693,10 +693,7 @@ __global__ __launch_bounds__(RB_TG_THREADS) void k_finish_grads_tiled(FinishArgs
   const int h_n = h_nt * h_kt;
   if (b < h_n) { rb_fc_gemm_dw_ranks(a.h, b / h_kt, b % h_kt, 8 * b, lds); return; }
   b -= h_n;
-  if (b < a.z_n) {
-    if (threadIdx.x < 256) rb_nl_dw_body_ranks(a.z, b % a.z_x, b / a.z_x, 4 * b);     // (a four-wave body without barriers)
-    return;
-  }
+  if (b < a.z_n) { rb_nl_dw_body_ranks(a.z, b % a.z_x, b / a.z_x, 8 * b); return; }      // (all eight waves: 512 columns per workgroup)
   b -= a.z_n;
   float acc = 0.0f;
   for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)a.nparts * blockDim.x) {
@@ -2541,7 +2538,6 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   const int64_t conv_n = L.h_mu;
   int c_slots = (int)rb_div_up(conv_n, 256 * 16);
   if (c_slots > 1024) c_slots = 1024;
-  RB_REQUIRE(zp.slots + hp.slots + c_slots <= 16384, "rb_learner_finish_grads: too many norm partials");
   for (FcDwPlan* p : {&zp, &hp}) {
     p->a.rpb = L.B; p->a.bstride = l->fact_stride; p->a.scale = 1.0f / (float)l->world;
     p->a.noise_blocks = f + l->fact_off[4];
@@ -2552,7 +2548,15 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   // rank's slab of the gathered factors is read once per 128 weight rows instead of once per 16
   const bool tiled = l->opt_finish_tiled && 2 * L.H >= 64 && L.F >= 64;
   const int h_nt = (int)rb_div_up(2 * L.H, RB_TG_T), h_kt = (int)rb_div_up(L.F, RB_TG_T);
-  if (tiled) hp.slots = 8 * h_nt * h_kt;
+  if (tiled) {
+    // (every workgroup of this launch is 512 threads at ~250 registers: ONE per CU.  The output layer's tiles therefore take all
+    // eight waves — 512 columns per workgroup, 23 instead of 46 workgroups at the canonical shape — so that the launch stays within
+    // one round of 256: with 266 workgroups the last ten waited for a CU and the launch took 40 us instead of 27)
+    hp.slots = 8 * h_nt * h_kt;
+    zp.dw_x = (int)rb_div_up(zp.a.K, 512);
+    zp.slots = 8 * zp.dw_x * zp.dw_y;
+  }
+  RB_REQUIRE(zp.slots + hp.slots + c_slots <= 16384, "rb_learner_finish_grads: too many norm partials");
   FinishArgs fa;
   if (tiled) { hp.a.sq_part = l->norm_part; zp.a.sq_part = l->norm_part + hp.slots; }
   else { zp.a.sq_part = l->norm_part; hp.a.sq_part = l->norm_part + zp.slots; }

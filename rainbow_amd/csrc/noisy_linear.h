@@ -645,7 +645,7 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
 // are scaled by 1 / world at the end — the arithmetic of "every replica computes its gradient, then all-reduce(mean)".
 __device__ __forceinline__ void rb_nl_dw_body_ranks(const NlDwArgs& a, int bx, int by, int slot_base) {
   const int lane = rb_lane(), wave = rb_wave();
-  const int kt = bx * 256 + wave * 64;
+  const int kt = bx * (int)blockDim.x + wave * 64;       // a wave owns 64 columns: 256 per 4-wave block, 512 per 8-wave block
   if (kt >= a.K) {                                       // wave-uniform, no barriers below
     if (a.sq_part && lane == 0) a.sq_part[slot_base + wave] = 0.0f;
     return;
