@@ -691,20 +691,32 @@ __global__ __launch_bounds__(RB_TG_THREADS) void k_finish_grads_tiled(FinishArgs
   __shared__ float s_red[16];
   int b = (int)blockIdx.x;
   const int h_n = h_nt * h_kt;
-  if (b < h_n) { rb_fc_gemm_dw_ranks(a.h, b / h_kt, b % h_kt, 8 * b, lds); return; }
-  b -= h_n;
-  if (b < a.z_n) { rb_nl_dw_body_ranks(a.z, b % a.z_x, b / a.z_x, 8 * b); return; }      // (all eight waves: 512 columns per workgroup)
-  b -= a.z_n;
-  float acc = 0.0f;
-  for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)a.nparts * blockDim.x) {
-    float v = 0.0f;
-    for (int r = 0; r < a.world; ++r) v += a.blocks[(int64_t)r * a.bstride + i];
-    v *= a.scale;
-    a.g[i] = v;
-    acc = fmaf(v, v, acc);
+  if (b < h_n) {
+    // the conv range rides in the tile workgroups (a.nparts == h_n: one slice and one partial per workgroup): its per-element chain —
+    // `world` loads, one add each — as 20 workgroups of their own was the launch's pole (22 of 40 us with the tile loop ablated:
+    // every thread walked 8 elements x 8 ranks one dependent load at a time).  Here: one element per thread and trip, all ranks'
+    // loads in flight, in front of the tile loop.
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)a.nparts * blockDim.x) {
+      float v = 0.0f;
+      for (int r0 = 0; r0 < a.world; r0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = a.blocks[(int64_t)(r0 + u < a.world ? r0 + u : a.world - 1) * a.bstride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += (r0 + u < a.world) ? t[u] : 0.0f;      // rank order
+      }
+      v *= a.scale;
+      a.g[i] = v;
+      acc = fmaf(v, v, acc);
+    }
+    acc = rb_block_sum(acc, s_red);
+    if (threadIdx.x == 0) a.part[b] = acc;
+    rb_fc_gemm_dw_ranks(a.h, b / h_kt, b % h_kt, 8 * b, lds);
+    return;
   }
-  acc = rb_block_sum(acc, s_red);
-  if (threadIdx.x == 0) a.part[b] = acc;
+  b -= h_n;
+  if (b < a.z_n) rb_nl_dw_body_ranks(a.z, b % a.z_x, b / a.z_x, 8 * b);      // (all eight waves: 512 columns per workgroup)
 }
 // Stage 2: every block re-reduces the partials (same order everywhere), then scales its slice.
 __global__ __launch_bounds__(256) void k_clip_scale(float* g, int64_t n, const float* part, int nparts, float max_norm,
@@ -2555,6 +2567,7 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
     hp.slots = 8 * h_nt * h_kt;
     zp.dw_x = (int)rb_div_up(zp.a.K, 512);
     zp.slots = 8 * zp.dw_x * zp.dw_y;
+    c_slots = h_nt * h_kt;         // the conv range: one slice (and one partial) per tile workgroup
   }
   RB_REQUIRE(zp.slots + hp.slots + c_slots <= 16384, "rb_learner_finish_grads: too many norm partials");
   FinishArgs fa;
@@ -2562,11 +2575,12 @@ int rb_learner_finish_grads(rb_learner_t* l, rb_stream_t stream_) {
   else { zp.a.sq_part = l->norm_part; hp.a.sq_part = l->norm_part + zp.slots; }
   fa.z = zp.a; fa.h = hp.a;
   fa.z_x = zp.dw_x; fa.z_n = zp.dw_x * zp.dw_y; fa.h_x = hp.dw_x; fa.h_n = hp.dw_x * hp.dw_y;
-  // the conv gradients travel in the same blocks: their replica mean (rank order) and its sum of squares (0.3 MB per rank)
+  // the conv gradients travel in the same blocks: their replica mean (rank order) and its sum of squares (0.3 MB per rank);
+  // tiled: sliced over the hidden layer's tile workgroups (c_slots above)
   fa.g = l->grads; fa.n = conv_n; fa.part = l->norm_part + zp.slots + hp.slots; fa.nparts = c_slots;
   fa.blocks = f + l->fact_off[5]; fa.bstride = l->fact_stride; fa.world = l->world; fa.scale = 1.0f / (float)l->world;
   if (tiled) {
-    RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads_tiled, dim3((unsigned)(h_nt * h_kt + fa.z_n + c_slots)), dim3(RB_TG_THREADS), stream, fa, h_nt, h_kt);
+    RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads_tiled, dim3((unsigned)(h_nt * h_kt + fa.z_n)), dim3(RB_TG_THREADS), stream, fa, h_nt, h_kt);
   } else {
     RB_LAUNCH_T("finish_grads:k_finish_grads", k_finish_grads, dim3((unsigned)(fa.z_n + fa.h_n + c_slots)), dim3(256), stream, fa);
   }
