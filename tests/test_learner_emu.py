@@ -670,7 +670,7 @@ def test_early_draw_on_the_replays_stream_is_bit_identical(emu, monkeypatch):
 
 
 
-@pytest.mark.parametrize("preceding", [3, 4])
+@pytest.mark.parametrize("preceding", [4])      # (the tentative draw then sits in table 1; 3 and 4 both run on the GPU)
 def test_public_sample_after_an_early_draw_reads_table_zero(emu, monkeypatch, preceding):
     ts_scenarios.public_sample_after_early_draw_check(emu, NumpyMem, monkeypatch, preceding)
 

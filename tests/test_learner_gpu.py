@@ -949,3 +949,10 @@ def test_public_sample_after_an_early_draw_reads_table_zero(hip, monkeypatch, pr
     import ts_scenarios
     from cabi_adapter import TorchMem
     ts_scenarios.public_sample_after_early_draw_check(hip, TorchMem, monkeypatch, preceding)
+
+
+def test_train_step_captured_into_a_graph_with_the_early_draw_option(hip, monkeypatch):
+    """(tests/ts_scenarios.py captured_train_step_check)"""
+    import ts_scenarios
+    from cabi_adapter import TorchMem
+    ts_scenarios.captured_train_step_check(hip, TorchMem, monkeypatch)

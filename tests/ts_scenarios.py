@@ -152,3 +152,55 @@ def public_sample_after_early_draw_check(lib, Mem, monkeypatch, preceding):
         assert np.array_equal(a[k], b[k]), ("train_step after the three calls", k)
     for (mem, rp, ad, o, job) in (h1, h2):
         ad.close(); rp.close()
+
+
+def captured_train_step_check(lib, Mem, monkeypatch):
+    """rb_learner_train_step captured into a hipGraph with RB_OPTS spec_draw=1.  Two eager calls arm the early
+    draw (streak >= 1); the THIRD call is captured: under stream capture the library must neither launch the early pair (it would run
+    at once, outside the graph, waiting for a flag the captured kernels only store on replay) nor bake an accepted tentative draw
+    into the captured sampler launch (replays would skip both the draw and the priority write-back).  The graph is replayed four
+    times — beta from the device word (rb_replay_set_beta_source), the step number from the device counter — against an eager twin
+    with spec_draw=0: batch, loss, parameters, moments, noise, norm, the sum-tree and the header bit-identical after every replay."""
+    import torch
+    name = "dataeff"
+    monkeypatch.setenv("RB_OPTS", "spec_draw=1")
+    h1 = ts_build(lib, Mem, name)
+    monkeypatch.setenv("RB_OPTS", "spec_draw=0")
+    h2 = ts_build(lib, Mem, name)
+    keep = []
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ctr = mem.upload(np.zeros(1, np.int64))
+        nb = mem.upload(np.array([-0.4], np.float32))
+        L.check(lib, lib.rb_learner_set_step_counter(ad.h, mem.ptr(ctr)))
+        L.check(lib, lib.rb_replay_set_beta_source(rp.h, mem.ptr(nb)))
+        keep.append((ctr, nb))
+
+    def call(h, stream):
+        mem, rp, ad, o, job = h
+        ts = ts_args(name, mem, rp, ad, o, job, 0.4, 0)
+        L.check(lib, lib.rb_learner_train_step(ad.h, C.byref(ts), stream))
+
+    for _ in range(2):
+        call(h1, h1[0].stream)
+        call(h2, h2[0].stream)
+    a, b = ts_snapshot(*h1[:4]), ts_snapshot(*h2[:4])
+    assert np.array_equal(a["params"], b["params"]) and np.array_equal(a["tree"], b["tree"])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call(h1, torch.cuda.current_stream().cuda_stream)
+    e = C.c_int64(-1)
+    for rep in range(4):
+        g.replay()
+        call(h2, h2[0].stream)
+        a, b = ts_snapshot(*h1[:4]), ts_snapshot(*h2[:4])
+        for k in a:
+            assert np.array_equal(a[k], b[k]), ("replay %d" % rep, k)
+        ha, hb = h1[1].raw_header(), h2[1].raw_header()
+        assert (ha.index, ha.full, ha.max, ha.total, ha.last_attempts, ha.last_status, ha.rng_counter) == \
+               (hb.index, hb.full, hb.max, hb.total, hb.last_attempts, hb.last_status, hb.rng_counter), rep
+    L.check(lib, lib.rb_replay_expired_waits(h1[1].h, C.byref(e)))
+    assert e.value == 0
+    del g
+    for (mem, rp, ad, o, job) in (h1, h2):
+        ad.close(); rp.close()

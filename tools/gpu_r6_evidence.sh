@@ -1,6 +1,7 @@
 # usage: bash tools/gpu_r6_evidence.sh <tag>: round 6's evidence set (copy gpurun_out/<tag>_* into profiles/ to commit): GPU suite (plain and with
 # serialised blocking launches), smoke, per BASELINE config the bench line + rocprofv3 kernel stats + FETCH / WRITE traffic + SQ counters, the
-# kernel traces of configs 2 and 3, the driver's 20-step line, the loop bench, the PER bench, the exchange kernels of config 5 on one device.
+# kernel traces of configs 2, 3 and 4, the driver's 20-step line, the loop bench, the PER bench, the exchange kernels of config 5 on one device,
+# the soak run in the shape of main.py's loop.
 # Every step under `timeout -k`.
 TAG=${1:-round6_final}
 mkdir -p gpurun_out
@@ -31,5 +32,6 @@ for v in "RAINBOW_AMD_LAZY_PRIORITIES=0" "RAINBOW_AMD_LAZY_PRIORITIES=1 PER_DONA
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_exch -o exch -- python -m pytest $ROOT/tests/test_exchange_gpu.py -q -k "factored and 8" -p no:cacheprovider > $ROOT/gpurun_out/${TAG}_exch.log 2>&1)
 python tools/exchange_world8_times.py $(find gpurun_out/${TAG}_exch -name "*kernel_stats.csv" | head -1) > gpurun_out/${TAG}_exchange_world8.txt 2>&1; cat gpurun_out/${TAG}_exchange_world8.txt
 rm -rf gpurun_out/${TAG}_exch gpurun_out/${TAG}_exch.log
+SOAK_STEPS=40000 timeout -k 10 600 python tools/soak.py > gpurun_out/${TAG}_soak.json.log 2>&1; tail -1 gpurun_out/${TAG}_soak.json.log | cut -c1-300
 AMD_SERIALIZE_KERNEL=3 HIP_LAUNCH_BLOCKING=1 timeout -k 10 1200 python -m pytest tests -m gpu -q -x > gpurun_out/${TAG}_serialized_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_serialized_pytest_gpu.log
 grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" gpurun_out/${TAG}_serialized_pytest_gpu.log | tail -3
