@@ -1231,8 +1231,11 @@ struct ConvWtJob {
   const float* w;
   float* wT;
   int cin, cout, KS, S, kpad;
+  int t16;                 // 1: the [phase][c][k'] layout of k_conv_dx_t16_multi (rb_conv_wt16_block), same buffer
 };
+__device__ __forceinline__ void rb_conv_wt16_block(const ConvWtJob& j, int blk, int nblk);
 __device__ __forceinline__ void rb_conv_wt_block(const ConvWtJob& j, int blk, int nblk) {
+  if (j.t16) { rb_conv_wt16_block(j, blk, nblk); return; }        // block-uniform
   const int KK = j.KS * j.KS, total = j.cout * j.cin * KK, ntiles = (j.cin + 31) / 32;
   for (int e = blk * (int)blockDim.x + (int)threadIdx.x; e < total; e += nblk * (int)blockDim.x) {
     const int co = e / (j.cin * KK), r = e - co * (j.cin * KK);
@@ -1503,6 +1506,177 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dx_lds(ConvLdsDxArgs a
   }
   RB_WGT(WK, wgi, 5);
   RB_WGT(WK, wgi, 6);
+}
+
+// ---- the same data gradient on whole-K 16x16x4 tiles, for the image loop of large batches (round 6) -----------------------------
+// k_conv_dx_lds<..., MULTI> splits the reduction over its 8 waves and sums the partial tiles through LDS for every image — the pattern
+// k_conv_fwd_multi_t16 removed from the forward (MFMA-busy 0.38 / 0.46 at batch 256, half of the launch spent outside the MFMA loop).
+// Here a workgroup owns (stride phase, 32 input channels, ALL positions of the phase): one wave per 16-position x 16-channel tile runs the
+// WHOLE reduction k' = (co, tap) for its tile — lane (x, kq) takes the contiguous quarter [kq K'/4, (kq + 1) K'/4), its A operands are
+// whole float4s of weight row c (the slab arrives ready-made as wT16[phase][c][k'], rb_conv_wt16_block), its B operands are cells of
+// the zero-haloed dY image at compile-time offsets co PPL - ty PW - tx — and the epilogue (relu' mask, store) goes from the accumulators
+// to memory.  Needs KS % S == 0 (every phase has the same taps), (COUT * taps) % 16 == 0, cin % 32 == 0 (host-checked).
+// grid = (phases, cin / 32, image groups) or image-group-fastest (a.img_fast); block = 64 * NWV.
+__device__ __forceinline__ void rb_conv_wt16_block(const ConvWtJob& j, int blk, int nblk) {
+  const int KK = j.KS * j.KS, total = j.cout * j.cin * KK, T = (j.KS + j.S - 1) / j.S, taps = T * T, kq = j.cout * taps;
+  for (int e = blk * (int)blockDim.x + (int)threadIdx.x; e < total; e += nblk * (int)blockDim.x) {
+    const int co = e / (j.cin * KK), r = e - co * (j.cin * KK);
+    const int c = r / KK, tap = r - c * KK;
+    const int ky = tap / j.KS, kx = tap - ky * j.KS;
+    const int py = ky % j.S, px = kx % j.S, ty = ky / j.S, tx = kx / j.S;
+    j.wT[((int64_t)(py * j.S + px) * j.cin + c) * kq + co * taps + ty * T + tx] = j.w[e];
+  }
+}
+template <class G, int COUT>
+struct ConvDxT16 {
+  static constexpr int TMAX = (G::KS + G::S - 1) / G::S, TAPS = TMAX * TMAX;
+  static constexpr int KP = COUT * TAPS, KQ = KP / 4, CQ = COUT / 4, WS = KP + 4;
+  static constexpr int PAD = TMAX - 1, NS = (G::IH + G::S - 1) / G::S, PADH = NS - G::OH, PW = G::OH + PAD + PADH, PP = PW * PW;
+  static constexpr int rb_pad() {
+    for (int p = 0; p < 64; ++p)
+      if ((CQ * (PP + p)) % 32 == 16) return p;
+    return 0;
+  }
+  static constexpr int PPL = PP + rb_pad();                    // dY plane stride: the four k-quarters of an operand read start 16 banks apart
+  static constexpr int NPOS = NS * NS, PT = (NPOS + 15) / 16, TILE_WAVES = 2 * PT, NWV = (TILE_WAVES + 3) / 4 * 4;
+  static constexpr int FLOATS = 32 * WS + COUT * PPL;
+  static constexpr bool OK = (G::KS % G::S) == 0 && (KP % 16) == 0 && (COUT % 4) == 0 && NWV <= 16 && FLOATS * 4 <= 150 * 1024;
+};
+template <class G, int COUT, bool LAZY>
+__global__ __launch_bounds__((64 * ConvDxT16<G, COUT>::NWV)) void k_conv_dx_t16_multi(ConvLdsDxArgs a) {
+  typedef ConvDxT16<G, COUT> Z;
+  constexpr int THREADS = 64 * Z::NWV, WS = Z::WS, PPL = Z::PPL, PW = Z::PW, PAD = Z::PAD, KQ = Z::KQ, CQ = Z::CQ, TAPS = Z::TAPS, TMAX = Z::TMAX;
+  static_assert(Z::OK, "k_conv_dx_t16_multi: geometry");
+  __shared__ __attribute__((aligned(16))) float smem[Z::FLOATS];
+  float* s_w = smem;
+  float* s_dy = smem + 32 * WS;
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bx_ = a.img_fast ? (int)blockIdx.z : (int)blockIdx.x, bz_ = a.img_fast ? (int)blockIdx.x : (int)blockIdx.z;
+  const int img0 = bz_ * a.ipb;
+  const int img_end = img0 + a.ipb < a.batch ? img0 + a.ipb : a.batch;
+  if (img0 >= a.batch) return;                                // block-uniform
+  const int c0 = (int)blockIdx.y * 32;
+  const int phase = bx_;
+  const int py = phase / G::S, px = phase % G::S;
+  const int nyy = (G::IH - py + G::S - 1) / G::S, nxx = (G::IH - px + G::S - 1) / G::S;
+  const int npos = nyy * nxx;
+  // ---- dY of an image: interior cells only, global loads into registers (issue), LDS stores later (commit); the zero halo is
+  // written once (k_conv_dx_lds: the staging of these kernels is instruction-bound)
+  constexpr int LIT = (COUT * G::P + THREADS - 1) / THREADS;
+  float pre_m[LAZY ? LIT : 1], pre_p[LAZY ? LIT : 1][4], pre_v[LAZY ? 1 : LIT];
+  const int ni = a.cout * G::P;
+  int cell[LIT];
+#pragma unroll
+  for (int i = 0; i < LIT; ++i) {
+    const int e = t + i * THREADS;
+    const int ec = e < ni ? e : ni - 1;
+    const int co = ec / G::P, r = ec - co * G::P;
+    const int y = r / G::OH, x = r - y * G::OH;
+    cell[i] = e < ni ? co * PPL + (y + PAD) * PW + x + PAD : -1;
+  }
+  for (int e = t; e < (COUT * PPL) / 4; e += THREADS) rb_st4(s_dy + 4 * e, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  for (int e = (COUT * PPL) / 4 * 4 + t; e < COUT * PPL; e += THREADS) s_dy[e] = 0.0f;
+  auto issue = [&](int img) {
+    const unsigned ibase = 4u * (unsigned)(img * ni);
+    if constexpr (LAZY) {
+      const rb_buf mk = rb_make_buf(a.dy_mask);
+      rb_buf pp[4];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) pp[sp] = rb_make_buf(a.dy_part + (int64_t)(sp < a.dy_splits ? sp : a.dy_splits - 1) * a.dy_stride);
+#pragma unroll
+      for (int i = 0; i < LIT; ++i) {
+        const int e = t + i * THREADS;
+        const unsigned off = 4u * (unsigned)(e < ni ? e : ni - 1);
+        pre_m[i] = rb_ld1_buf(mk, off, ibase);
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) pre_p[i][sp] = rb_ld1_buf(pp[sp], off, ibase);
+      }
+    } else {
+      const rb_buf src = rb_make_buf(a.dy);
+#pragma unroll
+      for (int i = 0; i < LIT; ++i) {
+        const int e = t + i * THREADS;
+        pre_v[i] = rb_ld1_buf(src, 4u * (unsigned)(e < ni ? e : ni - 1), ibase);
+      }
+    }
+  };
+  auto commit = [&]() {
+    if constexpr (LAZY) {
+#pragma unroll
+      for (int i = 0; i < LIT; ++i) {
+        if (cell[i] >= 0) {
+          float acc = 0.0f;                                                 // k_dfeat_finish's order: ((0 + p0) + p1) + ...
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) acc += sp < a.dy_splits ? pre_p[i][sp] : 0.0f;
+          s_dy[cell[i]] = pre_m[i] > 0.0f ? acc : 0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LIT; ++i) if (cell[i] >= 0) s_dy[cell[i]] = pre_v[i];
+    }
+  };
+  issue(img0);
+  {   // the slab [32 channels c0 ..][K'] of this phase: a straight copy of a.wT (wT16 layout), rows of channels >= cin zero
+    const float* src = a.wT + ((int64_t)phase * a.cin + c0) * Z::KP;
+    for (int e = t; e < 32 * (Z::KP / 4); e += THREADS) {
+      const int m = e / (Z::KP / 4), q = e - m * (Z::KP / 4);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (c0 + m < a.cin) v = rb_ld4(src + (int64_t)m * Z::KP + 4 * q);
+      rb_st4(s_w + m * WS + 4 * q, v);
+    }
+  }
+  // ---- this wave's tile: position tile pt, channel tile ct0; lane (x, kq)
+  const bool tile_wave = wave < Z::TILE_WAVES;
+  const int pt = wave % Z::PT, ct0 = (wave / Z::PT) % 2;
+  const int x = lane & 15, kq = lane >> 4;
+  int n = pt * 16 + x;
+  const bool pv = n < npos;
+  if (n > npos - 1) n = npos - 1;
+  const int yy = n / nxx, xx = n - yy * nxx;
+  const float* bp = s_dy + kq * CQ * PPL + (yy + PAD) * PW + xx + PAD;
+  const float* ap = s_w + (ct0 * 16 + x) * WS + kq * KQ;
+  int eoff[4];                                          // the lane's four output cells (channel 4 kq + r of its tile): offset in the image, -1 = none
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ct0 * 16 + 4 * kq + r;
+    eoff[r] = (pv && c < a.cin) ? c * G::IP + (yy * G::S + py) * G::IH + xx * G::S + px : -1;
+  }
+  __syncthreads();                                      // zero fill complete before the first interior stores (other threads' cells)
+  for (int img = img0; img < img_end; ++img) {
+    commit();
+    const float* xa = a.x_act + (int64_t)img * a.cin * G::IP;
+    float mask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mask[r] = xa[eoff[r] >= 0 ? eoff[r] : 0];
+    __syncthreads();                                    // dY (and the slab) complete
+    if (img + 1 < img_end) issue(img + 1);
+    if (tile_wave) {
+      rb_f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int jq = 0; jq < KQ / 4; ++jq) {
+        const float4 w4 = rb_ld4(ap + 4 * jq);
+        float b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          constexpr int dummy = 0; (void)dummy;
+          const int j = 4 * jq + u, co = j / TAPS, tap = j % TAPS;
+          b[u] = bp[co * PPL - (tap / TMAX) * PW - (tap % TMAX)];
+        }
+        acc = rb_mfma16(w4.x, b[0], acc);
+        acc = rb_mfma16(w4.y, b[1], acc);
+        acc = rb_mfma16(w4.z, b[2], acc);
+        acc = rb_mfma16(w4.w, b[3], acc);
+      }
+      float* dxi = a.dx + (int64_t)img * a.cin * G::IP;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (eoff[r] >= 0) dxi[eoff[r]] = mask[r] > 0.0f ? acc[r] : 0.0f;
+    }
+    __syncthreads();                                    // every wave is done reading this image's dY
+  }
 }
 
 // ======================================================================= weight gradient ==

@@ -163,7 +163,7 @@ struct rb_learner {
   int lazy_splits;
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
-  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_img_fast, opt_finish_tiled;
+  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   int opt_implicit_small;
@@ -1144,6 +1144,18 @@ static int forward(rb_learner* l, int n_on, int n_tg, const ImgSrc& src, const N
   return RB_OK;
 }
 
+// The data gradient of conv layer `layer` (>= 1) on the whole-K 16x16x4 tile kernel (conv_lds.h k_conv_dx_t16_multi): the image-loop
+// form, i.e. batches of 64 and more (or RB_OPTS dx_ipb > 1, the test hook), the canonical later layers' geometries (64 output
+// channels, kernel size a multiple of the stride).  RB_OPTS dx_t16=0: k_conv_dx_lds<..., MULTI>.  Decides the layout of conv_wT too.
+static bool dx_uses_t16(const rb_learner* l, int layer) {
+  const Layout& L = l->L;
+  if (layer < 1 || layer >= L.nconv || !l->fast_conv || !l->conv_wT[layer] || !l->opt_dx_t16) return false;
+  const ConvLayer& c = L.conv[layer];
+  if (c.cout != 64 || c.cin % 32 != 0 || c.ks % c.s != 0) return false;
+  if (!((c.ks == 4 && c.s == 2 && c.ih == 20) || (c.ks == 3 && c.s == 1 && c.ih == 9))) return false;      // GeomC2 / GeomC3 (ConvDxT16<G, 64>::OK)
+  return L.B >= 64 || l->opt_dx_ipb > 1;
+}
+
 // mode bit 0: weight/bias grads (+ split reduction); bit 1: data grads into dact[layer-1]
 template <class G>
 static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipStream_t stream, int mode) {
@@ -1208,6 +1220,24 @@ static int launch_conv_bwd(rb_learner* l, int layer, const uint8_t* states, hipS
     if (l->opt_img_fast && L.B % ipb == 0 && (L.B / ipb) % 8 == 0) {      // image(-group)-fastest block order: image i on XCD i mod 8 in every conv launch
       a.img_fast = 1;
       grid = dim3((unsigned)(L.B / ipb), (unsigned)rb_div_up(c.cin, 32), (unsigned)(G::S * G::S) * groups);
+    }
+    if constexpr (ConvDxT16<G, 64>::OK) {
+      if (dx_uses_t16(l, layer)) {
+        // whole-K tiles: a workgroup per (phase, 32 input channels, image group), about one round of 256
+        const int units = G::S * G::S * (int)rb_div_up(c.cin, 32);
+        int tp = ipb_env > 0 ? ipb_env : (int)rb_div_up((int64_t)units * L.B, 256);
+        if (tp < 1) tp = 1;
+        if (ipb_env <= 0 && l->opt_img_fast)
+          while (tp < L.B && (rb_div_up(L.B, tp) % 8 != 0 || L.B % tp != 0)) ++tp;
+        a.ipb = tp;
+        const unsigned ng = (unsigned)rb_div_up(L.B, tp);
+        a.img_fast = (l->opt_img_fast && L.B % tp == 0 && ng % 8 == 0) ? 1 : 0;
+        const dim3 gt = a.img_fast ? dim3(ng, (unsigned)rb_div_up(c.cin, 32), (unsigned)(G::S * G::S))
+                                   : dim3((unsigned)(G::S * G::S), (unsigned)rb_div_up(c.cin, 32), ng);
+        RB_LAUNCH_T(tags[layer], (k_conv_dx_t16_multi<G, 64, lazy>), gt, dim3(64 * ConvDxT16<G, 64>::NWV), stream, a);
+        RB_LAUNCH_CHECK();
+        return RB_OK;
+      }
     }
     if (ipb > 1) { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, lazy, true>), grid, dim3(RB_CONV_THREADS), stream, a); }
     else { RB_LAUNCH_T(tags[layer], (k_conv_dx_lds<G, NT, 64, lazy, false>), grid, dim3(RB_CONV_THREADS), stream, a); }
@@ -1425,6 +1455,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->fast_conv = (L.hist <= 4 && generic != 1) ? 1 : 0;
   l->opt_conv_multi = rb_opt("conv_multi", -1);       // images per workgroup of the conv forward (-1: by image count)
   l->opt_conv_multi_t16 = rb_opt("conv_multi_t16", 1);    // the image loop on whole-K 16x16x4 tiles (0: the split-K body)
+  l->opt_dx_t16 = rb_opt("dx_t16", 1);                    // the image-loop conv data gradient on whole-K 16x16x4 tiles (0: the split-K body)
   l->opt_finish_tiled = rb_opt("finish_tiled", 1);        // rb_learner_finish_grads: the hidden layer's replica-mean weight gradient on 128 x 128 tiles
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
@@ -1871,7 +1902,8 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
         if (!l->conv_wT[layer]) continue;
         const ConvLayer& c = L.conv[layer];
         const int tmax = (c.ks + c.s - 1) / c.s;
-        tn.job[n_jobs++] = ConvWtJob{on.conv_w[layer], l->conv_wT[layer], c.cin, c.cout, c.ks, c.s, (int)rb_div_up(c.cout * tmax * tmax, 16) * 16};
+        tn.job[n_jobs++] = ConvWtJob{on.conv_w[layer], l->conv_wT[layer], c.cin, c.cout, c.ks, c.s, (int)rb_div_up(c.cout * tmax * tmax, 16) * 16,
+                                     dx_uses_t16(l, layer) ? 1 : 0};
       }
       if (n_jobs == 1) tn.job[1] = tn.job[0];
       tn.per_job = n_jobs > 0 ? 48 : 0;                  // (one element or two per thread: the tenants must stay shorter than the head)

@@ -82,13 +82,14 @@ def test_conv_forward_tile_variants_match_golden(emu, monkeypatch, t16):
 @pytest.mark.parametrize("name,steps,full,t16", [("dataeff", None, "1", 1), ("canon", 1, "1", 1), ("canon", 1, "0", 1), ("canon", 1, "1", 0)])
 def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, full, t16):
     """Large batches run the conv forward and data-gradient kernels with one weight slab per workgroup and a loop over
-    images (k_conv_fwd_multi_t16 — whole-K 16x16x4 tiles, round 6 — or, conv_multi_t16=0, the split-K k_conv_fwd_multi;
+    images (k_conv_fwd_multi_t16 / k_conv_dx_t16_multi — whole-K 16x16x4 tiles, round 6 — or, t16 = 0, the split-K k_conv_fwd_multi /
     k_conv_dx_lds<..., MULTI>); RB_OPTS conv_multi / dx_ipb force those paths (ragged: neither divides the batch; the group of 5
     that holds the last online and the first target image re-stages its slab) on the small fixtures, with the last layer's dY
     formed from the row-split partials in the loop."""
     # dx_ipb / conv_multi: ragged image groups in the input-gradient and forward kernels; conv_full: the first layer's
     # whole-image kernel (k_conv_fwd_full) or, 0, the one-image kernel
-    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s,conv_multi_t16=%d" % (full, t16))
+    # (t16 = 0: the split-K bodies of both the forward and the data gradient; 1: k_conv_fwd_multi_t16 / k_conv_dx_t16_multi)
+    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s,conv_multi_t16=%d,dx_t16=%d" % (full, t16, t16))
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=steps)
     golden = load_golden("learn_%s.npz" % name)
