@@ -1063,8 +1063,18 @@ template <class G, int KMAX>
 struct ConvFwdFullLds {
   static constexpr int KPAD = (KMAX + 1) / 2 * 2;
   static constexpr int CMAX = KMAX / G::KK;
-  static constexpr int FLOATS = KPAD * 33 + CMAX * G::IP;
   static constexpr int NTILES = (G::P + 31) / 32;
+  // TAIL16: the last 32-position tile holds at most 16 positions and 12 full tiles precede it (the canonical first layer: 400 =
+  // 12 * 32 + 16).  As a 13th 32x32 tile it gave ONE SIMD four tiles and the others three (waves w and w + 4 share a SIMD).  It
+  // runs instead as four 16x16x4 units — (channel half, reduction half), one on each of waves 4..7, i.e. one per SIMD — whose
+  // two reduction halves meet through 4 KB of LDS behind the end-of-image barrier: 3.25 tiles per SIMD instead of 4 / 3 / 3 / 3.
+#if defined(RB_NO_TAIL16)      // (variant build for A/B runs)
+  static constexpr bool TAIL16 = false;
+#else
+  static constexpr bool TAIL16 = (G::P % 32) != 0 && (G::P % 32) <= 16 && NTILES == 13 && RB_CONV_WAVES == 8 && (G::KS % 4) == 0 && (CMAX % 2) == 0;
+#endif
+  static constexpr int TAILF = TAIL16 ? 4 * 4 * 64 : 0;
+  static constexpr int FLOATS = KPAD * 33 + CMAX * G::IP + TAILF;
   static constexpr bool FITS = FLOATS * 4 <= 160 * 1024 && NTILES <= 2 * RB_CONV_WAVES && (G::IP % 16) == 0;
 };
 template <class G, int KMAX>
@@ -1074,6 +1084,10 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
   __shared__ __attribute__((aligned(16))) float s_all[SZ::FLOATS];
   float* s_w = s_all;
   float* s_patch = s_all + KPAD * 33;
+  float* s_tail = s_all + KPAD * 33 + CMAX * G::IP;    // TAIL16: [unit][4][64] partial tiles
+  (void)s_tail;
+  constexpr bool TAIL16 = SZ::TAIL16;
+  constexpr int FT = TAIL16 ? NTILES - 1 : NTILES;     // tiles that run as 32x32 tiles
 
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
 #if defined(RB_STAMP)
@@ -1123,7 +1137,11 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
   };
 
   const int kh = lane >> 5, ml = lane & 31;
-  const bool two = wave + RB_CONV_WAVES < NTILES;                       // wave-uniform: a second tile
+  const bool two = wave + RB_CONV_WAVES < FT;                           // wave-uniform: a second tile
+  // TAIL16 unit of waves 4..7: channel half ct, reduction half kh2; lane (x, kq) = (position / channel row, k slot)
+  const int tu = wave - 4, tct = tu & 1, tkh = (tu >> 1) & 1, tx = lane & 15, tkq = lane >> 4;
+  float tbias[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  (void)tct; (void)tkh; (void)tx; (void)tkq;
   int noff[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -1142,6 +1160,13 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
       for (int r = 0; r < 16; ++r) {
         const int m = rb_mfma_row(r, lane);
         bias_r[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+      }
+      if constexpr (TAIL16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = tct * 16 + 4 * tkq + r;
+          tbias[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+        }
       }
     }
     RB_FSTAMP(img == img0 ? 57 : 58);
@@ -1204,6 +1229,27 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
         }
       }
     }
+    if constexpr (TAIL16) {
+      if (wave >= 4) {                                  // wave-uniform
+        constexpr int CH = CMAX / 2;                    // channels per reduction half
+        int p = (NTILES - 1) * 32 + tx;
+        if (p > G::P - 1) p = G::P - 1;                 // clamped lanes are never stored
+        // k = c * KK + 4 j + kq: KS % 4 == 0, so the slot kq stays inside a kernel row — it goes into the base pointers and a
+        // step's offsets are immediates, as in the 32x32 loops above
+        const float* pb = s_patch + tkh * CH * G::IP + (p / G::OH) * G::S * G::IH + (p % G::OH) * G::S + tkq;
+        const float* wp = s_w + (tkh * CH * G::KK + tkq) * 33 + tct * 16 + tx;
+        rb_f32x4 tacc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tacc[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int j = 0; j < G::KK / 4; ++j)
+            tacc = rb_mfma16(wp[(c * G::KK + 4 * j) * 33], pb[c * G::IP + rb_patch_off<G>(4 * j)], tacc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_tail[(tu * 4 + r) * 64 + lane] = tacc[r];
+      }
+    }
     RB_FSTAMP(img == img0 ? 50 : 54);
     // epilogue straight from the accumulators: row r of the tile is output channel rb_mfma_row(r, lane), 32 consecutive
     // positions per half-wave (contiguous in the NCHW activation)
@@ -1218,6 +1264,19 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_fwd_full(ConvLdsFwdArg
     }
     RB_FSTAMP(img == img0 ? 51 : 55);
     __syncthreads();            // every wave is done reading this image before the next one is committed
+    if constexpr (TAIL16) {
+      // the tail tile: reduction half 0 + half 1 (fixed order), bias, ReLU — waves 4 and 5, one channel half each.  The scratch
+      // is written again only behind the next image's commit barrier.
+      if (wave == 4 || wave == 5) {
+        const int p = (NTILES - 1) * 32 + tx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = tct * 16 + 4 * tkq + r;
+          const float v = s_tail[(tu * 4 + r) * 64 + lane] + s_tail[((tu + 2) * 4 + r) * 64 + lane];
+          if (m < a.cout && p < G::P) outi[m * G::P + p] = fmaxf(v + tbias[r], 0.0f);
+        }
+      }
+    }
     RB_FSTAMP(img == img0 ? 52 : 56);
   }
 }
