@@ -167,9 +167,20 @@ struct ConvFwdWaves {
   // puts 3 waves on two SIMDs, and the compiler, which sizes the register allocation for the AVERAGE waves per SIMD its LDS
   // footprint allows (next_free_vgpr is raised to the smallest count that still gives that occupancy), then leaves no room
   // for the second workgroup the LDS would admit (profiles/round4_experiments.txt §5); the spare waves help staging and leave
-  static constexpr int TILE_WAVES = T16 == 1 ? 2 * PT : PT;
+  // SPLIT_LAST (a wave per (position tile, channel tile) unit, 2 PT = 4 n + 2 units: the first layer's 80-position chunks, ten
+  // units): waves w, w + 4, w + 8 share a SIMD, so two SIMDs multiplied for three units and two for two — and with two such
+  // workgroups per CU those SIMDs' MFMAs were the launch's critical path.  The last two units run instead as four half-units
+  // (unit, reduction half) on four waves, one per SIMD; the halves meet through 4 KB of LDS: 2.5 units per SIMD.
+#if defined(RB_NO_SPLIT_LAST)    // (variant build for A/B runs)
+  static constexpr bool SPLIT_LAST = false;
+#else
+  static constexpr bool SPLIT_LAST = T16 == 1 && PT >= 3 && ((2 * PT) % 4) == 2 && ((KMAX / 4) % 8) == 0;
+#endif
+  static constexpr int TILE_WAVES = T16 == 1 ? (SPLIT_LAST ? 2 * PT + 2 : 2 * PT) : PT;
+  static constexpr int PARTF = SPLIT_LAST ? 4 * 4 * 64 : 0;   // floats of LDS behind ConvFwdLdsSize::FLOATS for the half-units' partial tiles
   static constexpr int NWV = T16 == 0 ? RB_CONV_WAVES : (TILE_WAVES + 3) / 4 * 4;
 };
+template <int V> struct rb_conv_int_c { static constexpr int value = V; };
 template <class G, int KMAX, int PLANE, int RP, int SUB>
 __device__ __forceinline__ constexpr int rb_t16_off(int j) {            // step j of a lane's K quarter -> offset in the patch
   return (j / G::KK) * PLANE + ((j % G::KK) / G::KS) * RP + (((j % G::KK) % G::KS) % G::S) * SUB + ((j % G::KK) % G::KS) / G::S;
@@ -481,9 +492,63 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     // CTW channel tiles per wave: 1 = a wave per (position tile, channel tile); 2 = a wave per position tile, both channel
     // tiles of the slab from ONE patch operand per step (the first layer: five waves instead of ten per workgroup)
     constexpr int PT = (PCH + 15) / 16, KQ = KMAX / 4, CQ = CMAX / 4, CTW = T16;
+    constexpr bool SPLIT_LAST = ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, T16>::SPLIT_LAST;
+    static_assert(!SPLIT_LAST || ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, T16>::TILE_WAVES == NWV, "SPLIT_LAST: every wave reaches the barrier");
     if (wave >= ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, F32SRC, T16>::TILE_WAVES) return;   // spare staging waves (no barrier follows)
-    const int pt = wave % PT, ct0 = (wave / PT) * CTW;      // wave-uniform: position tile, first channel tile
     const int x = lane & 15, kq = lane >> 4;
+    if constexpr (SPLIT_LAST) {
+      if (wave >= 2 * PT - 2) {                           // wave-uniform: a half-unit
+        float* s_part = smem + SZ::FLOATS;                // [half-unit][4][64]
+        const int tu = wave - (2 * PT - 2), unit = 2 * PT - 2 + (tu & 1), kh2 = tu >> 1;
+        const int upt = unit % PT, ct = unit / PT;
+        int p = p0 + upt * 16 + x;
+        const bool pv = p < G::P && p < p0 + PCH;
+        if (p > G::P - 1) p = G::P - 1;
+        const float* bp = s_patch + kq * CQ * PLANE + (p / G::OH - oy0) * G::S * RP + (p % G::OH);
+        const float* ap = s_w + (ct * 16 + x) * WS + kq * KQ;
+        rb_f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+        auto half = [&](auto h_c) {                        // the lane's steps [h KQ / 2, (h + 1) KQ / 2) of its quarter: immediates again
+          constexpr int H = decltype(h_c)::value;
+#pragma unroll
+          for (int jq = H * (KQ / 8); jq < (H + 1) * (KQ / 8); ++jq) {
+            const float4 w4 = rb_ld4(ap + 4 * jq);
+            acc = rb_mfma16(w4.x, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 0)], acc);
+            acc = rb_mfma16(w4.y, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 1)], acc);
+            acc = rb_mfma16(w4.z, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 2)], acc);
+            acc = rb_mfma16(w4.w, bp[rb_t16_off<G, KMAX, PLANE, RP, SUB>(4 * jq + 3)], acc);
+          }
+        };
+        if (kh2 == 0) half(rb_conv_int_c<0>()); else half(rb_conv_int_c<1>());
+        float bias1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = cout0 + ct * 16 + 4 * kq + r;
+          bias1[r] = a.bias[net][m < a.cout ? m : a.cout - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_part[(tu * 4 + r) * 64 + lane] = acc[r];
+        __syncthreads();                                  // (the other waves meet it behind their own epilogue, below)
+        if (kh2 == 0) {                                   // first half + second half, bias, ReLU
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = cout0 + ct * 16 + 4 * kq + r;
+            if (pv && m < a.cout) {
+              const float o = fmaxf((s_part[(tu * 4 + r) * 64 + lane] + s_part[((tu + 2) * 4 + r) * 64 + lane]) + bias1[r], 0.0f);
+              a.out[((int64_t)img * a.cout + m) * G::P + p] = o;
+              if (a.out_blocked) {
+                const int k = m * G::P + p;
+                a.out_blocked[((int64_t)(k >> 4) * a.rows_total + img) * 16 + (k & 15)] = o;
+              }
+            }
+          }
+        }
+        RB_WGT(WK, wgi, 4); RB_WGT(WK, wgi, 5); RB_WGT(WK, wgi, 6);
+        return;
+      }
+    }
+    const int pt = wave % PT, ct0 = (wave / PT) * CTW;      // wave-uniform: position tile, first channel tile
     int p = p0 + pt * 16 + x;
     const bool pv = p < G::P && p < p0 + PCH;
     if (p > G::P - 1) p = G::P - 1;                   // clamped lanes are never stored
@@ -538,6 +603,7 @@ __device__ __forceinline__ void rb_conv_fwd_body(const ConvLdsFwdArgs& a, int bx
     RB_CSTAMP_LAST(SB + 5);
     RB_WGT(WK, wgi, 5);
     RB_WGT(WK, wgi, 6);
+    if constexpr (SPLIT_LAST) __syncthreads();            // the split tile's waves exchange their halves behind this barrier
     return;
   }
   // ---- MFMA loop: wave w owns k in [w*KW, (w+1)*KW) of the padded reduction (weights beyond K are zero)
@@ -644,7 +710,7 @@ __global__ __launch_bounds__(RB_CONV_THREADS, (ConvFwdLdsSize<G, NT, PR, KMAX>::
 template <class G, int NT, int PR, int KMAX, bool FIRST, int PCH = 32 * NT, int CTW = 1>
 __global__ __launch_bounds__((64 * ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, CTW>::NWV))
 void k_conv_fwd_t16(ConvLdsFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, CTW>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[ConvFwdLdsSize<G, NT, PR, KMAX, CTW>::FLOATS + ConvFwdWaves<G, NT, PR, KMAX, FIRST, PCH, false, CTW>::PARTF];
   if (a.img_fast) rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, false, CTW>(a, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
   else rb_conv_fwd_body<G, NT, PR, KMAX, FIRST, PCH, false, CTW>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
