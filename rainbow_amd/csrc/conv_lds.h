@@ -2065,7 +2065,7 @@ struct ConvDwAllArgs {
   int nblocks[3];          // workgroups of each layer
   int cotiles[3];
   int batch;
-  int ipb;                 // images summed per workgroup
+  int ipb[3];              // images summed per workgroup, per layer (the layers' workgroups cost differently: learner.hip conv_dw_all)
   int img_fast;            // decode with the image group as the FASTEST index (see k_conv_fwd_lds): needs block ranges and group
                            // counts that are multiples of 8
 };
@@ -2081,29 +2081,29 @@ __global__ __launch_bounds__(RB_CONV_THREADS) void k_conv_dw_all(ConvDwAllArgs a
   if (b < a.nblocks[0]) {                              // decode: chunk fastest, then cout tile, then image
     constexpr int CH = (G0::OH + RC0 - 1) / RC0;
     if (a.img_fast) {
-      const int ng = (a.batch + a.ipb - 1) / a.ipb, rest = b / ng;
-      rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], rest % CH, rest / CH, b % ng, CH, a.ipb, a.batch, smem);
+      const int ng = (a.batch + a.ipb[0] - 1) / a.ipb[0], rest = b / ng;
+      rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], rest % CH, rest / CH, b % ng, CH, a.ipb[0], a.batch, smem);
     } else
-    rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], b % CH, (b / CH) % a.cotiles[0], b / (CH * a.cotiles[0]), CH, a.ipb, a.batch, smem);
+    rb_conv_dw_body<G0, RC0, 4 * G0::KK, true>(a.layer[0], b % CH, (b / CH) % a.cotiles[0], b / (CH * a.cotiles[0]), CH, a.ipb[0], a.batch, smem);
     return;
   }
   b -= a.nblocks[0];
   if (b < a.nblocks[1]) {
     constexpr int CH = (G1::OH + RC1 - 1) / RC1;
     if (a.img_fast) {
-      const int ng = (a.batch + a.ipb - 1) / a.ipb, rest = b / ng;
-      rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], rest % CH, rest / CH, b % ng, CH, a.ipb, a.batch, smem);
+      const int ng = (a.batch + a.ipb[1] - 1) / a.ipb[1], rest = b / ng;
+      rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], rest % CH, rest / CH, b % ng, CH, a.ipb[1], a.batch, smem);
     } else
-    rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], b % CH, (b / CH) % a.cotiles[1], b / (CH * a.cotiles[1]), CH, a.ipb, a.batch, smem);
+    rb_conv_dw_body<G1, RC1, K1, false>(a.layer[1], b % CH, (b / CH) % a.cotiles[1], b / (CH * a.cotiles[1]), CH, a.ipb[1], a.batch, smem);
     return;
   }
   if (NL > 2) {
     b -= a.nblocks[1];
     constexpr int CH = (G2::OH + RC2 - 1) / RC2;
     if (a.img_fast) {
-      const int ng = (a.batch + a.ipb - 1) / a.ipb, rest = b / ng;
-      rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], rest % CH, rest / CH, b % ng, CH, a.ipb, a.batch, smem);
+      const int ng = (a.batch + a.ipb[2] - 1) / a.ipb[2], rest = b / ng;
+      rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], rest % CH, rest / CH, b % ng, CH, a.ipb[2], a.batch, smem);
     } else
-    rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], b % CH, (b / CH) % a.cotiles[2], b / (CH * a.cotiles[2]), CH, a.ipb, a.batch, smem);
+    rb_conv_dw_body<G2, RC2, K2, false>(a.layer[2], b % CH, (b / CH) % a.cotiles[2], b / (CH * a.cotiles[2]), CH, a.ipb[2], a.batch, smem);
   }
 }

@@ -163,7 +163,7 @@ struct rb_learner {
   int lazy_splits;
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
-  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled;
+  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   int opt_implicit_small;
@@ -1266,10 +1266,35 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   const Layout& L = l->L;
   ConvDwAllArgs a;
   a.batch = L.B;
-  a.ipb = L.B > 32 ? (int)rb_div_up(L.B, 32) : 1;      // keep about 32 image groups: the slice count stays at its batch-32 size
-  const int groups = (int)rb_div_up(L.B, a.ipb);
+  const int ipb_all = L.B > 32 ? (int)rb_div_up(L.B, 32) : 1;      // keep about 32 image groups: the slice count stays at its batch-32 size
+  bool uniform = true;
   unsigned total = 0;
+  for (int i = 0; i < 3; ++i) a.ipb[i] = ipb_all;
+  // Batches beyond 32, the canonical stack: images per workgroup chosen PER LAYER.  A workgroup walks its images one after the other
+  // and the layers' images cost differently (7.5 / 7.4 / 6.2 us per image at batch 256, tools/wg_timeline.py): with 8 images
+  // everywhere the launch was 224 workgroups of 60 / 59 / 50 us on 256 CUs; 7 / 7 / 8 images are 249 workgroups of 52 / 52 / 50 us
+  // (-7.6 us per step, profiles/round6_dw_layer_ipb_ab.txt).  Smallest longest workgroup that still fits ONE round over the CUs.
+  if (L.B > 32 && L.nconv == 3 && l->opt_dw_balance) {
+    const int cost[3] = {75, 74, 62};
+    const int chunks0 = (L.conv[0].oh + 6) / 7, ct[3] = {(int)rb_div_up(L.conv[0].cout, 32), (int)rb_div_up(L.conv[1].cout, 32), (int)rb_div_up(L.conv[2].cout, 32)};
+    int best_t = ipb_all * cost[0], best[3] = {ipb_all, ipb_all, ipb_all};
+    for (int i0 = 1; i0 <= ipb_all; ++i0)
+      for (int i1 = 1; i1 <= ipb_all + 4; ++i1)
+        for (int i2 = 1; i2 <= ipb_all + 4; ++i2) {
+          const int wgs = chunks0 * ct[0] * (int)rb_div_up(L.B, i0) + ct[1] * (int)rb_div_up(L.B, i1) + ct[2] * (int)rb_div_up(L.B, i2);
+          if (wgs > l->n_cu) continue;
+          int t = i0 * cost[0];
+          if (i1 * cost[1] > t) t = i1 * cost[1];
+          if (i2 * cost[2] > t) t = i2 * cost[2];
+          if (t < best_t) { best_t = t; best[0] = i0; best[1] = i1; best[2] = i2; }
+        }
+    for (int i = 0; i < 3; ++i) a.ipb[i] = best[i];
+  }
   for (int i = 0; i < L.nconv; ++i) {
+    if (l->opt_dw_ipb[i] > 0) a.ipb[i] = l->opt_dw_ipb[i];
+    if (a.ipb[i] > L.B) a.ipb[i] = L.B;
+    if (a.ipb[i] != ipb_all) uniform = false;
+    const int groups = (int)rb_div_up(L.B, a.ipb[i]);
     const ConvLayer& c = L.conv[i];
     ConvLdsDwArgs& d = a.layer[i];
     d.cin = c.cin; d.cout = c.cout; d.dy = l->dact[i]; d.part = l->dw_part[i];
@@ -1288,7 +1313,7 @@ static int conv_dw_all(rb_learner* l, hipStream_t stream) {
   for (int i = L.nconv; i < 3; ++i) { a.nblocks[i] = 0; a.cotiles[i] = 1; a.layer[i] = a.layer[0]; }
   // image-fastest decode (an image group's workgroups of every layer on XCD group mod 8, where the input-gradient chain left
   // its dY): block ranges and the group count must be multiples of 8
-  a.img_fast = (l->opt_img_fast && groups % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
+  a.img_fast = (l->opt_img_fast && uniform && (int)rb_div_up(L.B, ipb_all) % 8 == 0 && a.nblocks[0] % 8 == 0 && a.nblocks[1] % 8 == 0) ? 1 : 0;
   // (a pipelined body — two operand sets in LDS, the next image's loads in flight under this image's MFMAs — was built in round 5,
   // bit-identical, and measured SLOWER at batch 256: 75.9 against 64.5 us for this launch, profiles/round5_experiments.txt; removed)
   if (L.nconv == 3) {
@@ -1458,6 +1483,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_dx_t16 = rb_opt("dx_t16", 1);                    // the image-loop conv data gradient on whole-K 16x16x4 tiles (0: the split-K body)
   l->opt_finish_tiled = rb_opt("finish_tiled", 1);        // rb_learner_finish_grads: the hidden layer's replica-mean weight gradient on 128 x 128 tiles
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
+  l->opt_dw_balance = rb_opt("dw_balance", 1);         // 0: the same number of images per workgroup in every layer of the weight-gradient launch
+  l->opt_dw_ipb[0] = rb_opt("dw_ipb0", 0); l->opt_dw_ipb[1] = rb_opt("dw_ipb1", 0); l->opt_dw_ipb[2] = rb_opt("dw_ipb2", 0);
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);

@@ -89,7 +89,8 @@ def test_multi_image_conv_kernels_match_golden(emu, monkeypatch, name, steps, fu
     # dx_ipb / conv_multi: ragged image groups in the input-gradient and forward kernels; conv_full: the first layer's
     # whole-image kernel (k_conv_fwd_full) or, 0, the one-image kernel
     # (t16 = 0: the split-K bodies of both the forward and the data gradient; 1: k_conv_fwd_multi_t16 / k_conv_dx_t16_multi)
-    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s,conv_multi_t16=%d,dx_t16=%d" % (full, t16, t16))
+    # dw_ipb<layer>: images summed per workgroup of the weight-gradient launch, chosen per layer at large batches (ragged here too)
+    monkeypatch.setenv("RB_OPTS", "dx_ipb=3,conv_multi=5,conv_full=%s,conv_multi_t16=%d,dx_t16=%d,dw_ipb0=3,dw_ipb1=2,dw_ipb2=5" % (full, t16, t16))
     ad = CAbiLearnAdapter(emu, NumpyMem(), name)
     trace = scenarios.learn_scenario(ad, name, O, steps=steps)
     golden = load_golden("learn_%s.npz" % name)

@@ -62,6 +62,24 @@ for k in range(8):
     uniq, cnt = np.unique(cu, return_counts=True)
     print("   ran on %d distinct CUs; workgroups per CU: max %d, mean %.2f" % (len(uniq), cnt.max(), cnt.mean()))
 
+# the weight-gradient launch by layer (block ranges: layer 0 first): whole-workgroup durations and end times
+rows5 = a[5]
+n5 = int((rows5[:, 0] > 0).sum())
+if n5:
+    B = cfg["batch_size"]
+    ipb = max(1, -(-B // 32)) if B > 32 else 1
+    groups = -(-B // ipb)
+    nb = [3 * groups, 2 * groups, 2 * groups] if cfg.get("architecture", "canonical") == "canonical" else [n5, 0, 0]
+    t0 = rows5[:n5, 0].min()
+    lo = 0
+    for li, n in enumerate(nb):
+        r = rows5[lo:lo + n]; lo += n
+        r = r[r[:, 0] > 0]
+        if len(r):
+            print("conv_dw layer %d: %3d workgroups; start median +%.2f | end median +%.2f last +%.2f | duration median %.2f max %.2f us"
+                  % (li, len(r), np.median(r[:, 0] - t0) * 0.01, np.median(r[:, 6] - t0) * 0.01, (r[:, 6].max() - t0) * 0.01,
+                     np.median(r[:, 6] - r[:, 0]) * 0.01, (r[:, 6] - r[:, 0]).max() * 0.01))
+
 # conv1: which workgroups pay the long input stage?  (wg index = img * 16 + cotile * 8 + chunk)
 rows_all = a[0]
 idx = np.nonzero(rows_all[:, 0] > 0)[0]
