@@ -163,7 +163,7 @@ struct rb_learner {
   int lazy_splits;
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
-  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance;
+  int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance, opt_wt_blocks;
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   int opt_implicit_small;
@@ -588,22 +588,60 @@ __global__ __launch_bounds__(RB_HEAD_THREADS) void k_head(int B, int Z, int A, c
   // b is monotone in the atom index (support increasing, nt*gamma^n >= 0), so equal l (and equal u) form
   // contiguous runs: the first atom of a run owns its bin and adds the run left to right — exactly the order of
   // the reference's first index_add_ (all l bins, j ascending) followed by the second (u bins) on the same m.
+  // The run's adds are inherently serial (float adds in the reference's order), but their OPERANDS need not be: walking the run with
+  // `jj < Z && s_l[jj] == key` made every atom two dependent LDS round trips (~130 cycles), fine for the usual one to three atoms per
+  // bin, 2 x 51 steps = 7 us for a TERMINAL transition, whose atoms all land in one bin — and with 256 samples per batch there is
+  // almost always one: the launch was 12 us for 5.4 us workgroups (profiles/round6_wg_timeline_b256.txt).  For Z <= 64 the run lengths
+  // come from one ballot of the run starts, and an owner fetches its run eight atoms per round trip, then adds them in order.
+#if defined(RB_HEAD_NO_SCAN)      // (variant build for A/B runs)
+  const bool by_ballot = false;
+#else
+  const bool by_ballot = Z <= 64;
+#endif
+  auto scatter_runs = [&](const int* s_key, const float* s_x, bool second) {      // wave 0, lane = atom
+    const bool valid = lane < Z;
+    const int key = s_key[valid ? lane : Z - 1];
+    const int prev = __shfl_up(key, 1);
+    const bool start = valid && (lane == 0 || prev != key);
+    const unsigned long long starts = __ballot(start ? 1 : 0);
+    const unsigned long long rest = lane < 63 ? starts >> (lane + 1) : 0ull;       // run starts behind this atom
+    const int len = rest ? __builtin_ctzll(rest) + 1 : Z - lane;                   // atoms of the run that starts here
+    if (start) {
+      float acc = second ? s_m[key] : 0.0f;
+      for (int i0 = 0; i0 < len; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int jj = lane + i0 + u; v[u] = s_x[jj < Z ? jj : Z - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = i0 + u < len ? acc + v[u] : acc;
+      }
+      s_m[key] = acc;
+    }
+  };
   {
-    for (int j = t; j < Z; j += T) {
-      const int key = s_l[j];
-      if (j == 0 || s_l[j - 1] != key) {
-        float acc = 0.0f;
-        for (int jj = j; jj < Z && s_l[jj] == key; ++jj) acc += s_lo[jj];
-        s_m[key] = acc;
+    if (by_ballot) {
+      if (wave == 0) scatter_runs(s_l, s_lo, false);
+    } else {
+      for (int j = t; j < Z; j += T) {
+        const int key = s_l[j];
+        if (j == 0 || s_l[j - 1] != key) {
+          float acc = 0.0f;
+          for (int jj = j; jj < Z && s_l[jj] == key; ++jj) acc += s_lo[jj];
+          s_m[key] = acc;
+        }
       }
     }
     __syncthreads();
-    for (int j = t; j < Z; j += T) {
-      const int key = s_u[j];
-      if (j == 0 || s_u[j - 1] != key) {
-        float acc = s_m[key];
-        for (int jj = j; jj < Z && s_u[jj] == key; ++jj) acc += s_hi[jj];
-        s_m[key] = acc;
+    if (by_ballot) {
+      if (wave == 0) scatter_runs(s_u, s_hi, true);
+    } else {
+      for (int j = t; j < Z; j += T) {
+        const int key = s_u[j];
+        if (j == 0 || s_u[j - 1] != key) {
+          float acc = s_m[key];
+          for (int jj = j; jj < Z && s_u[jj] == key; ++jj) acc += s_hi[jj];
+          s_m[key] = acc;
+        }
       }
     }
   }
@@ -1483,6 +1521,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_dx_t16 = rb_opt("dx_t16", 1);                    // the image-loop conv data gradient on whole-K 16x16x4 tiles (0: the split-K body)
   l->opt_finish_tiled = rb_opt("finish_tiled", 1);        // rb_learner_finish_grads: the hidden layer's replica-mean weight gradient on 128 x 128 tiles
   l->opt_conv_full = rb_opt("conv_full", 1);          // first layer's whole-image kernel at large batches
+  l->opt_wt_blocks = rb_opt("wt_blocks", 48);          // tenant workgroups of the head launch per weight-operand job
   l->opt_dw_balance = rb_opt("dw_balance", 1);         // 0: the same number of images per workgroup in every layer of the weight-gradient launch
   l->opt_dw_ipb[0] = rb_opt("dw_ipb0", 0); l->opt_dw_ipb[1] = rb_opt("dw_ipb1", 0); l->opt_dw_ipb[2] = rb_opt("dw_ipb2", 0);
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
@@ -1933,7 +1972,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
                                      dx_uses_t16(l, layer) ? 1 : 0};
       }
       if (n_jobs == 1) tn.job[1] = tn.job[0];
-      tn.per_job = n_jobs > 0 ? 48 : 0;                  // (one element or two per thread: the tenants must stay shorter than the head)
+      tn.per_job = n_jobs > 0 ? l->opt_wt_blocks : 0;                  // (one element or two per thread: the tenants must stay shorter than the head)
     }
     const dim3 hgrid((unsigned)(B + (n_jobs > 0 ? 2 * tn.per_job : 0))), hblock((unsigned)(64 * hwaves));
 #define RB_HEAD_ARGS B, L.Z, L.A, (const float*)l->logits, actions_dev, returns_dev, nonterminals_dev, weights_dev, (const float*)l->support, \
