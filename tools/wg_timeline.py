@@ -115,6 +115,9 @@ for k, nm in ((8, "fc_z_bwd"), (9, "fc_h_bwd")):
             print("   %-10s n %4d  start median +%.2f last +%.2f | end median +%.2f last +%.2f | duration median %.2f max %.2f us"
                   % (rn, len(r), np.median(r[:, 0] - t0) * 0.01, (r[:, 0].max() - t0) * 0.01, np.median(r[:, 6] - t0) * 0.01,
                      (r[:, 6].max() - t0) * 0.01, np.median(r[:, 6] - r[:, 0]) * 0.01, (r[:, 6] - r[:, 0]).max() * 0.01))
+    r2 = rows[(rows[:, 1] == 2) & (rows[:, 6] > 0)]
+    if len(r2) and len(r2) <= 64:
+        print("   dX durations, sorted (us):", " ".join("%.2f" % x for x in sorted((r2[:, 6] - r2[:, 0]) * 0.01)))
     r = rows[(rows[:, 1] == 2) & (rows[:, 6] > 0) & (rows[:, 2] > 0)]
     if len(r):
         d = np.diff(r[:, [0, 2, 3, 4, 5, 6]], axis=1) * 0.01
