@@ -534,12 +534,32 @@ __global__ __launch_bounds__(256) void k_act_fused(ActFusedArgs a) {
   // the hidden layer's row of this wave, requested first thing by every workgroup (requesting it AFTER the first layer's unit
   // in the workgroups that have one measured slower: 35.5 against 33.3 us for the launch)
   if (HQ > 0 && fused && a.phase_lo <= 3 && a.phase_hi > 3) rb_act_fc_prefetch<HQ>(a.h, 4 * wg + wave, hm, hs);
-  int prev = -1;
+  int prev = -1, prev_units = 0;
   RB_WGT(10, wg, 0);                                             // RB_STAMP builds: slot 0 start, slot 1 + phase = end of that phase
   RB_WGT(11, wg, 0);                                             // ... kernel id 11: slot 1 + phase = the phase's wait is over
+  // units of work of a phase (workgroup wg takes units wg, wg + G, ...: it has work iff wg < units)
+  auto units_of = [&](int phase) {
+    if (phase < 3) {
+      const ActConvArgs& c = a.conv[phase];
+      const int tiles = rb_act_conv_tiles(c);
+      return tiles > 0 ? tiles : c.cout * ((c.OH + c.RG - 1) / c.RG);
+    }
+    return phase == 3 ? (a.h.n_rows + 3) / 4 : phase == 4 ? (a.z.n_rows + 3) / 4 : 1;
+  };
   for (int phase = a.phase_lo; phase < a.phase_hi; ++phase) {
     if (phase < 3 && phase >= a.nconv) continue;                 // (two conv layers: phase 2 does not exist)
+    // Only the workgroups WITH work in a phase arrive at its boundary, and only those with work in the next one wait for it
+    // (round 6: the conv phases have 50 / 24 / 16 units, the output layer 90 — with every one of the 256 workgroups arriving and
+    // polling at every boundary, ~200 idle pollers sat on the counter lines the few working workgroups had to get their arrivals
+    // through).  Transitive: a producer of boundary p waited for boundary p - 1 before it produced.
+    const int units = units_of(phase);
+    const bool has_work = wg < units;                            // block-uniform
+#if defined(RB_ACT_ALL_ARRIVE)      // (variant build for A/B runs: every workgroup arrives and waits at every boundary)
     if (prev >= 0) rb_fan_wait(a.ctr + prev * (RB_FAN_SHARDS * RB_FAN_STRIDE), a.epoch * (unsigned)(G / RB_FAN_SHARDS), a.err, a.epoch);
+#else
+    if (prev >= 0 && has_work)
+      rb_fan_wait_first(a.ctr + prev * (RB_FAN_SHARDS * RB_FAN_STRIDE), a.epoch, prev_units < G ? prev_units : G, a.err, a.epoch);
+#endif
     RB_WGT(11, wg, 1 + phase);
     if (phase < 3) {
       const ActConvArgs& c = a.conv[phase];
@@ -577,7 +597,11 @@ __global__ __launch_bounds__(256) void k_act_fused(ActFusedArgs a) {
       rb_head_act_body(a.Z, a.A, lg, a.support, s_mean, s_ev, a.action_out, a.q_out, a.err, a.epoch);
     }
     RB_WGT(10, wg, 1 + phase);
+#if defined(RB_ACT_ALL_ARRIVE)
     if (phase + 1 < a.phase_hi) rb_fan_signal(a.ctr + phase * (RB_FAN_SHARDS * RB_FAN_STRIDE), wg);
-    prev = phase;
+#else
+    if (phase + 1 < a.phase_hi && has_work) rb_fan_signal(a.ctr + phase * (RB_FAN_SHARDS * RB_FAN_STRIDE), wg);
+#endif
+    prev = phase; prev_units = units;
   }
 }

@@ -176,6 +176,28 @@ __device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned t
   __syncthreads();
 #endif
 }
+// The same wait where only the workgroups [0, producers) of the launch arrive at this boundary (shard = index mod 8, so shard s
+// gets (producers - s + 7) / 8 arrivals per launch): `launches` = this launch's number, counters monotonic as above.
+__device__ __forceinline__ void rb_fan_wait_first(const unsigned* counters, unsigned launches, int producers, unsigned* err, unsigned err_tag = 1u) {   // all threads call
+#if defined(RB_HOST_INTERP)
+  __syncthreads();
+  (void)counters; (void)launches; (void)producers; (void)err; (void)err_tag;
+#else
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    const unsigned target = lane < RB_FAN_SHARDS ? launches * (unsigned)((producers - lane + RB_FAN_SHARDS - 1) / RB_FAN_SHARDS) : 0u;
+    unsigned spins = 0;
+    for (;;) {
+      unsigned v = target;
+      if (lane < RB_FAN_SHARDS && lane < producers) v = __hip_atomic_load(counters + lane * RB_FAN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all((int)(v - target) >= 0)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22)) { if (lane == 0) __hip_atomic_store(err, err_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+#endif
+}
 
 // A 4-byte load through a pointer the CALLER knows to be global memory: where a pointer is a runtime choice among several
 // kernel arguments (the three frame sources of the first conv layer) the compiler may fall back to a generic pointer and a FLAT
