@@ -143,7 +143,9 @@ __device__ __forceinline__ void rb_chain_wait(const unsigned* counter, unsigned 
 // counter serialises its arrivals at ~12 ns each (256 workgroups: 3.3-4.4 us per boundary, tools/stamp/act_timeline.py), so
 // the arrivals are SHARDED over 8 counters in 8 different 128-byte lines (shard = workgroup index mod 8, i.e. its XCD) and a
 // waiter reads all eight in one batch.  `counters` = the boundary's 8 x 32 words; per_shard = arrivals per shard and launch.
-#define RB_FAN_SHARDS 8
+#ifndef RB_FAN_SHARDS
+#define RB_FAN_SHARDS 32           // (8 until round 6: with 256 producers — the hidden layer's phase — 32 arrivals per line still took 3 us)
+#endif
 #define RB_FAN_STRIDE 32            // words between shards (128 bytes)
 __device__ __forceinline__ void rb_fan_signal(unsigned* counters, int wg) {           // all threads of the workgroup call
 #if defined(RB_HOST_INTERP)
@@ -162,7 +164,7 @@ __device__ __forceinline__ void rb_fan_wait(const unsigned* counters, unsigned t
   __syncthreads();                                                          // (one launch per phase there: nothing to wait for)
   (void)counters; (void)target_per_shard; (void)err; (void)err_tag;
 #else
-  if (threadIdx.x < 64) {                                                   // wave 0: lanes 0..7 poll one shard each
+  if (threadIdx.x < 64) {                                                   // wave 0: lane s polls shard s
     const int lane = (int)threadIdx.x;
     unsigned spins = 0;
     for (;;) {

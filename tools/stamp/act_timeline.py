@@ -25,8 +25,11 @@ done, past = a[10], a[11]
 sel = done[:, 0] > 0
 t0 = done[sel, 0].min()
 print("workgroups %d, starts: median +%.2f last +%.2f us" % (sel.sum(), np.median(done[sel, 0] - t0) * 0.01, (done[sel, 0].max() - t0) * 0.01))
+# only the workgroups WITH work in a phase wait for / arrive at its boundaries (round 6): the canonical stack's units per phase
+units = [50, 24, 16, 256, (cfg["atoms"] * (cfg["actions"] + 1) + 3) // 4 if "atoms" in cfg else 90, 1]
 for ph, nm in enumerate(["conv1", "conv2", "conv3", "fc_h", "fc_z", "head"]):
-    d, p = done[sel, 1 + ph], past[sel, 1 + ph]
+    w = np.arange(W) < units[ph]
+    d, p = done[sel & w, 1 + ph], past[sel & w, 1 + ph]
     d, p = d[d > 0], p[p > 0]
     if len(d):
         print("%-6s past the wait: first +%.2f median +%.2f last +%.2f | phase done: first +%.2f median +%.2f last +%.2f"
