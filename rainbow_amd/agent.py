@@ -235,6 +235,12 @@ class Agent:
         self._act_pin = torch.zeros(2 * self.batch_size, dtype=torch.int32).pin_memory()     # written by the device
         self._q_pin = torch.zeros(2 * self.batch_size, dtype=torch.float32).pin_memory()
         self._act_np, self._q_np = self._act_pin.numpy(), self._q_pin.numpy()
+        # the single-state path (act / evaluate_q): (action, q) as ONE 8-byte pinned pair — the head stores both with a single
+        # system-scope store (csrc/act_path.h rb_head_act_body) instead of q, a fence, then the action
+        self._aq_pin = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._aq_act = self._aq_pin.numpy()
+        self._aq_q = self._aq_act.view(np.float32)
+        self._aq_ptrs = (self._aq_pin.data_ptr(), self._aq_pin.data_ptr() + 4)
         self._pin_ptrs = None
         self._world = rdist.world_size()
         self._dist = rdist.active()
@@ -348,11 +354,8 @@ class Agent:
         st = state
         if st.dtype != torch.float32 or st.device != self.device or not st.is_contiguous():     # (env.py hands over exactly this)
             st = state.to(device=self.device, dtype=torch.float32).contiguous()
-        act = self._act_np
-        pins = self._pin_ptrs
-        if pins is None or pins[2] is not self._act_pin:
-            pins = self._pin_ptrs = (self._act_pin.data_ptr(), self._q_pin.data_ptr(), self._act_pin)
-        # launch + wait in ONE C call: completion = the pinned action word changes (the head writes q, fences, then the action);
+        pins = self._aq_ptrs
+        # launch + wait in ONE C call: completion = the pinned action word changes (the head writes action and q as one 8-byte word);
         # the library polls it in a compiled loop (a Python loop over a numpy scalar sees the store a microsecond or two late),
         # falls back to a stream synchronise, and retries once when the one-launch path reports an expired in-launch wait
         rc = self._lib.rb_learner_act_wait(self._h, st.data_ptr(), 1 if self.training else 0, pins[0], pins[1], None, None,
@@ -363,7 +366,7 @@ class Agent:
     def act(self, state):
         """agent.py:53-55: greedy action on the expected value of the (noisy) online distribution."""
         self._forward_single(state)
-        return int(self._act_np[0])
+        return int(self._aq_act[0])
 
     def act_batch(self, states):
         """Vectorised actors: `states` f32 [n, h, 84, 84] on the device (processed 2*batch_size at a time).
@@ -389,7 +392,7 @@ class Agent:
     def evaluate_q(self, state):
         """agent.py:110-112."""
         self._forward_single(state)
-        return float(self._q_np[0])
+        return float(self._aq_q[1])
 
     def evaluate_q_batch(self, states, chunk=512):
         """Batched agent.py:110-112: `states` f32 [n, h, 84, 84] on the device -> numpy float32 [n],

@@ -207,8 +207,19 @@ __device__ __forceinline__ void rb_head_act_body(int Z, int A, const float* lg, 
 #else
     if (err && err_epoch != 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_epoch) best = -1;   // a bounded in-launch wait of THIS launch expired: no action
 #endif
+#if !defined(RB_HOST_INTERP) && !defined(RB_ACT_NO_PACK)      // (RB_ACT_NO_PACK: variant build for A/B runs)
+    // (action, q) as ONE aligned 8-byte word where the caller laid them out that way (rainbow_amd/agent.py _forward_single: a pinned
+    // pair): a single system-scope store — both are there when the host sees the action change, and the launch ends one host-memory
+    // round trip earlier than with q, a system-scope fence, then the action (round 6: ~1 us of act()'s 39)
+    if (action_out && q_out && reinterpret_cast<const void*>(q_out) == reinterpret_cast<const void*>(action_out + 1) &&
+        (reinterpret_cast<uintptr_t>(action_out) & 7u) == 0) {
+      const unsigned long long pack = (unsigned long long)(unsigned)best | ((unsigned long long)__builtin_bit_cast(unsigned, bv) << 32);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(action_out), pack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+#endif
     // q BEFORE the action, a system-scope fence in between: a host that polls the (pinned) action word for the value it
-    // preset to change may read q right after (rainbow_amd/agent.py _forward_single)
+    // preset to change may read q right after
     if (q_out) *q_out = bv;
 #if !defined(RB_HOST_INTERP)
     __threadfence_system();
