@@ -282,7 +282,9 @@ int rb_learner_act(rb_learner_t* l, const float* state_dev, int32_t noisy, int32
 /* rb_learner_act for a caller that needs the result on the HOST at once (agent.py:53-55 returns a Python int; main.py:153 feeds it to
  * the emulator): action_pinned / q_pinned are PINNED host words mapped on the device (hipHostMalloc / torch pin_memory); the call
  * presets the action word, launches, polls the word in a compiled loop (falling back to a stream synchronise after ~10 ms) and
- * returns the action and its value through action_out / q_out (either may be NULL).  One call instead of launch + a Python poll loop. */
+ * returns the action and its value through action_out / q_out (either may be NULL).  One call instead of launch + a Python poll loop.
+ * Where q_pinned == (float*)(action_pinned + 1) and action_pinned is 8-byte aligned, the device writes both with ONE 8-byte store
+ * (otherwise: q, a system-scope fence, then the action): rb_learner_act behaves the same way.                                    */
 int rb_learner_act_wait(rb_learner_t* l, const float* state_dev, int32_t noisy, int32_t* action_pinned, float* q_pinned,
                         int32_t* action_out, float* q_out, rb_stream_t stream);
 /* The same for n states at once (vectorised actors; the reference acts on one state per call,
