@@ -105,7 +105,15 @@ def _create_library_comm(lib, dev):
     raw = (C.c_ubyte * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
     comm = C.c_void_p()
     with torch.cuda.device(dev):
-        L.check(lib, lib.rb_comm_create(C.byref(comm), raw, dist.get_world_size(), dist.get_rank()))
+        rc = lib.rb_comm_create(C.byref(comm), raw, dist.get_world_size(), dist.get_rank())
+    # a rank whose communicator could not be created must not leave the others with one: agree, and fall back TOGETHER to the
+    # collective in torch.distributed (the step then costs a torch call more, the results are the same)
+    made = torch.tensor([1 if rc == 0 and comm.value else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(made, op=dist.ReduceOp.MIN)
+    if int(made.item()) == 0:
+        if rc == 0 and comm.value:
+            lib.rb_comm_destroy(comm)
+        return None
     return comm
 
 
