@@ -25,7 +25,7 @@ def main():
     steps = int(os.environ.get("SOAK_STEPS", "60000"))
     cap = int(os.environ.get("SOAK_CAPACITY", "20000"))
     dev = torch.device("cuda", 0)
-    cfg = dict(bench.CONFIGS["pong-canonical-b32"]); cfg["capacity"] = cap
+    cfg = dict(bench.CONFIGS[os.environ.get("SOAK_CONFIG", "pong-canonical-b32")]); cfg["capacity"] = cap
     args = bench.make_args(cfg, dev)
     env = types.SimpleNamespace(action_space=lambda: cfg["actions"])
     torch.manual_seed(3); np.random.seed(3)
