@@ -1102,14 +1102,26 @@ void k_conv_fwd_multi_t16(ConvLdsFwdArgs a) {
       cur ^= 1;
     }
   } else {
+    // RB_STAMP builds (tools/wg_timeline.py, kernel id = layer): slot 0 start, 1 / 3 the first / second image's patch (and slab)
+    // complete, 2 / 4 its tiles done, 6 end
+    const int wgt = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    constexpr int WKM = G::KS == 4 ? 1 : 2;
+    (void)wgt; (void)WKM;
+    RB_WGT(WKM, wgt, 0);
     for (int img = img0; img < img_end; ++img) {
       if (img == img0 || img == a.n_on) stage_slab(img);   // block-uniform (every wave is past the previous image's MFMA loop: the barrier below)
       commit(s_patch);
       __syncthreads();                                // patch (and slab) complete
+      if (img == img0) RB_WGT(WKM, wgt, 1);
+      if (img == img0 + 1) RB_WGT(WKM, wgt, 3);
       if (img + 1 < img_end) issue(img + 1);
       if (tile_wave) tile(img, bp);                   // wave-uniform; the spare waves (NWV is a multiple of 4) only stage
       __syncthreads();                                // every wave is done reading this image's patch (and, at a net change, the slab)
+      if (img == img0) RB_WGT(WKM, wgt, 2);
+      if (img == img0 + 1) RB_WGT(WKM, wgt, 4);
     }
+    RB_WGT(WKM, wgt, 5);
+    RB_WGT(WKM, wgt, 6);
   }
 }
 
