@@ -164,6 +164,7 @@ struct rb_learner {
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
   int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance, opt_wt_blocks;
+  int opt_z_narrow;     // ... on 32-column tiles (rb_nl_dx_body_tall<2>)
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
   int opt_implicit_small;
@@ -1527,6 +1528,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_dx_ipb = rb_opt("dx_ipb", 0);                // images per workgroup of the conv input gradients (0: by batch)
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);
+  l->opt_z_narrow = rb_opt("z_narrow", 1);
   l->opt_t16 = rb_opt("t16", 7);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
   l->opt_implicit_small = rb_opt("implicit_small", 0);   // test hook: RB_LEARNER_IMPLICIT_SIGMA on hidden layers of any size
   l->opt_fc_gemm = rb_opt("fc_gemm", -1);             // hidden layer as LDS-tiled GEMMs (fc_gemm.h): -1 = from 128 rows on
@@ -2036,7 +2038,9 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     // the output layer's input gradient with eight waves per workgroup (noisy_linear.h rb_nl_dx_body_tall) at batch <= 32
     // (RB_OPTS z_tall=0: the four-wave body)
     const int z_tall = (l->opt_z_tall && B <= 32) ? 1 : 0;
-    NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, 64), 1, 2 * (int)rb_div_up(B, 64)};
+    // ... on 32-column tiles (RB_OPTS z_narrow=0: 64-column tiles): twice the workgroups, half the weight bytes through each CU
+    const int z_narrow = (z_tall && l->opt_z_narrow && (L.H % 32) == 0) ? 1 : 0;
+    NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, z_narrow ? 32 : 64), 1, 2 * (int)rb_div_up(B, 64), z_narrow};
     // ---- hidden layer
     NlDxArgs hx;
     hx.dy = l->dh; hx.ldy = 2 * L.H; hx.M = B; hx.w = nl_h(on); hx.K = L.F; hx.n_prob = 1;

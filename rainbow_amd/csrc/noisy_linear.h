@@ -409,6 +409,28 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
 // Non-split launches with M <= 32 only; block = 64 * RB_NL_DXT_WAVES threads.
 #define RB_NL_DXT_WAVES 8        // (16 waves = 1024 threads cap the kernel at 128 registers: the weight-gradient body of the same launch spilled)
 #define RB_NL_DXT_LDS (RB_NL_DXT_WAVES * 32 * 64)
+// CW = columns per lane: 4 = 64-column tiles (16-byte loads), 2 = 32-column tiles (8-byte loads, still one whole 128-byte line per
+// weight row and row-step: twice the workgroups at half the bytes each — the advantage stream's 64-column workgroup pulls 157 KB
+// of mu | sigma through ONE CU, 8.0 us against the value stream's 5.3; RB_OPTS z_narrow).  Same rows per wave, same wave-order sum:
+// an element's value does not depend on CW.
+template <int CW>
+struct RbVec;
+template <> struct RbVec<4> { typedef float4 T; };
+template <> struct RbVec<2> { typedef float2 T; };
+template <int CW>
+__device__ __forceinline__ void rb_ldv(const float* p, float (&v)[CW]) {
+  const typename RbVec<CW>::T t = *reinterpret_cast<const typename RbVec<CW>::T*>(p);
+  v[0] = t.x; v[1] = t.y;
+  if constexpr (CW == 4) { v[2] = t.z; v[3] = t.w; }
+}
+template <int CW>
+__device__ __forceinline__ void rb_stv(float* p, const float (&v)[CW]) {
+  typename RbVec<CW>::T t;
+  t.x = v[0]; t.y = v[1];
+  if constexpr (CW == 4) { t.z = v[2]; t.w = v[3]; }
+  *reinterpret_cast<typename RbVec<CW>::T*>(p) = t;
+}
+template <int CW>
 __device__ __forceinline__ void rb_nl_dx_body_tall(const NlDxArgs& a, int bx, int bz, float* lds) {
   float (*s_red)[32][64] = reinterpret_cast<float (*)[32][64]>(lds);   // [waves][(mt * 4 + e) * 4 + j][lane]
   const int lane = rb_lane(), wave = rb_wave();
@@ -416,7 +438,7 @@ __device__ __forceinline__ void rb_nl_dx_body_tall(const NlDxArgs& a, int bx, in
   const NlDxProblem pr = a.prob[pi];
   const int mt_cnt = (a.M + 15) / 16;                     // <= 2
   const int K = a.K;
-  const int kt = bx * 64;
+  const int kt = bx * (16 * CW);
   const int row_end = pr.row_begin + pr.row_cnt;
   constexpr int ST = 10;                                  // row-steps of 4 rows in flight per wave: 40 rows
   const int per_wave = ((pr.row_cnt + RB_NL_DXT_WAVES - 1) / RB_NL_DXT_WAVES + 3) / 4 * 4;   // rows per wave, multiple of 4
@@ -424,41 +446,51 @@ __device__ __forceinline__ void rb_nl_dx_body_tall(const NlDxArgs& a, int bx, in
   int wr1 = wr0 + per_wave;
   if (wr1 > row_end) wr1 = row_end;
   const int c = lane & 15, q = lane >> 4;
-  int col4 = kt + 4 * c;
-  if (col4 > K - 4) col4 = K - 4;                        // clamped lanes are never stored
-  const float4 e0 = rb_ld4(a.w.ein + pr.ein_off0 + col4);
-  const float4 e1 = rb_ld4(a.w.ein + pr.ein_off1 + col4);
+  int col4 = kt + CW * c;
+  if (col4 > K - CW) col4 = K - CW;                      // clamped lanes are never stored
+  float e0[CW], e1[CW];
+  rb_ldv<CW>(a.w.ein + pr.ein_off0 + col4, e0);
+  rb_ldv<CW>(a.w.ein + pr.ein_off1 + col4, e1);
   // the ReLU mask of this thread's output cells: requested with the operands (in the epilogue: one more dependent trip)
   constexpr int TT = 64 * RB_NL_DXT_WAVES, EIT = (8 * 64 + TT - 1) / TT;     // 8 (mt, e) slots x 64 lanes over the threads
-  float4 msk[EIT];
+  float msk[EIT][CW];
   int64_t oidx[EIT];
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
     const int idx = (int)threadIdx.x + it * TT;            // slot = idx >> 6 over (mt, e), lane = idx & 63
     const int slot = idx >> 6, l = idx & 63;
     const int m = 16 * (slot >> 2) + 4 * (l >> 4) + (slot & 3);
-    int k = kt + 4 * (l & 15);
-    if (k > K - 4) k = K - 4;
+    int k = kt + CW * (l & 15);
+    if (k > K - CW) k = K - CW;
     oidx[it] = (int64_t)(m < a.M ? m : a.M - 1) * a.ld_out + pr.out_off + k;
-    msk[it] = a.mask_src ? rb_ld4(a.mask_src + oidx[it]) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (a.mask_src) rb_ldv<CW>(a.mask_src + oidx[it], msk[it]);
+    else {
+#pragma unroll
+      for (int j = 0; j < CW; ++j) msk[it][j] = 1.0f;
+    }
   }
-  rb_f32x4 acc[2][4];
+  rb_f32x4 acc[2][CW];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < CW; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[mt][j][e] = 0.0f;
   for (int nb = wr0; nb < wr1; nb += 4 * ST) {            // (one pass for up to 320 rows per problem)
-    float4 w4[ST];
+    float w4[ST][CW];
     float av[ST][2];
 #pragma unroll
     for (int st = 0; st < ST; ++st) {
       const int n = nb + 4 * st + q;
       const bool nv = n < wr1;
       const int nc = nv ? n : wr1 - 1;
-      w4[st] = rb_noisy4(rb_ld4(a.w.mu + (int64_t)nc * K + col4), rb_ld4(a.w.sigma + (int64_t)nc * K + col4),
-                         a.w.eout[nc], nc >= pr.ein_split_row ? e1 : e0);
+      float mu[CW], sg[CW];
+      rb_ldv<CW>(a.w.mu + (int64_t)nc * K + col4, mu);
+      rb_ldv<CW>(a.w.sigma + (int64_t)nc * K + col4, sg);
+      const float eo = a.w.eout[nc];
+      const bool second = nc >= pr.ein_split_row;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) w4[st][j] = mu[j] + sg[j] * (eo * (second ? e1[j] : e0[j]));     // rb_noisy4's expression
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int m = 16 * mt + c;
@@ -471,10 +503,8 @@ __device__ __forceinline__ void rb_nl_dx_body_tall(const NlDxArgs& a, int bx, in
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           if (mt < mt_cnt) {
-            acc[mt][0] = rb_mfma16(av[st][mt], w4[st].x, acc[mt][0]);
-            acc[mt][1] = rb_mfma16(av[st][mt], w4[st].y, acc[mt][1]);
-            acc[mt][2] = rb_mfma16(av[st][mt], w4[st].z, acc[mt][2]);
-            acc[mt][3] = rb_mfma16(av[st][mt], w4[st].w, acc[mt][3]);
+#pragma unroll
+            for (int j = 0; j < CW; ++j) acc[mt][j] = rb_mfma16(av[st][mt], w4[st][j], acc[mt][j]);
           }
         }
       }
@@ -485,33 +515,33 @@ __device__ __forceinline__ void rb_nl_dx_body_tall(const NlDxArgs& a, int bx, in
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
+      for (int j = 0; j < CW; ++j) s_red[wave][(mt * 4 + e) * 4 + j][lane] = acc[mt][j][e];
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
     const int idx = (int)threadIdx.x + it * TT;
     const int slot = idx >> 6, l = idx & 63;
     if (slot >= mt_cnt * 4) continue;
-    float4 v;
-    float* vv = &v.x;
+    float vv[CW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CW; ++j) {
       float s = s_red[0][slot * 4 + j][l];
 #pragma unroll
       for (int w = 1; w < RB_NL_DXT_WAVES; ++w) s += s_red[w][slot * 4 + j][l];     // fixed order w0, w1, ...
       vv[j] = s;
     }
     const int m = 16 * (slot >> 2) + 4 * (l >> 4) + (slot & 3);
-    const int k = kt + 4 * (l & 15);
+    const int k = kt + CW * (l & 15);
     if (m < a.M && k < K) {
       if (a.mask_src) {
-        v.x = msk[it].x > 0.0f ? v.x : 0.0f; v.y = msk[it].y > 0.0f ? v.y : 0.0f;
-        v.z = msk[it].z > 0.0f ? v.z : 0.0f; v.w = msk[it].w > 0.0f ? v.w : 0.0f;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) vv[j] = msk[it][j] > 0.0f ? vv[j] : 0.0f;
       }
-      rb_st4(a.out + oidx[it], v);
+      rb_stv<CW>(a.out + oidx[it], vv);
       if (a.outT && a.mask_src) {
         float* ot = a.outT + (int64_t)(pr.out_off + k) * a.M + m;
-        ot[0] = v.x; ot[a.M] = v.y; ot[2 * (int64_t)a.M] = v.z; ot[3 * (int64_t)a.M] = v.w;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) ot[(int64_t)j * a.M] = vv[j];
       }
     }
   }
@@ -857,7 +887,7 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
 // Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in
 // ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
 // the dX tiles.
-struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; };
+struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; int dx_narrow; };   // dx_narrow (TALL only): 32-column input-gradient tiles
 // Optional third tenant of the output layer's backward launch: the sum-tree priority write-back (agent.py:100,
 // memory.py:157-159).  It depends only on (tree indices, per-sample loss), both final before this launch, and is a
 // single-workgroup latency chain — as one more block here it costs nothing on the step's critical path.
@@ -934,7 +964,10 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
   } else {
     const int r = b - ndw;
     RB_SPAN_BEGIN(sb + 2);
-    if constexpr (TALL) rb_nl_dx_body_tall(dx, r % g.dx_x, r / g.dx_x, lds);
+    if constexpr (TALL) {
+      if (g.dx_narrow) rb_nl_dx_body_tall<2>(dx, r % g.dx_x, r / g.dx_x, lds);      // block-uniform
+      else rb_nl_dx_body_tall<4>(dx, r % g.dx_x, r / g.dx_x, lds);
+    }
     else rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     RB_SPAN_END(sb + 2);
     RB_WGT_ROLE(kid, wgb, 2);
