@@ -164,6 +164,7 @@ struct rb_learner {
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
   int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance, opt_wt_blocks;
+  int opt_z_ct, opt_h_ct;   // column tiles per wave of the pipelined weight-gradient body (output / hidden layer)
   int opt_z_narrow;     // ... on 32-column tiles (rb_nl_dx_body_tall<2>)
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
   int opt_t16;          // bit l: conv layer l's forward on the whole-K 16x16x4 kernel (conv_lds.h k_conv_fwd_t16) at small batches
@@ -1529,6 +1530,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_z_narrow = rb_opt("z_narrow", 1);
+  l->opt_z_ct = rb_opt("z_ct", 2); if (l->opt_z_ct < 1) l->opt_z_ct = 1;
+  l->opt_h_ct = rb_opt("h_ct", 4); if (l->opt_h_ct < 1) l->opt_h_ct = 1;
   l->opt_t16 = rb_opt("t16", 7);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
   l->opt_implicit_small = rb_opt("implicit_small", 0);   // test hook: RB_LEARNER_IMPLICIT_SIGMA on hidden layers of any size
   l->opt_fc_gemm = rb_opt("fc_gemm", -1);             // hidden layer as LDS-tiled GEMMs (fc_gemm.h): -1 = from 128 rows on
@@ -1998,7 +2001,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     // sum-of-squares slots (clip_grad_norm_ without re-reading the gradient): [fc_z dW waves | fc_h dW waves | conv reduce blocks]
     // pipelined weight-gradient body (one reduction pass per tile, i.e. batch <= 32): column tiles per wave
     const bool pipe = B <= 32 && !exch;
-    const int z_ct = pipe ? 2 : 0, h_ct = pipe ? 4 : 0;
+    const int z_ct = pipe ? l->opt_z_ct : 0, h_ct = pipe ? l->opt_h_ct : 0;     // (RB_OPTS z_ct / h_ct: 256-column tiles per wave and workgroup)
     FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
     FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, feat, B, h_ct);
     // batch >= 128: the hidden layer's two gradients as LDS-tiled GEMMs in one launch (fc_gemm.h k_fc_gemm_bwd)

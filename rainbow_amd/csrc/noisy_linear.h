@@ -131,6 +131,10 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
     xo[mt] = (unsigned)((((int64_t)(grp.x_off >> 4) * a.rows_total + a.m_base[net] + m) * 16 + 4 * q) * 4);
   }
   const unsigned xstep = (unsigned)a.rows_total * 64u;     // bytes between consecutive 16-wide k chunks of the activations
+  // the epilogue's bias terms (every epilogue cell of a thread is column row0 + (lane & 15)): requested HERE, with the first
+  // operands — in the epilogue they were one more dependent round trip at the end of a 4 us chain (the output layer's launch)
+  const int nb_ = row0 + (lane & 15) < row_end ? row0 + (lane & 15) : row_end - 1;
+  const float b_mu = w.bmu[nb_], b_sg = w.bsigma[nb_], b_eo = w.eout[nb_];
 
   rb_f32x4 acc[MT];
 #pragma unroll
@@ -223,7 +227,11 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
     const int m = m0 + 16 * mt + 4 * (l >> 4) + e;
     const int n = row0 + (l & 15);
     if (m < M && m < m0 + 16 * MT && n < row_end) {
-      float o = v + (w.bmu[n] + w.bsigma[n] * w.eout[n]);                 // model.py:44
+#if defined(RB_NO_BIAS_PRE)                                                 // (A/B build: the loads in the epilogue)
+      float o = v + (w.bmu[n] + w.bsigma[n] * w.eout[n]);
+#else
+      float o = v + (b_mu + b_sg * b_eo);                                 // model.py:44 (n == nb_ for every cell that is stored)
+#endif
       if (a.relu) o = fmaxf(o, 0.0f);
       const int rowi = a.m_base[net] + m;
       a.out[(int64_t)rowi * a.ld_out + n] = o;
