@@ -164,6 +164,8 @@ struct rb_learner {
   // test hooks read ONCE, when the handle is created (RB_OPTS, rb_opts below): they force the large-batch code paths and the
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
   int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance, opt_wt_blocks;
+  int opt_h_dw_deep;    // ... and its weight gradient with all four column tiles' operands in flight (rb_nl_dw_body_pipe_all)
+  int opt_h_deep;       // the hidden layer's input gradient at batch <= 32 with 8 row-steps of loads in flight (rb_nl_dx_body<2, 8>)
   int opt_z_ct, opt_h_ct;   // column tiles per wave of the pipelined weight-gradient body (output / hidden layer)
   int opt_z_narrow;     // ... on 32-column tiles (rb_nl_dx_body_tall<2>)
   int opt_z_tall;       // the output layer's input gradient with 16 waves per workgroup (noisy_linear.h rb_nl_dx_body_tall)
@@ -1530,6 +1532,8 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_img_fast = rb_opt("img_fast", 1);            // image-fastest block order of the conv launches (0: the fallback order)
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_z_narrow = rb_opt("z_narrow", 1);
+  l->opt_h_deep = rb_opt("h_deep", 1);
+  l->opt_h_dw_deep = rb_opt("h_dw_deep", 1);
   l->opt_z_ct = rb_opt("z_ct", 2); if (l->opt_z_ct < 1) l->opt_z_ct = 1;
   l->opt_h_ct = rb_opt("h_ct", 4); if (l->opt_h_ct < 1) l->opt_h_ct = 1;
   l->opt_t16 = rb_opt("t16", 7);                      // conv forward layers on k_conv_fwd_t16 (bit per layer)
@@ -2004,6 +2008,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const int z_ct = pipe ? l->opt_z_ct : 0, h_ct = pipe ? l->opt_h_ct : 0;     // (RB_OPTS z_ct / h_ct: 256-column tiles per wave and workgroup)
     FcDwPlan zp = fc_dw_plan(l, on, 0, l->dlogits, l->h, B, z_ct);
     FcDwPlan hp = fc_dw_plan(l, on, 1, l->dh, feat, B, h_ct);
+    hp.a.deep = l->opt_h_dw_deep;
     // batch >= 128: the hidden layer's two gradients as LDS-tiled GEMMs in one launch (fc_gemm.h k_fc_gemm_bwd)
     const bool gemm_bwd = !exch && l->gemm_part && (l->opt_fc_gemm == 1 || (l->opt_fc_gemm < 0 && B >= 128));
     const int g_nt = (int)rb_div_up(2 * L.H, RB_TG_T), g_kt = (int)rb_div_up(L.F, RB_TG_T);
@@ -2053,7 +2058,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const int hsplits = (int)rb_div_up(2 * L.H, hx.rows_per_split);
     hx.out = l->dfeat_part; hx.ld_out = L.F; hx.mask_src = nullptr;
     hx.dyT = l->dhT; hx.ldyT = B; hx.outT = nullptr;
-    NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : hp.dw_y, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64)};
+    NlBwdGrid hg{exch ? 0 : hp.dw_x, exch ? 0 : hp.dw_y, (int)rb_div_up(L.F, 64), hsplits, (int)rb_div_up(B, 64), (B <= 32 && l->opt_h_deep) ? 1 : 0};
     NlPriorityUpdate up;
     memset(&up, 0, sizeof(up));
     // the write-back leaves this launch for the replay's stream (decided HERE, once: an expiry seen later only affects the next call)

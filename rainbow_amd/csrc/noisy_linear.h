@@ -270,6 +270,11 @@ struct NlDxArgs {
 
 // grid = (64-column tiles, row splits, n_prob * m-chunks of 64), block = 256 (4 waves split the rows)
 #define RB_NL_DX_LDS (2 * 64 * 64)   // floats: two wave tiles (the four waves meet pairwise, see the reduction below)
+// MTC = 16-row m tiles a workgroup can hold (4: 64-row m-chunks; 2: batches of <= 32 — half the accumulators), ST = row-steps of 4
+// weight rows whose loads are in flight together.  <2, 8> (RB_OPTS h_deep, batch <= 32): a wave's 64 rows are TWO dependent load ->
+// MFMA trips instead of four (round6_wg_timeline_b32.txt: first trip 4.6 us, the three behind it 6.4 of the workgroup's 14.6) —
+// the rows enter the accumulators in the same order: an element's bits do not depend on ST.
+template <int MTC, int ST>
 __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by, int bz, float* lds) {
   float (*s_red)[64][64] = reinterpret_cast<float (*)[64][64]>(lds);   // [2][64][64]
   const int lane = rb_lane(), wave = rb_wave();
@@ -277,7 +282,8 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
   const NlDxProblem pr = a.prob[pi];
   const int m0 = mc * 64;
   if (m0 >= a.M) return;
-  const int mt_cnt = (a.M - m0 >= 64) ? 4 : (a.M - m0 + 15) / 16;
+  const int mt_cnt0 = (a.M - m0 >= 64) ? 4 : (a.M - m0 + 15) / 16;
+  const int mt_cnt = mt_cnt0 < MTC ? mt_cnt0 : MTC;      // (the caller picks MTC >= the launch's m tiles)
   const int K = a.K;
   const int kt = bx * 64;
   const int row_end = pr.row_begin + pr.row_cnt;
@@ -295,9 +301,9 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
   const float4 e0 = rb_ld4(a.w.ein + pr.ein_off0 + col4);
   const float4 e1 = rb_ld4(a.w.ein + pr.ein_off1 + col4);
 
-  rb_f32x4 acc[4][4];
+  rb_f32x4 acc[MTC][4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -309,27 +315,27 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
   const int kid_ = a.K > 1000 ? 9 : 8;
   RB_WGT(kid_, (int)blockIdx.x, 2);
 #endif
-  for (int nb = wr0; nb < wr1; nb += 16) {               // 4 row-steps of loads in flight per iteration
-    float4 w4[4];
-    float av[4][4];
+  for (int nb = wr0; nb < wr1; nb += 4 * ST) {           // ST row-steps of loads in flight per iteration
+    float4 w4[ST];
+    float av[ST][MTC];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < ST; ++st) {
       const int n = nb + 4 * st + q;
       const bool nv = n < wr1;
       const int nc = nv ? n : wr1 - 1;
       w4[st] = rb_noisy4(rb_ld4(a.w.mu + (int64_t)nc * K + col4), rb_ld4(a.w.sigma + (int64_t)nc * K + col4),
                          a.w.eout[nc], nc >= pr.ein_split_row ? e1 : e0);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MTC; ++mt) {
         const int m = m0 + 16 * mt + c;
         av[st][mt] = (mt < mt_cnt && nv && m < a.M) ? (a.dyT ? a.dyT[(int64_t)n * a.ldyT + m] : a.dy[(int64_t)m * a.ldy + n]) : 0.0f;
       }
     }
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < ST; ++st) {
       if (nb + 4 * st < wr1) {                             // wave-uniform
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MTC; ++mt) {
           if (mt < mt_cnt) {
             acc[mt][0] = rb_mfma16(av[st][mt], w4[st].x, acc[mt][0]);
             acc[mt][1] = rb_mfma16(av[st][mt], w4[st].y, acc[mt][1]);
@@ -350,7 +356,7 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
   // sets how many workgroups of the fused backward launch a CU holds)
   if (wave >= 2) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -359,7 +365,7 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
   __syncthreads();
   if (wave < 2) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -368,7 +374,7 @@ __device__ __forceinline__ void rb_nl_dx_body(const NlDxArgs& a, int bx, int by,
   __syncthreads();
   if (wave < 2) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -573,6 +579,7 @@ struct NlDwArgs {
   const float *eout, *ein;
   float* sq_part;            // optional: one slot per (block, wave) receiving the sum of squares of what that wave wrote
                              // (feeds clip_grad_norm_ without another pass over the 27 MB gradient)
+  int deep;                  // ct == 4: every tile's operands in flight before the first MFMA (rb_nl_dw_body_pipe_all)
   int ct;                    // > 0: pipelined body, `ct` column tiles per wave (M <= 32); 0: one tile per wave;
                              // < 0: the LDS-shared 64 x 64 tile body for large M (rb_nl_dw_body_wide)
   int no_sigma;              // 1: g_sigma is formed for the sum of squares only and NOT stored (the hosted optimiser pass forms it
@@ -889,13 +896,113 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe(const NlDwArgs& a, int bx, in
     if (lane == 0) a.sq_part[slot_base + wave] = sq;
   }
 }
+// ... with the operands of ALL CT column tiles of a wave requested before the first MFMA (RB_OPTS h_dw_deep): the one-tile-ahead
+// form above turns a tile every ~3.3 us (13.2 us for the hidden layer's four: a round trip beside the launch's 39 MB is longer than
+// a tile's 40 MFMAs), this one pays the trip once.  Same tiles, same order inside a tile: bit-identical gradients and norm partials.
+template <int CT>
+__device__ __forceinline__ void rb_nl_dw_body_pipe_all(const NlDwArgs& a, int bx, int by, int slot_base) {
+  const int lane = rb_lane(), wave = rb_wave();
+  constexpr int ct = CT;
+  const int kt0 = bx * ct * 256 + wave * 64;
+  if (kt0 >= a.K) {                                      // wave-uniform, no barriers below
+    if (a.sq_part && lane == 0) a.sq_part[slot_base + wave] = 0.0f;
+    return;
+  }
+  const int g = (a.n_prob > 1 && by >= a.prob[1].tile_begin) ? 1 : 0;
+  const NlDwProblem pr = a.prob[g];
+  const int row0 = pr.row_begin + (by - pr.tile_begin) * 16;
+  const int row_end = pr.row_begin + pr.row_cnt;
+  const int c = lane & 15, q = lane >> 4;
+  int arow = row0 + c;
+  const bool av_ok = arow < row_end;
+  if (!av_ok) arow = row_end - 1;
+  float eo4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = row0 + 4 * q + e;
+    eo4[e] = a.eout[n < row_end ? n : row_end - 1];
+  }
+  float avs[8];
+  const float* xrow[8];
+  float xmask[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int m = 4 * st + q;
+    const bool mv = m < a.M;
+    const int mcl = mv ? m : a.M - 1;
+    avs[st] = (mv && av_ok) ? a.dy[(int64_t)mcl * a.ldy + arow] : 0.0f;
+    xrow[st] = a.x + (int64_t)mcl * a.ldx + pr.x_off;
+    xmask[st] = mv ? 1.0f : 0.0f;
+  }
+  auto col_of = [&](int j) { int col4 = kt0 + j * 256 + 4 * c; return col4 < a.K ? col4 : a.K - 4; };
+  float4 xa[CT][8], ea[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {                         // (clamped: always a legal address)
+    const int col4 = col_of(j);
+    ea[j] = rb_ld4(a.ein + pr.ein_off + col4);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) xa[j][st] = rb_ld4(xrow[st] + col4);
+  }
+  float sq = 0.0f;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int kt = kt0 + j * 256;
+    if (kt >= a.K) break;                                // wave-uniform
+    const float4 e4 = ea[j];
+    const float4 (&xs)[8] = xa[j];
+    const bool cv = kt + 4 * c < a.K;
+    const int col4 = col_of(j);
+    const bool do_bias = kt == 0;
+    rb_f32x4 acc[4], accb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { accb[e] = 0.0f; acc[0][e] = 0.0f; acc[1][e] = 0.0f; acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      if (4 * st < a.M) {                                // uniform
+        acc[0] = rb_mfma16(avs[st], xs[st].x * xmask[st], acc[0]);
+        acc[1] = rb_mfma16(avs[st], xs[st].y * xmask[st], acc[1]);
+        acc[2] = rb_mfma16(avs[st], xs[st].z * xmask[st], acc[2]);
+        acc[3] = rb_mfma16(avs[st], xs[st].w * xmask[st], acc[3]);
+        if (do_bias) accb = rb_mfma16(avs[st], 1.0f, accb);   // wave-uniform
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = row0 + 4 * q + e;
+      if (n < row_end) {
+        const float eo = eo4[e];
+        if (cv) {
+          float4 gm, gs;
+          gm.x = acc[0][e]; gm.y = acc[1][e]; gm.z = acc[2][e]; gm.w = acc[3][e];
+          gs.x = gm.x * (eo * e4.x); gs.y = gm.y * (eo * e4.y); gs.z = gm.z * (eo * e4.z); gs.w = gm.w * (eo * e4.w);
+          if (!a.norm_only) {                            // wave-uniform
+            rb_st4(a.g_mu + (int64_t)n * a.K + col4, gm);
+            if (!a.no_sigma) rb_st4(a.g_sigma + (int64_t)n * a.K + col4, gs);
+          }
+          sq = fmaf(gm.x, gm.x, sq); sq = fmaf(gm.y, gm.y, sq); sq = fmaf(gm.z, gm.z, sq); sq = fmaf(gm.w, gm.w, sq);
+          sq = fmaf(gs.x, gs.x, sq); sq = fmaf(gs.y, gs.y, sq); sq = fmaf(gs.z, gs.z, sq); sq = fmaf(gs.w, gs.w, sq);
+        }
+        if (do_bias && c == 0) {
+          const float gb = accb[e], gbs = accb[e] * eo;
+          a.g_bmu[n] = gb;
+          a.g_bsigma[n] = gbs;
+          sq = fmaf(gb, gb, sq); sq = fmaf(gbs, gbs, sq);
+        }
+      }
+    }
+  }
+  if (a.sq_part) {                                        // wave-uniform
+    sq = rb_wave_sum(sq);
+    if (lane == 0) a.sq_part[slot_base + wave] = sq;
+  }
+}
 // the wide body as a launch of its own: inside k_nl_bwd it would inherit that kernel's register allocation (145 + 64: two
 // workgroups per CU), and with 8 short chunks per workgroup it is latency-bound — it wants many resident workgroups
 
 // Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in
 // ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
 // the dX tiles.
-struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; int dx_narrow; };   // dx_narrow (TALL only): 32-column input-gradient tiles
+struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; int dx_narrow; };   // dx_narrow: TALL: 32-column input-gradient tiles; else: rb_nl_dx_body<2, 8> (batch <= 32, deep loads)
 // Optional third tenant of the output layer's backward launch: the sum-tree priority write-back (agent.py:100,
 // memory.py:157-159).  It depends only on (tree indices, per-sample loss), both final before this launch, and is a
 // single-workgroup latency chain — as one more block here it costs nothing on the step's critical path.
@@ -965,7 +1072,8 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
     if (TALL && threadIdx.x >= 256) return;              // the weight-gradient bodies are 4-wave bodies (their barriers count
                                                          // the waves that are still alive)
     RB_SPAN_BEGIN(sb + 1);
-    if (dw.ct > 0) rb_nl_dw_body_pipe(dw, b % g.dw_x, b / g.dw_x, 4 * b);
+    if (dw.ct == 4 && dw.deep) rb_nl_dw_body_pipe_all<4>(dw, b % g.dw_x, b / g.dw_x, 4 * b);     // block-uniform
+    else if (dw.ct > 0) rb_nl_dw_body_pipe(dw, b % g.dw_x, b / g.dw_x, 4 * b);
     else rb_nl_dw_body(dw, b % g.dw_x, b / g.dw_x, 4 * b);
     RB_SPAN_END(sb + 1);
     RB_WGT_ROLE(kid, wgb, 1);
@@ -976,7 +1084,8 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
       if (g.dx_narrow) rb_nl_dx_body_tall<2>(dx, r % g.dx_x, r / g.dx_x, lds);      // block-uniform
       else rb_nl_dx_body_tall<4>(dx, r % g.dx_x, r / g.dx_x, lds);
     }
-    else rb_nl_dx_body(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
+    else if (g.dx_narrow) rb_nl_dx_body<2, 8>(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);   // block-uniform
+    else rb_nl_dx_body<4, 4>(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     RB_SPAN_END(sb + 2);
     RB_WGT_ROLE(kid, wgb, 2);
   }
