@@ -157,6 +157,8 @@ class FactoredExchange:
             self.lib.rb_learner_set_exchange(self.h, 1, None, None)
             self.h = None
         if getattr(self, "comm", None):
+            if getattr(self, "cuda", False):
+                torch.cuda.synchronize(self.local.device)      # an all-gather may still be in flight on the learn call's stream
             self.lib.rb_comm_destroy(self.comm)
             self.comm = None
 
