@@ -165,6 +165,7 @@ struct rb_learner {
   // fallback block order onto small fixtures — conv_multi (-1 = by image count), conv_full, dx_ipb (0 = by batch), img_fast
   int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance, opt_wt_blocks;
   int opt_h_dw_deep;    // ... and its weight gradient with all four column tiles' operands in flight (rb_nl_dw_body_pipe_all)
+  int opt_z_deep;       // the output layer's input gradient at batch > 32 with 8 row-steps of loads in flight (rb_nl_dx_body<4, 8>)
   int opt_h_deep;       // the hidden layer's input gradient at batch <= 32 with 8 row-steps of loads in flight (rb_nl_dx_body<2, 8>)
   int opt_z_ct, opt_h_ct;   // column tiles per wave of the pipelined weight-gradient body (output / hidden layer)
   int opt_z_narrow;     // ... on 32-column tiles (rb_nl_dx_body_tall<2>)
@@ -1533,6 +1534,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_z_narrow = rb_opt("z_narrow", 1);
   l->opt_h_deep = rb_opt("h_deep", 1);
+  l->opt_z_deep = rb_opt("z_deep", 1);
   l->opt_h_dw_deep = rb_opt("h_dw_deep", 1);
   l->opt_z_ct = rb_opt("z_ct", 2); if (l->opt_z_ct < 1) l->opt_z_ct = 1;
   l->opt_h_ct = rb_opt("h_ct", 4); if (l->opt_h_ct < 1) l->opt_h_ct = 1;
@@ -2048,7 +2050,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     const int z_tall = (l->opt_z_tall && B <= 32) ? 1 : 0;
     // ... on 32-column tiles (RB_OPTS z_narrow=0: 64-column tiles): twice the workgroups, half the weight bytes through each CU
     const int z_narrow = (z_tall && l->opt_z_narrow && (L.H % 32) == 0) ? 1 : 0;
-    NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, z_narrow ? 32 : 64), 1, 2 * (int)rb_div_up(B, 64), z_narrow};
+    NlBwdGrid zg{exch ? 0 : zp.dw_x, exch ? 0 : vt + at, (int)rb_div_up(L.H, z_narrow ? 32 : 64), 1, 2 * (int)rb_div_up(B, 64), z_tall ? z_narrow : (l->opt_z_deep ? 2 : 0)};
     // ---- hidden layer
     NlDxArgs hx;
     hx.dy = l->dh; hx.ldy = 2 * L.H; hx.M = B; hx.w = nl_h(on); hx.K = L.F; hx.n_prob = 1;

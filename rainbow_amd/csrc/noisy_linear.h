@@ -632,28 +632,52 @@ __device__ __forceinline__ void rb_nl_dw_body(const NlDwArgs& a, int bx, int by,
     const int n = row0 + 4 * q + e;
     eo4[e] = a.eout[n < row_end ? n : row_end - 1];
   }
-  for (int mb = 0; mb < a.M; mb += 32) {                  // 8 reduction steps of loads in flight per iteration
-    float avs[8];
-    float4 xs[8];
+  // 8 reduction steps (32 samples) of loads per trip, and the NEXT trip's loads requested before this trip's MFMAs: at batch 256 the
+  // eight trips were eight dependent round trips (13.3 of the output layer's 14.4 us backward launch, round6_wg_timeline_b256.txt).
+  // Same MFMAs in the same order: bit-identical.
+  auto issue = [&](int mb, float (&avs)[8], float4 (&xs)[8]) {
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       const int m = mb + 4 * st + q;
       const bool mv = m < a.M;
       const int mcl = mv ? m : a.M - 1;
-      avs[st] = (mv && av_ok) ? a.dy[(int64_t)mcl * a.ldy + arow] : 0.0f;
+      avs[st] = a.dy[(int64_t)mcl * a.ldy + arow];
       xs[st] = rb_ld4(a.x + (int64_t)mcl * a.ldx + pr.x_off + col4);
-      if (!mv) { xs[st].x = 0.0f; xs[st].y = 0.0f; xs[st].z = 0.0f; xs[st].w = 0.0f; }
     }
+  };
+  auto mfmas = [&](int mb, const float (&avs)[8], const float4 (&xs)[8]) {
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       if (mb + 4 * st < a.M) {                             // uniform
-        acc[0] = rb_mfma16(avs[st], xs[st].x, acc[0]);
-        acc[1] = rb_mfma16(avs[st], xs[st].y, acc[1]);
-        acc[2] = rb_mfma16(avs[st], xs[st].z, acc[2]);
-        acc[3] = rb_mfma16(avs[st], xs[st].w, acc[3]);
-        if (do_bias) accb = rb_mfma16(avs[st], 1.0f, accb);   // wave-uniform
+        const bool mv = mb + 4 * st + q < a.M;
+        const float av = (mv && av_ok) ? avs[st] : 0.0f;
+        const float4 x = xs[st];
+        acc[0] = rb_mfma16(av, mv ? x.x : 0.0f, acc[0]);
+        acc[1] = rb_mfma16(av, mv ? x.y : 0.0f, acc[1]);
+        acc[2] = rb_mfma16(av, mv ? x.z : 0.0f, acc[2]);
+        acc[3] = rb_mfma16(av, mv ? x.w : 0.0f, acc[3]);
+        if (do_bias) accb = rb_mfma16(av, 1.0f, accb);      // wave-uniform
       }
     }
+  };
+  {
+    float avs0[8], avs1[8];
+    float4 xs0[8], xs1[8];
+#if defined(RB_DW_NOPRE)                                   // (A/B build: one trip at a time)
+    for (int mb = 0; mb < a.M; mb += 32) { issue(mb, avs0, xs0); mfmas(mb, avs0, xs0); }
+    (void)avs1; (void)xs1;
+#else
+    issue(0, avs0, xs0);
+    for (int mb = 0; mb < a.M; mb += 64) {
+      const bool second = mb + 32 < a.M;                   // uniform
+      if (second) issue(mb + 32, avs1, xs1);
+      mfmas(mb, avs0, xs0);
+      if (second) {
+        if (mb + 64 < a.M) issue(mb + 64, avs0, xs0);
+        mfmas(mb + 32, avs1, xs1);
+      }
+    }
+#endif
   }
   float sq = 0.0f;
 #pragma unroll
@@ -1002,7 +1026,7 @@ __device__ __forceinline__ void rb_nl_dw_body_pipe_all(const NlDwArgs& a, int bx
 // Horizontal fusion: the weight-gradient and the input-gradient of one layer are independent given dY, so both run in
 // ONE launch (one ~5 us kernel boundary less on the critical path).  Blocks [0, dw_x*dw_y) take the dW tiles, the rest
 // the dX tiles.
-struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; int dx_narrow; };   // dx_narrow: TALL: 32-column input-gradient tiles; else: rb_nl_dx_body<2, 8> (batch <= 32, deep loads)
+struct NlBwdGrid { int dw_x, dw_y, dx_x, dx_y, dx_z; int dx_narrow; };   // dx_narrow: TALL: 32-column input-gradient tiles; else: 1 = rb_nl_dx_body<2, 8> (batch <= 32), 2 = <4, 8>: deep loads
 // Optional third tenant of the output layer's backward launch: the sum-tree priority write-back (agent.py:100,
 // memory.py:157-159).  It depends only on (tree indices, per-sample loss), both final before this launch, and is a
 // single-workgroup latency chain — as one more block here it costs nothing on the step's critical path.
@@ -1084,7 +1108,8 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
       if (g.dx_narrow) rb_nl_dx_body_tall<2>(dx, r % g.dx_x, r / g.dx_x, lds);      // block-uniform
       else rb_nl_dx_body_tall<4>(dx, r % g.dx_x, r / g.dx_x, lds);
     }
-    else if (g.dx_narrow) rb_nl_dx_body<2, 8>(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);   // block-uniform
+    else if (g.dx_narrow == 2) rb_nl_dx_body<4, 8>(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);   // block-uniform
+    else if (g.dx_narrow) rb_nl_dx_body<2, 8>(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     else rb_nl_dx_body<4, 4>(dx, r % g.dx_x, (r / g.dx_x) % g.dx_y, r / (g.dx_x * g.dx_y), lds);
     RB_SPAN_END(sb + 2);
     RB_WGT_ROLE(kid, wgb, 2);
