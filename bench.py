@@ -25,7 +25,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                     learner) timed on this box's host cores on a bounded sample (rank 0, N=1 only)
   library_source_hash — hash of the sources the loaded librainbow_hip.so was built from; must equal the tree's
 --no-profile: no HIP-event bracket anywhere (the run a rocprofv3 kernel trace should see).
-Runs shorter than 40 steps bracket 1 launch in (steps // 5) of the dominant kernel (at least 5 samples; else 1 in 8).
+Runs shorter than 24 steps bracket 1 launch in ceil(steps / 3) of the dominant kernel (three samples: an event pair idles the stream for
+≈ 13 µs — five pairs were 3.4 µs per step of a 20-step run); longer runs 1 in 8.
 """
 import argparse
 import ctypes as C
@@ -393,10 +394,11 @@ def main():
         probe = {k: bracketed(k, 30)[0] for k in ktab}
         kname = max((k for k in probe if probe[k] is not None), key=lambda k: probe[k])
     lib.rb_profile_select(kname.encode() if kname else None)
-    # 1 launch in 8 is bracketed inside a long timed region; a short one keeps at least 5 bracketed launches (a 20-step run:
-    # every fourth launch), so that `roofline` is never a 2- or 3-sample mean and `value` is not charged an event pair (~5 us
-    # of idle stream) per step; the launch's duration varies by < 1 us from launch to launch
-    stride = max(1, min(PROFILE_STRIDE, opt.steps // 5))       # >= 5 bracketed launches in any run of >= 5 steps (20 steps: every 4th)
+    # 1 launch in 8 is bracketed inside a long timed region; a short one keeps three bracketed launches (a 20-step run: launches
+    # 0, 7, 14).  An event pair idles the stream for ~13 us (round 6: five pairs in 20 steps read 161.75 us per step against 158.37
+    # without them), the launch's duration varies by < 1 us from launch to launch, and `frac` is priced with the larger of this
+    # mean and rocprofv3's own over 300 steps
+    stride = max(1, min(PROFILE_STRIDE, (opt.steps + 2) // 3))  # >= 3 bracketed launches in any run of >= 3 steps
     lib.rb_profile_stride(stride)
     if world > 1 or force_dist:
         torch.distributed.barrier()
