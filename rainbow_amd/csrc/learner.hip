@@ -166,6 +166,7 @@ struct rb_learner {
   int opt_conv_multi, opt_conv_multi_t16, opt_conv_full, opt_dx_ipb, opt_dx_t16, opt_img_fast, opt_finish_tiled, opt_dw_ipb[3], opt_dw_balance, opt_wt_blocks;
   int opt_h_dw_deep;    // ... and its weight gradient with all four column tiles' operands in flight (rb_nl_dw_body_pipe_all)
   int opt_z_deep;       // the output layer's input gradient at batch > 32 with 8 row-steps of loads in flight (rb_nl_dx_body<4, 8>)
+  int opt_wb_auto;      // the priority write-back inside the hidden layer's backward launch through rb_update_auto (sorted batch: one wave)
   int opt_h_deep;       // the hidden layer's input gradient at batch <= 32 with 8 row-steps of loads in flight (rb_nl_dx_body<2, 8>)
   int opt_z_ct, opt_h_ct;   // column tiles per wave of the pipelined weight-gradient body (output / hidden layer)
   int opt_z_narrow;     // ... on 32-column tiles (rb_nl_dx_body_tall<2>)
@@ -1534,6 +1535,7 @@ int rb_learner_create(rb_learner_t** out, const rb_learner_config_t* cfg, float*
   l->opt_z_tall = rb_opt("z_tall", 1);
   l->opt_z_narrow = rb_opt("z_narrow", 1);
   l->opt_h_deep = rb_opt("h_deep", 1);
+  l->opt_wb_auto = rb_opt("wb_auto", 1);
   l->opt_z_deep = rb_opt("z_deep", 1);
   l->opt_h_dw_deep = rb_opt("h_dw_deep", 1);
   l->opt_z_ct = rb_opt("z_ct", 2); if (l->opt_z_ct < 1) l->opt_z_ct = 1;
@@ -2066,7 +2068,7 @@ static int learn_impl(rb_learner_t* l, const ImgSrc& src, const uint8_t* states_
     // the write-back leaves this launch for the replay's stream (decided HERE, once: an expiry seen later only affects the next call)
     const bool spec = l->spec_now && l->sink && B <= 256 && !exch && rb_replay_spec_allowed(l->sink);
     if (l->sink && B <= 256 && !spec) {
-      up.enabled = 1; up.tree_idx = l->sink_idx; up.loss = loss_dev; up.n = B;
+      up.enabled = l->opt_wb_auto ? 2 : 1; up.tree_idx = l->sink_idx; up.loss = loss_dev; up.n = B;
       if (rb_replay_internal_view(l->sink, &up.view, &up.omega) != RB_OK) {
         rb_set_error("rb_learner_learn: bad priority sink");
         return RB_ERR_STATE;

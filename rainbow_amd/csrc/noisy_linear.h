@@ -1083,7 +1083,12 @@ __global__ __launch_bounds__(TALL ? 64 * RB_NL_DXT_WAVES : 256) void k_nl_bwd(Nl
       RB_SPAN_BEGIN(sb + 0);
       // (the one-wave sorted write-back of k_update measured no faster HERE — same-box A/B of two builds on all three configs:
       // 160.9 / 103.5 / 498.5 against 161.4 / 103.0 / 497.8 us per step — this block is not the launch's long pole)
-      rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // n <= 256
+      // enabled == 2 (RB_OPTS wb_auto, default): a sorted batch of <= 64 leaves — what the sampler hands back — on ONE wave without LDS
+      // tables or workgroup barriers (rb_update_sorted_wave), anything else through the hashed body.  Round 4 measured no gain from it
+      // HERE, when the input-gradient tiles were this launch's pole; since round 6's deeper bodies the write-back is (17.0 us hashed,
+      // round6_final_wg_timeline_b32.txt).  Same tree, bit for bit, either way.
+      if (up.enabled == 2) rb_update_auto<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);   // block-uniform
+      else rb_update_body<512, 256>(up.view, up.tree_idx, up.loss, up.n, 1, up.omega, lds);     // n <= 256
       RB_SPAN_END(sb + 0);
       RB_WGT_ROLE(kid, wgb, 0);
       RB_WGT(kid, wgb, 6);
