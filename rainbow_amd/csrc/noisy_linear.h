@@ -167,8 +167,20 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
       for (int mt = 0; mt < MT; ++mt) r_x[d][h][mt] = rb_ld4_buf(bx, xo[mt], so);
     }
   };
+  // EXACT: no ring slot is ever loaded with a block past the wave's range (round 6: the clamped duplicates — the output layer's 2 blocks
+  // per wave in a ring of 4, the 3-4 refills of the hidden layer's last round — were a fifth to a half of what a workgroup pulled
+  // through its CU: fc_h 15.7 -> 15.0 us, fc_z 6.1 -> 5.1 us; the 64-row form of batch 256 measured 1 us slower with it and keeps the
+  // clamped loads, as does an -DRB_FWD_CLAMPED_REFILLS build)
+#if defined(RB_FWD_CLAMPED_REFILLS)
+  constexpr bool EXACT = false;
+#else
+  constexpr bool EXACT = MT <= 2;
+#endif
 #pragma unroll
-  for (int d = 0; d < RING; ++d) { load_w(d, blk_of(d)); load_x(d, blk_of(d)); }
+  for (int d = 0; d < RING; ++d) {
+    if (!EXACT) { load_w(d, blk_of(d)); load_x(d, blk_of(d)); }
+    else if (d < nsc) { load_w(d, b0 + d); load_x(d, b0 + d); }   // wave-uniform
+  }
   __syncthreads();                                       // eps_in visible
   auto compute = [&](int d, int b) {
     const float4 e4 = *reinterpret_cast<const float4*>(&s_ein[b * 32 + 4 * lk]);
@@ -191,7 +203,9 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
     }
   };
   const int full = nsc / RING * RING;
-  for (int sc0 = 0; sc0 < full; sc0 += RING) {
+  // EXACT: the LAST full round refills only the slots the tail will consume (nsc - full of RING); else every round refills every slot
+  const int steady = !EXACT ? full : full >= RING ? full - RING : 0;
+  for (int sc0 = 0; sc0 < steady; sc0 += RING) {
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
       const int sc = sc0 + d;
@@ -202,6 +216,20 @@ __global__ __launch_bounds__(64 * RB_NL_FWD_WAVES) void k_nl_fwd3(NlFwd2Args a) 
       load_x(d, blk_of(sc + RING));                      // ... and its activation half, once the MFMAs have read it
       rb_wave_sync();                                    // tile reads done before the next block overwrites it
       RB_SCHED_FENCE();                                  // keep this slot's refill here, not at the end of the loop
+    }
+  }
+  if (steady < full) {                                   // wave-uniform: the last full round
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+      const int sc = steady + d;
+      const bool refill = sc + RING < nsc;               // wave-uniform
+      compute(d, b0 + sc);
+      if (refill) load_w(d, b0 + sc + RING);
+      rb_wave_sync();
+      mfmas(d);
+      if (refill) load_x(d, b0 + sc + RING);
+      rb_wave_sync();
+      RB_SCHED_FENCE();
     }
   }
 #pragma unroll
